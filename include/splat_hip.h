@@ -1,0 +1,126 @@
+/*
+ * splat_hip.h -- C ABI of libsplat_hip.so, the MI355X (gfx950) drop-in for the
+ * rasterisation hot path of thomasantony/splat.
+ *
+ * The reference has no FFI; its operator surface for this path is the Rust API
+ *     GaussianSplatPipeline01::render_to_buffer(&self, &mut euc::Buffer<u32,2>)   src/pipelines.rs:66-86
+ *     GaussianSplatPipeline02::render_to_buffer(...)                              src/pipelines.rs:260-280
+ * which internally runs sort (src/gaussians.rs:297-306, 464-471), the euc vertex
+ * stage (src/pipelines.rs:96-125 / 184-213 -> src/gaussians.rs:40-99, 114-161,
+ * 473-522; src/pipelines.rs:17-51), euc's triangle rasteriser, fragment
+ * (src/pipelines.rs:127-145) and blend (src/pipelines.rs:147-168).
+ * The entry points below are what a Rust `extern "C"` block in that crate binds
+ * (INTEGRATION.md shows the stub); every signature uses plain pointers and sizes.
+ *
+ * Conventions: all matrices column-major f32 (nalgebra storage); pixels are
+ * 0xAARRGGBB u32, row-major, `w*h` of them; every function returns SPLAT_OK or
+ * a negative error code and never throws/unwinds across the boundary;
+ * splat_last_error() gives the message.  One splat_ctx per host thread/GPU.
+ */
+#ifndef SPLAT_HIP_H
+#define SPLAT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPLAT_OK 0
+#define SPLAT_ERR_INVALID (-1)   /* bad argument                                          */
+#define SPLAT_ERR_HIP (-2)       /* HIP runtime error (no device, OOM, launch failure)    */
+#define SPLAT_ERR_NO_SCENE (-3)  /* render before upload                                  */
+#define SPLAT_ERR_CAPACITY (-4)  /* (Gaussian,tile) pair buffer could not be grown        */
+
+#define SPLAT_TILE 16            /* 16x16 pixel tiles                                     */
+
+/* composite modes */
+#define SPLAT_MODE_EXACT 0       /* back-to-front, 8-bit truncation per splat: bit-faithful to blend() */
+
+typedef struct splat_ctx splat_ctx;
+
+typedef struct {
+    int32_t device;        /* HIP device ordinal                                          */
+    int32_t mode;          /* SPLAT_MODE_*                                                */
+    /* euc conventions; splat_default_config() documents defaults  */
+    int32_t y_up;          /* 1: NDC +y is row 0                                          */
+    int32_t sample_half;   /* 1: sample at pixel centres                                  */
+    int32_t zclip;         /* 1: cull quads with ndc.z outside [zmin,zmax]                */
+    float zmin, zmax;
+    uint64_t pair_capacity;/* initial (Gaussian,tile) pair capacity; 0 = auto; grows      */
+} splat_config;
+
+/* Per-frame constants = what Camera's getters return (src/camera.rs:70-93). */
+typedef struct {
+    float view[16];        /* Camera::get_view_matrix                                     */
+    float proj[16];        /* Camera::get_project_matrix                                  */
+    float w, h;            /* Camera::w, Camera::h                                        */
+    float htanx, htany, focal; /* Camera::get_htanfovxy_focal                             */
+    float cam_pos[3];      /* Camera::position (the field, src/pipelines.rs:99)           */
+    float lowpass;         /* 0.01 for Pipeline01 (gaussians.rs:156), 0.3 for Pipeline02 (:517) */
+    int32_t sh_dim;        /* 15 at both call sites (src/pipelines.rs:100,189)            */
+} splat_camera;
+
+typedef struct {
+    uint64_t n_gaussians;
+    uint64_t n_visible;    /* Gaussians with >= 1 covered sample in this context's slab    */
+    uint64_t n_singular;   /* det(cov2d) == 0: skipped (the reference panics, pipelines.rs:22) */
+    uint64_t n_pairs;      /* D = (visible Gaussian, tile) overlaps                        */
+    uint64_t max_tile_len; /* longest per-tile list                                        */
+    uint64_t bytes_algorithmic; /* N*148 + n_visible*48 + D*60 + w*h*4   */
+    /* device time of the last frame per kernel, ms (HIP events on the context's stream)  */
+    float ms_preprocess, ms_scan, ms_emit, ms_sort, ms_composite, ms_total;
+} splat_stats;
+
+/* Projected per-Gaussian record as the kernels keep it (debug / stage parity). */
+typedef struct {
+    float cx, cy, hx, hy;           /* quad centre and 3-sigma half extents, pixels        */
+    float conic_a, conic_b, conic_c, opacity;
+    float r, g, b, depth;           /* SH colour + 0.5 (unclamped); view-space z           */
+    int32_t px0, px1, py0, py1;     /* exactly covered inclusive pixel range; px0>px1 = culled */
+} splat_record;
+
+void splat_default_config(splat_config* cfg);
+int splat_create(const splat_config* cfg, splat_ctx** out);
+void splat_destroy(splat_ctx* ctx);
+const char* splat_last_error(const splat_ctx* ctx);   /* ctx may be NULL: last create() error */
+
+/* Scene upload: exactly GaussianList's buffers (src/gaussians.rs:408-416):
+ * pos4 = positions.as_slice() (4n: x,y,z,1), cov3d = 3x3 column-major blocks (9n),
+ * opacity (n), sh (48n, f_dc then f_rest un-transposed).  Host pointers; copied. */
+int splat_upload_scene(splat_ctx* ctx, uint64_t n, const float* pos4, const float* cov3d,
+                       const float* opacity, const float* sh);
+
+/* compute_cov3d (src/gaussians.rs:101-113, 446-462) on the GPU.  scales3 (3n, already exp'd),
+ * rot4 (4n, nalgebra coords order i,j,k,w, un-normalised), cov3d_out (9n).  Host pointers. */
+int splat_compute_cov3d(splat_ctx* ctx, uint64_t n, const float* scales3, const float* rot4,
+                        float* cov3d_out);
+
+/* Restrict rendering to tile rows [tile_row0, tile_row1) (multi-GPU slabs); (0,-1) = all. */
+int splat_set_slab(splat_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
+
+/* render_to_buffer: blends the scene onto `argb` (in/out, host, w*h u32).  stats may be NULL. */
+int splat_render(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb, splat_stats* stats);
+
+/* Same with a device-resident image (in/out, w*h u32 in HBM).  Work is enqueued on the
+ * context's stream; with sync != 0 (or stats != NULL) the call waits for completion. */
+int splat_render_device(splat_ctx* ctx, const splat_camera* cam, void* d_argb, int32_t sync,
+                        splat_stats* stats);
+int splat_sync(splat_ctx* ctx);                       /* wait + report deferred errors */
+void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */
+/* Run on a caller-owned hipStream_t (e.g. the stream a device image / RCCL gather lives on). */
+int splat_set_stream(splat_ctx* ctx, void* hip_stream);
+/* Accumulated per-kernel device time since the last reset, from HIP events recorded on the
+ * context's stream around every launch: ms[0..5] = preprocess, scan, emit, sort, composite,
+ * status read-back; *frames = frames accumulated.  Waits for outstanding frames. */
+int splat_get_timing(splat_ctx* ctx, double ms[6], uint64_t* frames, int32_t reset);
+
+/* Debug / stage parity: results of the last frame. */
+int splat_get_records(splat_ctx* ctx, splat_record* out, uint64_t n);
+/* tile_offsets: n_tiles+1 entries (slab-local tiles, row-major); order: n_pairs Gaussian indices,
+ * each tile's list in blend order (far -> near). Pass NULL to query sizes via stats. */
+int splat_get_tile_lists(splat_ctx* ctx, uint32_t* tile_offsets, uint64_t n_offsets, uint32_t* order,
+                         uint64_t n_order);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,11 @@
+"""splat_amd -- MI355X-native drop-in for the rasterisation hot path of thomasantony/splat.
+
+Host-side mirror of the reference's operator interface (`Camera`, `GaussianList`,
+`GaussianSplatPipeline01/02.render_to_buffer`) over the C ABI of libsplat_hip.so
+(include/splat_hip.h), whose kernels are hand-written HIP for gfx950.  There is no CPU
+fallback: anything that computes needs the built library and a GPU, and says so loudly.
+"""
+from .camera import Camera  # noqa: F401
+from .gaussians import GaussianList, naive_gaussians, load_from_ply, synthetic_scene, write_ply  # noqa: F401
+from .pipelines import GaussianSplatPipeline01, GaussianSplatPipeline02  # noqa: F401
+from .renderer import Renderer, SplatError  # noqa: F401

@@ -1,0 +1,79 @@
+"""ctypes binding of libsplat_hip.so (include/splat_hip.h).  Fails loudly if the library is
+missing: there is no fallback path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsplat_hip.so")
+
+SPLAT_OK, ERR_INVALID, ERR_HIP, ERR_NO_SCENE, ERR_CAPACITY = 0, -1, -2, -3, -4
+TILE = 16
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("mode", C.c_int32), ("y_up", C.c_int32), ("sample_half", C.c_int32),
+                ("zclip", C.c_int32), ("zmin", C.c_float), ("zmax", C.c_float), ("pair_capacity", C.c_uint64)]
+
+
+class CameraC(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("w", C.c_float), ("h", C.c_float),
+                ("htanx", C.c_float), ("htany", C.c_float), ("focal", C.c_float), ("cam_pos", C.c_float * 3),
+                ("lowpass", C.c_float), ("sh_dim", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_gaussians", C.c_uint64), ("n_visible", C.c_uint64), ("n_singular", C.c_uint64),
+                ("n_pairs", C.c_uint64), ("max_tile_len", C.c_uint64), ("bytes_algorithmic", C.c_uint64),
+                ("ms_preprocess", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float),
+                ("ms_sort", C.c_float), ("ms_composite", C.c_float), ("ms_total", C.c_float)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Record(C.Structure):
+    _fields_ = [("cx", C.c_float), ("cy", C.c_float), ("hx", C.c_float), ("hy", C.c_float),
+                ("conic_a", C.c_float), ("conic_b", C.c_float), ("conic_c", C.c_float), ("opacity", C.c_float),
+                ("r", C.c_float), ("g", C.c_float), ("b", C.c_float), ("depth", C.c_float),
+                ("px0", C.c_int32), ("px1", C.c_int32), ("py0", C.c_int32), ("py1", C.c_int32)]
+
+
+# every symbol include/splat_hip.h declares: (name, restype, argtypes)
+_fp = C.POINTER(C.c_float)
+SYMBOLS = [
+    ("splat_default_config", None, [C.POINTER(Config)]),
+    ("splat_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    ("splat_destroy", None, [C.c_void_p]),
+    ("splat_last_error", C.c_char_p, [C.c_void_p]),
+    ("splat_upload_scene", C.c_int, [C.c_void_p, C.c_uint64, _fp, _fp, _fp, _fp]),
+    ("splat_compute_cov3d", C.c_int, [C.c_void_p, C.c_uint64, _fp, _fp, _fp]),
+    ("splat_set_slab", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("splat_render", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
+    ("splat_render_device", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p, C.c_int32, C.POINTER(Stats)]),
+    ("splat_sync", C.c_int, [C.c_void_p]),
+    ("splat_stream", C.c_void_p, [C.c_void_p]),
+    ("splat_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("splat_get_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),
+    ("splat_get_records", C.c_int, [C.c_void_p, C.POINTER(Record), C.c_uint64]),
+    ("splat_get_tile_lists", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32),
+                                        C.c_uint64]),
+]
+
+_LIB = None
+
+
+def lib():
+    """Load libsplat_hip.so.  Raises if it has not been built (__graft_entry__.build())."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "splat_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C splat_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)   # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB

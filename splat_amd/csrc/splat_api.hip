@@ -1,0 +1,466 @@
+// splat_api.hip -- C ABI (include/splat_hip.h) over the gfx950 kernels.  Host side only:
+// buffer ownership, per-frame constants, launch sequence, HIP-event timing, error reporting.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "splat_internal.h"
+
+using namespace splat;
+
+namespace {
+thread_local std::string g_create_error;
+constexpr int N_EV = 7;        // event boundaries: start, preprocess, scan, emit, sort, composite(+copy) ...
+constexpr int EV_RING = 32;
+
+struct EvSet {
+    hipEvent_t e[N_EV];
+    bool used = false;
+};
+}  // namespace
+
+struct splat_ctx {
+    splat_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // scene
+    uint64_t n = 0;
+    float4* planes = nullptr;
+    Rec* recs = nullptr;
+    float* depth = nullptr;
+    ushort4* rect = nullptr;
+    // binning
+    unsigned int* counts = nullptr;
+    unsigned int* offsets = nullptr;
+    unsigned int* cursor = nullptr;
+    unsigned int m_alloc = 0;
+    unsigned long long* keys = nullptr;
+    uint64_t cap = 0;
+    FrameStatus* d_status = nullptr;
+    FrameStatus* h_status = nullptr;   // pinned, one per ring slot
+    // host-image path
+    uint32_t* d_img = nullptr;
+    size_t img_cap = 0;
+    // slab
+    int slab0 = 0, slab1 = -1;
+    // timing
+    EvSet ring[EV_RING];
+    int ring_next = 0;
+    double acc_ms[N_EV - 1] = {0, 0, 0, 0, 0, 0};
+    uint64_t acc_frames = 0;
+    // last frame
+    FrameConst fc{};
+    unsigned int n_tiles = 0;
+    int last_slot = -1;
+    uint64_t overflow_want = 0;        // a harvested frame overflowed the pair buffer: grow to this
+    FrameStatus last{};
+    std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                             \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                            \
+            return SPLAT_ERR_HIP;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+int fail(splat_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+template <typename T>
+void dfree(T*& p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+void harvest(splat_ctx* c, int slot) {
+    EvSet& s = c->ring[slot];
+    if (!s.used) return;
+    (void)hipEventSynchronize(s.e[N_EV - 1]);
+    for (int k = 0; k + 1 < N_EV; ++k) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.e[k], s.e[k + 1]) == hipSuccess) c->acc_ms[k] += ms;
+    }
+    c->acc_frames++;
+    const FrameStatus& st = c->h_status[slot];
+    if (st.overflow) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
+    s.used = false;
+}
+
+int ensure_bins(splat_ctx* c, unsigned int m) {
+    if (m + 1 <= c->m_alloc) return SPLAT_OK;
+    dfree(c->counts); dfree(c->offsets); dfree(c->cursor);
+    c->m_alloc = 0;
+    HIP_TRY(c, hipMalloc(&c->counts, sizeof(unsigned int) * (size_t)(m + 1)));
+    HIP_TRY(c, hipMalloc(&c->offsets, sizeof(unsigned int) * (size_t)(m + 1)));
+    HIP_TRY(c, hipMalloc(&c->cursor, sizeof(unsigned int) * (size_t)(m + 1)));
+    HIP_TRY(c, hipMemsetAsync(c->counts, 0, sizeof(unsigned int) * (size_t)(m + 1), c->stream));
+    c->m_alloc = m + 1;
+    return SPLAT_OK;
+}
+
+int ensure_keys(splat_ctx* c, uint64_t want) {
+    if (want <= c->cap) return SPLAT_OK;
+    if (want >= 0xFFFFFFF0ull) return fail(c, SPLAT_ERR_CAPACITY, "pair count exceeds 2^32");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->keys);
+    c->cap = 0;
+    hipError_t e = hipMalloc(&c->keys, sizeof(unsigned long long) * want);
+    if (e != hipSuccess) return fail(c, SPLAT_ERR_CAPACITY, std::string("cannot allocate pair buffer: ") + hipGetErrorString(e));
+    c->cap = want;
+    return SPLAT_OK;
+}
+
+int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, unsigned int* n_tiles) {
+    if (!cam) return fail(c, SPLAT_ERR_INVALID, "camera is NULL");
+    if (!(cam->w >= 1.0f) || !(cam->h >= 1.0f) || cam->w > 65535.0f || cam->h > 65535.0f ||
+        cam->w != std::floor(cam->w) || cam->h != std::floor(cam->h))
+        return fail(c, SPLAT_ERR_INVALID, "camera w/h must be integers in [1, 65535]");
+    std::memcpy(fc->view, cam->view, sizeof fc->view);
+    std::memcpy(fc->proj, cam->proj, sizeof fc->proj);
+    fc->w = cam->w; fc->h = cam->h;
+    fc->htanx = cam->htanx; fc->htany = cam->htany; fc->focal = cam->focal;
+    fc->cam[0] = cam->cam_pos[0]; fc->cam[1] = cam->cam_pos[1]; fc->cam[2] = cam->cam_pos[2];
+    fc->lowpass = cam->lowpass; fc->sh_dim = cam->sh_dim;
+    fc->y_up = c->cfg.y_up; fc->sample_half = c->cfg.sample_half; fc->zclip = c->cfg.zclip;
+    fc->zmin = c->cfg.zmin; fc->zmax = c->cfg.zmax;
+    fc->W = (int)cam->w; fc->H = (int)cam->h;
+    fc->tiles_x = (fc->W + TILE - 1) / TILE;
+    int tiles_y = (fc->H + TILE - 1) / TILE;
+    int r0 = std::max(0, c->slab0), r1 = (c->slab1 < 0) ? tiles_y : std::min(c->slab1, tiles_y);
+    if (r1 < r0) r1 = r0;
+    fc->tile_row0 = r0; fc->n_tile_rows = r1 - r0;
+    fc->row_px0 = r0 * TILE; fc->row_px1 = std::min(r1 * TILE, fc->H);
+    *n_tiles = (unsigned int)(fc->tiles_x * fc->n_tile_rows);
+    return SPLAT_OK;
+}
+
+// Enqueue one frame on the stream (never blocks unless the event ring wraps onto a frame
+// that is still running, 32 frames behind).
+int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
+    const int slot = c->ring_next;
+    EvSet& ev = c->ring[slot];
+    c->ring_next = (c->ring_next + 1) % EV_RING;
+    harvest(c, slot);
+    const unsigned int m = c->n_tiles * SUB;
+    HIP_TRY(c, hipEventRecord(ev.e[0], c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(FrameStatus), c->stream));
+    launch_preprocess(c->stream, c->n, c->planes, c->fc, c->recs, c->depth, c->rect, c->counts, c->d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[1], c->stream));
+    launch_scan(c->stream, m, c->counts, c->offsets, c->cursor, c->d_status, c->cap);
+    HIP_TRY(c, hipEventRecord(ev.e[2], c->stream));
+    launch_emit(c->stream, c->n, c->fc, c->depth, c->rect, c->cursor, c->keys, c->d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[3], c->stream));
+    launch_sort(c->stream, c->n_tiles, c->offsets, c->keys, c->d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[4], c->stream));
+    launch_composite(c->stream, c->n_tiles, c->fc, c->offsets, c->keys, c->recs, d_argb, c->d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[5], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->h_status[slot], c->d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(ev.e[6], c->stream));
+    HIP_TRY(c, hipGetLastError());
+    ev.used = true;
+    c->last_slot = slot;
+    return SPLAT_OK;
+}
+
+// Wait for everything enqueued; returns SPLAT_ERR_CAPACITY (after growing the pair buffer) if a
+// frame overflowed it -- that frame's composite was skipped and it must be rendered again.
+int finish_frame(splat_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->last_slot >= 0) c->last = c->h_status[c->last_slot];
+    for (int k = 0; k < EV_RING; ++k) harvest(c, k);
+    if (c->overflow_want) {
+        uint64_t want = (uint64_t)((double)c->overflow_want * 1.25) + 1024;
+        c->overflow_want = 0;
+        int rc = ensure_keys(c, want);
+        if (rc != SPLAT_OK) return rc;
+        return fail(c, SPLAT_ERR_CAPACITY, "pair buffer overflowed; capacity grown, frame must be re-rendered");
+    }
+    return SPLAT_OK;
+}
+
+void fill_stats(splat_ctx* c, splat_stats* st) {
+    std::memset(st, 0, sizeof *st);
+    st->n_gaussians = c->n;
+    st->n_visible = c->last.n_visible;
+    st->n_singular = c->last.n_singular;
+    st->n_pairs = c->last.n_pairs;
+    st->max_tile_len = c->last.max_tile_len;
+    st->bytes_algorithmic = c->n * 148ull + c->last.n_visible * 48ull + c->last.n_pairs * 60ull +
+                            (uint64_t)c->fc.W * (uint64_t)(c->fc.row_px1 - c->fc.row_px0) * 4ull;
+    float t[N_EV - 1] = {0};
+    float tot = 0.f;
+    if (c->last_slot >= 0) {
+        EvSet& ev = c->ring[c->last_slot];   // events stay valid after harvest
+        for (int k = 0; k + 1 < N_EV; ++k) (void)hipEventElapsedTime(&t[k], ev.e[k], ev.e[k + 1]);
+        (void)hipEventElapsedTime(&tot, ev.e[0], ev.e[5]);
+    }
+    st->ms_preprocess = t[0]; st->ms_scan = t[1]; st->ms_emit = t[2]; st->ms_sort = t[3]; st->ms_composite = t[4];
+    st->ms_total = tot;
+}
+
+}  // namespace
+
+extern "C" {
+
+void splat_default_config(splat_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->device = 0;
+    cfg->mode = SPLAT_MODE_EXACT;
+    cfg->y_up = 1;          // pinned: notes/screenshot.png has the orientation of the notebook render
+    cfg->sample_half = 1;   // euc samples pixel centres (unpinned)
+    cfg->zclip = 1; cfg->zmin = 0.0f; cfg->zmax = 1.0f;   // euc CoordinateMode::VULKAN default (unpinned)
+    cfg->pair_capacity = 0;
+}
+
+int splat_create(const splat_config* cfg, splat_ctx** out) {
+    if (!out) return fail(nullptr, SPLAT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    splat_config def;
+    splat_default_config(&def);
+    if (!cfg) cfg = &def;
+    if (cfg->mode != SPLAT_MODE_EXACT) return fail(nullptr, SPLAT_ERR_INVALID, "unknown mode");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SPLAT_ERR_HIP, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, SPLAT_ERR_INVALID, "device ordinal out of range");
+    splat_ctx* c = new (std::nothrow) splat_ctx();
+    if (!c) return fail(nullptr, SPLAT_ERR_INVALID, "out of host memory");
+    c->cfg = *cfg;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        splat_destroy(c);
+        return SPLAT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    c->own_stream = true;
+    if ((e = hipMalloc(&c->d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
+    if ((e = hipHostMalloc(&c->h_status, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipHostMalloc(status)", e);
+    std::memset(c->h_status, 0, sizeof(FrameStatus) * EV_RING);
+    for (auto& s : c->ring)
+        for (auto& ev : s.e)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    *out = c;
+    return SPLAT_OK;
+}
+
+void splat_destroy(splat_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect);
+    dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->keys);
+    dfree(c->d_status); dfree(c->d_img);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    for (auto& s : c->ring)
+        for (auto& ev : s.e)
+            if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* splat_last_error(const splat_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+void* splat_stream(splat_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int splat_set_stream(splat_ctx* c, void* stream) {
+    if (!c) return SPLAT_ERR_INVALID;
+    int rc = finish_frame(c);
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+    return rc;
+}
+
+int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
+                       const float* sh) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (n && (!pos4 || !cov3d || !opacity || !sh)) return fail(c, SPLAT_ERR_INVALID, "NULL scene pointer");
+    if (n >= 0xFFFFFFFFull) return fail(c, SPLAT_ERR_INVALID, "too many Gaussians (index is 32-bit)");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    (void)finish_frame(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect);
+    c->n = 0;
+    if (n == 0) return SPLAT_OK;
+    float *d_pos = nullptr, *d_cov = nullptr, *d_op = nullptr, *d_sh = nullptr;
+    auto cleanup = [&] { dfree(d_pos); dfree(d_cov); dfree(d_op); dfree(d_sh); };
+    hipError_t e;
+#define UP_TRY(expr)                                                            \
+    if ((e = (expr)) != hipSuccess) {                                            \
+        cleanup();                                                               \
+        return fail(c, SPLAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e)); \
+    }
+    UP_TRY(hipMalloc(&c->planes, sizeof(float4) * SCENE_PLANES * n));
+    UP_TRY(hipMalloc(&c->recs, sizeof(Rec) * n));
+    UP_TRY(hipMalloc(&c->depth, sizeof(float) * n));
+    UP_TRY(hipMalloc(&c->rect, sizeof(ushort4) * n));
+    UP_TRY(hipMalloc(&d_pos, sizeof(float) * 4 * n));
+    UP_TRY(hipMalloc(&d_cov, sizeof(float) * 9 * n));
+    UP_TRY(hipMalloc(&d_op, sizeof(float) * n));
+    UP_TRY(hipMalloc(&d_sh, sizeof(float) * 48 * n));
+    UP_TRY(hipMemcpyAsync(d_pos, pos4, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream));
+    UP_TRY(hipMemcpyAsync(d_cov, cov3d, sizeof(float) * 9 * n, hipMemcpyHostToDevice, c->stream));
+    UP_TRY(hipMemcpyAsync(d_op, opacity, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    UP_TRY(hipMemcpyAsync(d_sh, sh, sizeof(float) * 48 * n, hipMemcpyHostToDevice, c->stream));
+    launch_pack_scene(c->stream, n, d_pos, d_cov, d_op, d_sh, c->planes);
+    UP_TRY(hipGetLastError());
+    UP_TRY(hipStreamSynchronize(c->stream));
+#undef UP_TRY
+    cleanup();
+    c->n = n;
+    if (c->cap == 0) {
+        uint64_t want = c->cfg.pair_capacity ? c->cfg.pair_capacity : std::max<uint64_t>(1ull << 22, 16 * n);
+        int rc = ensure_keys(c, want);
+        if (rc != SPLAT_OK) return rc;
+    }
+    return SPLAT_OK;
+}
+
+int splat_compute_cov3d(splat_ctx* c, uint64_t n, const float* scales3, const float* rot4, float* cov3d_out) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (n == 0) return SPLAT_OK;
+    if (!scales3 || !rot4 || !cov3d_out) return fail(c, SPLAT_ERR_INVALID, "NULL pointer");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    float *d_s = nullptr, *d_r = nullptr, *d_o = nullptr;
+    hipError_t e = hipSuccess;
+    int rc = SPLAT_OK;
+    do {
+        if ((e = hipMalloc(&d_s, sizeof(float) * 3 * n)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_r, sizeof(float) * 4 * n)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_o, sizeof(float) * 9 * n)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_s, scales3, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_r, rot4, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+        launch_cov3d(c->stream, n, d_s, d_r, d_o);
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(cov3d_out, d_o, sizeof(float) * 9 * n, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess) rc = fail(c, SPLAT_ERR_HIP, std::string("splat_compute_cov3d: ") + hipGetErrorString(e));
+    dfree(d_s); dfree(d_r); dfree(d_o);
+    return rc;
+}
+
+int splat_set_slab(splat_ctx* c, int32_t tile_row0, int32_t tile_row1) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (tile_row0 < 0 || (tile_row1 >= 0 && tile_row1 < tile_row0)) return fail(c, SPLAT_ERR_INVALID, "bad slab");
+    c->slab0 = tile_row0; c->slab1 = tile_row1;
+    return SPLAT_OK;
+}
+
+int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (!d_argb) return fail(c, SPLAT_ERR_INVALID, "d_argb is NULL");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc = SPLAT_OK;
+    if (c->n == 0 && !c->planes) {
+        // an empty scene renders nothing (the reference's loop body never runs)
+        if (stats) { c->last = FrameStatus{}; unsigned int nt; rc = build_frame_const(c, cam, &c->fc, &nt); if (rc) return rc; fill_stats(c, stats); }
+        return SPLAT_OK;
+    }
+    rc = build_frame_const(c, cam, &c->fc, &c->n_tiles);
+    if (rc != SPLAT_OK) return rc;
+    if (c->n_tiles == 0) { if (stats) { c->last = FrameStatus{}; fill_stats(c, stats); } return SPLAT_OK; }
+    rc = ensure_bins(c, c->n_tiles * SUB);
+    if (rc != SPLAT_OK) return rc;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        rc = enqueue_frame(c, (uint32_t*)d_argb);
+        if (rc != SPLAT_OK) return rc;
+        if (!sync && !stats) return SPLAT_OK;
+        rc = finish_frame(c);
+        if (rc == SPLAT_ERR_CAPACITY && c->cap > c->last.n_pairs) continue;   // grown: the frame was skipped, redo
+        break;
+    }
+    if (rc != SPLAT_OK) return rc;
+    if (stats) fill_stats(c, stats);
+    return SPLAT_OK;
+}
+
+int splat_render(splat_ctx* c, const splat_camera* cam, uint32_t* argb, splat_stats* stats) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (!argb || !cam) return fail(c, SPLAT_ERR_INVALID, "NULL argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    FrameConst fc; unsigned int nt;
+    int rc = build_frame_const(c, cam, &fc, &nt);
+    if (rc != SPLAT_OK) return rc;
+    size_t bytes = (size_t)fc.W * fc.H * 4;
+    if (bytes > c->img_cap) {
+        (void)finish_frame(c);
+        dfree(c->d_img); c->img_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_img, bytes));
+        c->img_cap = bytes;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_img, argb, bytes, hipMemcpyHostToDevice, c->stream));
+    rc = splat_render_device(c, cam, c->d_img, 1, stats);
+    if (rc != SPLAT_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(argb, c->d_img, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPLAT_OK;
+}
+
+int splat_sync(splat_ctx* c) {
+    if (!c) return SPLAT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    return finish_frame(c);
+}
+
+int splat_get_timing(splat_ctx* c, double ms_out[6], uint64_t* frames, int32_t reset) {
+    if (!c) return SPLAT_ERR_INVALID;
+    int rc = splat_sync(c);
+    if (rc != SPLAT_OK) return rc;
+    if (ms_out) for (int k = 0; k < N_EV - 1; ++k) ms_out[k] = c->acc_ms[k];
+    if (frames) *frames = c->acc_frames;
+    if (reset) { for (auto& v : c->acc_ms) v = 0; c->acc_frames = 0; }
+    return SPLAT_OK;
+}
+
+int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
+    if (!c || !out) return SPLAT_ERR_INVALID;
+    if (n != c->n) return fail(c, SPLAT_ERR_INVALID, "record count mismatch");
+    if (n == 0) return SPLAT_OK;
+    int rc = splat_sync(c);
+    if (rc != SPLAT_OK) return rc;
+    std::vector<Rec> r(n); std::vector<float> d(n); std::vector<ushort4> q(n);
+    HIP_TRY(c, hipMemcpy(r.data(), c->recs, sizeof(Rec) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(d.data(), c->depth, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(q.data(), c->rect, sizeof(ushort4) * n, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        splat_record& o = out[i];
+        o.cx = r[i].a.x; o.cy = r[i].a.y; o.hx = r[i].a.z; o.hy = r[i].a.w;
+        o.conic_a = r[i].b.x; o.conic_b = r[i].b.y; o.conic_c = r[i].b.z; o.opacity = r[i].b.w;
+        o.r = r[i].c.x; o.g = r[i].c.y; o.b = r[i].c.z; o.depth = d[i];
+        o.px0 = q[i].x; o.px1 = q[i].y; o.py0 = q[i].z; o.py1 = q[i].w;
+    }
+    return SPLAT_OK;
+}
+
+int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offsets, uint32_t* order, uint64_t n_order) {
+    if (!c) return SPLAT_ERR_INVALID;
+    int rc = splat_sync(c);
+    if (rc != SPLAT_OK) return rc;
+    if (n_offsets != (uint64_t)c->n_tiles + 1 || n_order != c->last.n_pairs)
+        return fail(c, SPLAT_ERR_INVALID, "tile list size mismatch");
+    std::vector<unsigned int> off((size_t)c->n_tiles * SUB + 1);
+    HIP_TRY(c, hipMemcpy(off.data(), c->offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost));
+    for (unsigned int t = 0; t <= c->n_tiles; ++t) tile_offsets[t] = off[(size_t)t * SUB];
+    if (n_order) {
+        std::vector<unsigned long long> k(n_order);
+        HIP_TRY(c, hipMemcpy(k.data(), c->keys, sizeof(unsigned long long) * n_order, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n_order; ++i) order[i] = (uint32_t)k[i];
+    }
+    return SPLAT_OK;
+}
+
+}  // extern "C"

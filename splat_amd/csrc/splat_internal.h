@@ -1,0 +1,65 @@
+// splat_internal.h -- shared between splat_api.hip (host) and splat_kernels.hip (gfx950 kernels).
+#ifndef SPLAT_INTERNAL_H
+#define SPLAT_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/splat_hip.h"
+
+namespace splat {
+
+constexpr int TILE = SPLAT_TILE;
+constexpr int SUB = 8;            // sub-buckets per tile: spreads same-address atomics over 8 words
+constexpr int SCENE_PLANES = 16;  // float4 planes per Gaussian (see pack_scene_kernel)
+constexpr int LIVE_PLANES = 10;   // planes read per frame at sh_dim <= 27 (160 B / Gaussian)
+
+// Everything a frame's kernels need, passed by value (kernarg -> SGPRs).
+struct FrameConst {
+    float view[16];
+    float proj[16];
+    float w, h;
+    float htanx, htany, focal;
+    float cam[3];
+    float lowpass;
+    int sh_dim;
+    int y_up, sample_half, zclip;
+    float zmin, zmax;
+    int W, H;              // integer target size
+    int tiles_x;           // tiles per row
+    int tile_row0;         // slab: first tile row
+    int n_tile_rows;       // slab: tile rows in this context
+    int row_px0, row_px1;  // slab pixel rows [row_px0, row_px1)
+};
+
+// Device-side frame status, read back once per frame.
+struct FrameStatus {
+    unsigned long long n_visible;
+    unsigned long long n_singular;
+    unsigned long long n_pairs;
+    unsigned int max_tile_len;
+    unsigned int overflow;   // 1: n_pairs > capacity, emit/sort/composite skipped
+};
+
+// 48-byte projected record (3 x float4), gathered by the compositor.
+struct Rec {
+    float4 a;   // cx, cy, hx, hy
+    float4 b;   // conic a, b, c, opacity
+    float4 c;   // r, g, b, power threshold (reserved)
+};
+
+void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
+                       const float* sh, float4* planes);
+void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d);
+void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, FrameConst fc, Rec* recs, float* depth,
+                       ushort4* rect, unsigned int* counts, FrameStatus* status);
+void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
+                 FrameStatus* status, unsigned long long capacity);
+void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect,
+                 unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
+void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, unsigned long long* keys,
+                 const FrameStatus* status);
+void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
+                      const unsigned long long* keys, const Rec* recs, uint32_t* argb, const FrameStatus* status);
+
+}  // namespace splat
+#endif

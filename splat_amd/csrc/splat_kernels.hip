@@ -1,0 +1,544 @@
+// splat_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the rasterisation hot
+// path of thomasantony/splat.  Compiled with -ffp-contract=off: the reference (Rust/nalgebra)
+// never fuses a*b+c, and image parity depends on the f32 operation order.
+//
+//   K0 cov3d_kernel       compute_cov3d                 src/gaussians.rs:101-113, 446-462
+//   K1 preprocess_kernel  Pipeline::vertex, once/Gaussian src/pipelines.rs:96-125, 17-51;
+//                                                       src/gaussians.rs:40-99, 114-161
+//   -- scan_kernel        per-(tile,sub-bucket) exclusive offsets
+//   K2 emit_kernel        instance expansion            src/pipelines.rs:69-79 (+ euc bbox clamp)
+//   K3 sort_tiles_*       per-tile painter's order      src/gaussians.rs:302-303 (stable asc. z)
+//   K4 composite_kernel   euc raster + fragment + blend src/pipelines.rs:127-168
+#include "splat_internal.h"
+
+namespace splat {
+
+// ---------------------------------------------------------------------------
+// small column-major matrix helpers; products accumulate left to right like
+// nalgebra's gemv-per-column (y_i = ((A_i0 x_0 + A_i1 x_1) + A_i2 x_2) + ...)
+// ---------------------------------------------------------------------------
+struct Mat3 { float m[9]; };
+#define M3(A, r, c) ((A).m[(c) * 3 + (r)])
+
+__device__ __forceinline__ Mat3 mat3_mul(const Mat3& a, const Mat3& b) {
+    Mat3 c;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float acc = M3(a, i, 0) * M3(b, 0, j);
+            acc = M3(a, i, 1) * M3(b, 1, j) + acc;
+            acc = M3(a, i, 2) * M3(b, 2, j) + acc;
+            M3(c, i, j) = acc;
+        }
+    return c;
+}
+__device__ __forceinline__ Mat3 mat3_t(const Mat3& a) {
+    Mat3 t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M3(t, i, j) = M3(a, j, i);
+    return t;
+}
+__device__ __forceinline__ void mat4_vec(const float* m, float x, float y, float z, float w, float out[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float acc = m[0 + i] * x;
+        acc = m[4 + i] * y + acc;
+        acc = m[8 + i] * z + acc;
+        acc = m[12 + i] * w + acc;
+        out[i] = acc;
+    }
+}
+__device__ __forceinline__ bool finitef(float v) { return fabsf(v) <= 3.402823466e+38f; }
+
+// ---------------------------------------------------------------------------
+// Scene packing (upload time).  GaussianList buffers -> 16 planes of float4, plane p of
+// Gaussian i at planes[p*n + i] so every per-frame load is a coalesced 16 B/lane stream.
+// Float slots: 0-2 xyz, 3 opacity, 4-12 cov3d (col-major 3x3, all nine: the reference's
+// R*S*R^T is not bit-symmetric), 13-39 sh[0..27), 40-60 sh[27..48), 61-63 zero.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_scene_kernel(uint64_t n, const float* __restrict__ pos4,
+                                                         const float* __restrict__ cov3d,
+                                                         const float* __restrict__ opacity,
+                                                         const float* __restrict__ sh, float4* __restrict__ planes) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float F[64];
+    F[0] = pos4[4 * i + 0]; F[1] = pos4[4 * i + 1]; F[2] = pos4[4 * i + 2]; F[3] = opacity[i];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) F[4 + k] = cov3d[9 * i + k];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) F[13 + k] = sh[48 * i + k];
+    F[61] = F[62] = F[63] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < SCENE_PLANES; ++p) planes[(uint64_t)p * n + i] = make_float4(F[4 * p], F[4 * p + 1], F[4 * p + 2], F[4 * p + 3]);
+}
+
+// K0 -- compute_cov3d, src/gaussians.rs:101-113.  rot = (i,j,k,w).
+__global__ __launch_bounds__(256) void cov3d_kernel(uint64_t n, const float* __restrict__ scales3,
+                                                    const float* __restrict__ rot4, float* __restrict__ out) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float q0 = rot4[4 * t], q1 = rot4[4 * t + 1], q2 = rot4[4 * t + 2], q3 = rot4[4 * t + 3];
+    // UnitQuaternion::from_quaternion: q / |q|, nalgebra 4-vector dot = (q0q0+q2q2)+(q1q1+q3q3)
+    float a = q0 * q0, b = q1 * q1, c = q2 * q2, d = q3 * q3;
+    a += c; b += d;
+    float nrm = sqrtf(a + b);
+    float i = q0 / nrm, j = q1 / nrm, k = q2 / nrm, w = q3 / nrm;
+    float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f;
+    float ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+    Mat3 R, S;
+    M3(R, 0, 0) = ww + ii - jj - kk; M3(R, 0, 1) = ij - wk;           M3(R, 0, 2) = wj + ik;
+    M3(R, 1, 0) = wk + ij;           M3(R, 1, 1) = ww - ii + jj - kk; M3(R, 1, 2) = jk - wi;
+    M3(R, 2, 0) = ik - wj;           M3(R, 2, 1) = wi + jk;           M3(R, 2, 2) = ww - ii - jj + kk;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) S.m[e] = 0.0f;
+    float s0 = scales3[3 * t], s1 = scales3[3 * t + 1], s2 = scales3[3 * t + 2];
+    M3(S, 0, 0) = s0 * s0; M3(S, 1, 1) = s1 * s1; M3(S, 2, 2) = s2 * s2;
+    Mat3 cov = mat3_mul(mat3_mul(R, S), mat3_t(R));
+#pragma unroll
+    for (int e = 0; e < 9; ++e) out[9 * t + e] = cov.m[e];
+}
+
+// Exactly covered pixel interval {p in [lo_lim,hi_lim] : |p + off - c| <= h}; false when empty.
+__device__ __forceinline__ bool covered_interval(float c, float h, float off, int lo_lim, int hi_lim, int* lo, int* hi) {
+    float flo = c - h - off, fhi = c + h - off;
+    if (!(fhi >= (float)lo_lim - 2.0f) || !(flo <= (float)hi_lim + 2.0f)) return false;
+    int a = (int)fmaxf(floorf(flo) - 1.0f, (float)lo_lim);
+    int b = (int)fminf(ceilf(fhi) + 1.0f, (float)hi_lim);
+    while (a <= b && !(fabsf(((float)a + off) - c) <= h)) ++a;
+    while (b >= a && !(fabsf(((float)b + off) - c) <= h)) --b;
+    if (a > b) return false;
+    *lo = a; *hi = b;
+    return true;
+}
+
+// SH basis constants, src/gaussians.rs:11-26
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+#define SH_C2_0 1.0925484305920792f
+#define SH_C2_1 (-1.0925484305920792f)
+#define SH_C2_2 0.31539156525252005f
+#define SH_C2_3 (-1.0925484305920792f)
+#define SH_C2_4 0.5462742152960396f
+#define SH_C3_0 (-0.5900435899266435f)
+#define SH_C3_1 2.890611442640554f
+#define SH_C3_2 (-0.4570457994644658f)
+#define SH_C3_3 0.3731763325901154f
+#define SH_C3_4 (-0.4570457994644658f)
+#define SH_C3_5 1.445305721320277f
+#define SH_C3_6 (-0.5900435899266435f)
+
+// K1 -- one thread per Gaussian: the whole vertex stage, a 48-B record, the exactly covered
+// pixel rectangle, and the per-(tile,sub-bucket) counts.
+__global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes, FrameConst fc,
+                                                         Rec* __restrict__ recs, float* __restrict__ depth,
+                                                         ushort4* __restrict__ rect, unsigned int* __restrict__ counts,
+                                                         FrameStatus* __restrict__ status) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float F[64];
+#pragma unroll
+    for (int p = 0; p < LIVE_PLANES; ++p) {
+        float4 v = planes[(uint64_t)p * n + i];
+        F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
+    }
+    const float px = F[0], py = F[1], pz = F[2], opacity = F[3];
+    const float* sh = F + 13;
+
+    // ray_direction = (position - camera.position).normalize()            src/pipelines.rs:99
+    float dxw = px - fc.cam[0], dyw = py - fc.cam[1], dzw = pz - fc.cam[2];
+    float nrm = sqrtf((dxw * dxw + dyw * dyw) + dzw * dzw);
+    float x = dxw / nrm, y = dyw / nrm, z = dzw / nrm;
+
+    // eval_spherical_harmonics                                           src/gaussians.rs:40-99
+    float col[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) col[ch] = SH_C0 * sh[ch];
+    if (fc.sh_dim > 3) {
+        float k1 = SH_C1 * y, k2 = SH_C1 * z, k3 = SH_C1 * x;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) col[ch] = col[ch] - k1 * sh[3 + ch] + k2 * sh[6 + ch] - k3 * sh[9 + ch];
+        if (fc.sh_dim > 12) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            float k4 = SH_C2_0 * xy, k5 = SH_C2_1 * yz, k6 = SH_C2_2 * (2.0f * zz - xx - yy);
+            float k7 = SH_C2_3 * xz, k8 = SH_C2_4 * (xx - yy);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                col[ch] = col[ch] + k4 * sh[12 + ch] + k5 * sh[15 + ch] + k6 * sh[18 + ch] + k7 * sh[21 + ch] +
+                          k8 * sh[24 + ch];
+            if (fc.sh_dim > 27) {
+#pragma unroll
+                for (int p = LIVE_PLANES; p < SCENE_PLANES; ++p) {
+                    float4 v = planes[(uint64_t)p * n + i];
+                    F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
+                }
+                float k9 = SH_C3_0 * y * (3.0f * xx - yy), k10 = SH_C3_1 * xy * z;
+                float k11 = SH_C3_2 * y * (4.0f * zz - xx - yy);
+                float k12 = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                float k13 = SH_C3_4 * x * (4.0f * zz - xx - yy), k14 = SH_C3_5 * z * (xx - yy);
+                float k15 = SH_C3_6 * x * (xx - 3.0f * yy);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    col[ch] = col[ch] + k9 * sh[27 + ch] + k10 * sh[30 + ch] + k11 * sh[33 + ch] + k12 * sh[36 + ch] +
+                              k13 * sh[39 + ch] + k14 * sh[42 + ch] + k15 * sh[45 + ch];
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) col[ch] = col[ch] + 0.5f;   // HALF, no clamp
+
+    // project_cov3d_to_screen                                            src/gaussians.rs:114-161
+    float pc[4];
+    mat4_vec(fc.view, px, py, pz, 1.0f, pc);
+    float limx = 1.3f * fc.htanx, limy = 1.3f * fc.htany;
+    float txtz = pc[0] / pc[2], tytz = pc[1] / pc[2];
+    float tx = fminf(limx, fmaxf(-limx, txtz)) * pc[2];
+    float ty = fminf(limy, fmaxf(-limy, tytz)) * pc[2];
+    float tz = pc[2];
+    Mat3 J;
+    M3(J, 0, 0) = fc.focal / tz; M3(J, 0, 1) = 0.0f;          M3(J, 0, 2) = -(fc.focal * tx) / (tz * tz);
+    M3(J, 1, 0) = 0.0f;          M3(J, 1, 1) = fc.focal / tz; M3(J, 1, 2) = -(fc.focal * ty) / (tz * tz);
+    M3(J, 2, 0) = 0.0f;          M3(J, 2, 1) = 0.0f;          M3(J, 2, 2) = 0.0f;
+    Mat3 Wm;   // viewmatrix.fixed_view::<3,3>(0,0).transpose()
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) M3(Wm, r, c) = fc.view[r * 4 + c];
+    Mat3 T = mat3_mul(Wm, J);
+    Mat3 Sg;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Sg.m[e] = F[4 + e];
+    Mat3 cov = mat3_mul(mat3_mul(mat3_t(T), mat3_t(Sg)), T);
+    float m11 = M3(cov, 0, 0) + fc.lowpass, m21 = M3(cov, 1, 0), m12 = M3(cov, 0, 1), m22 = M3(cov, 1, 1) + fc.lowpass;
+
+    // gaussian_vertex_shader                                             src/pipelines.rs:17-51
+    float det = m11 * m22 - m21 * m12;       // nalgebra 2x2 try_inverse
+    float q[4];
+    mat4_vec(fc.proj, pc[0], pc[1], pc[2], pc[3], q);
+    float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];
+    float ca = m22 / det, cb = -m12 / det, cc = m11 / det;
+    float hx = 3.0f * sqrtf(m11), hy = 3.0f * sqrtf(m22);
+    // euc: NDC -> target pixels
+    float cx = (ndcx * 0.5f + 0.5f) * fc.w;
+    float cy = fc.y_up ? (ndcy * -0.5f + 0.5f) * fc.h : (ndcy * 0.5f + 0.5f) * fc.h;
+
+    bool singular = (det == 0.0f);
+    bool vis = !singular && finitef(cx) && finitef(cy) && finitef(hx) && finitef(hy) && finitef(ca) && finitef(cb) &&
+               finitef(cc) && finitef(ndcz);
+    if (vis && fc.zclip) vis = (fc.zmin <= ndcz) && (ndcz <= fc.zmax);
+    // pixel ranges that can be covered at all on this target (the slab bounds the y range only)
+    int x0 = 1, x1 = 0, y0 = 1, y1 = 0, fx0 = 1, fx1 = 0, fy0 = 1, fy1 = 0;
+    const float off = fc.sample_half ? 0.5f : 0.0f;
+    bool on_target = vis && covered_interval(cx, hx, off, 0, fc.W - 1, &fx0, &fx1) &&
+                     covered_interval(cy, hy, off, 0, fc.H - 1, &fy0, &fy1);
+    bool in_slab = false;
+    if (on_target) {
+        x0 = fx0; x1 = fx1;
+        y0 = max(fy0, fc.row_px0); y1 = min(fy1, fc.row_px1 - 1);
+        in_slab = y0 <= y1;
+    }
+    Rec r;
+    r.a = make_float4(cx, cy, hx, hy);
+    r.b = make_float4(ca, cb, cc, opacity);
+    r.c = make_float4(col[0], col[1], col[2], 0.0f);
+    recs[i] = r;
+    depth[i] = pc[2];
+    // the rectangle kept for debug/parity is the whole-target one; tiles are emitted for the slab part
+    rect[i] = on_target ? make_ushort4((unsigned short)fx0, (unsigned short)fx1, (unsigned short)fy0, (unsigned short)fy1)
+                        : make_ushort4(1, 0, 1, 0);
+    if (singular) atomicAdd(&status->n_singular, 1ull);
+    if (!in_slab) return;
+    atomicAdd(&status->n_visible, 1ull);
+    int tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = (y0 >> 4) - fc.tile_row0, ty1 = (y1 >> 4) - fc.tile_row0;
+    unsigned int sub = (unsigned int)i & (SUB - 1);
+    for (int tyy = ty0; tyy <= ty1; ++tyy)
+        for (int txx = tx0; txx <= tx1; ++txx)
+            atomicAdd(&counts[(unsigned int)(tyy * fc.tiles_x + txx) * SUB + sub], 1u);
+}
+
+// Exclusive scan of the m = n_tiles*SUB counters by ONE 1024-thread workgroup (m <= ~1M).
+// Writes offsets[0..m] and cursor[0..m), zeroes counts for the next frame, reports D.
+__global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int* __restrict__ counts,
+                                                    unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor,
+                                                    FrameStatus* __restrict__ status, unsigned long long capacity) {
+    __shared__ unsigned int part[1024];
+    __shared__ unsigned int red[16];
+    const unsigned int tid = threadIdx.x;
+    const unsigned int chunk = (m + 1023u) / 1024u;
+    const unsigned int lo = min(tid * chunk, m), hi = min(lo + chunk, m);
+    unsigned int sum = 0;
+    for (unsigned int k = lo; k < hi; ++k) sum += counts[k];
+    part[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partials
+    for (unsigned int d = 1; d < 1024; d <<= 1) {
+        unsigned int v = (tid >= d) ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned int run = part[tid] - sum;
+    for (unsigned int k = lo; k < hi; ++k) {
+        unsigned int c = counts[k];
+        counts[k] = 0;
+        offsets[k] = run;
+        cursor[k] = run;
+        run += c;
+    }
+    const unsigned int total = part[1023];
+    if (tid == 0) {
+        offsets[m] = total;
+        status->n_pairs = total;
+        status->overflow = ((unsigned long long)total > capacity) ? 1u : 0u;
+    }
+    __syncthreads();   // offsets[] written by this workgroup are visible to it
+    unsigned int mx = 0;
+    const unsigned int n_tiles = m / SUB;
+    for (unsigned int t = tid; t < n_tiles; t += 1024) {
+        unsigned int b = offsets[t * SUB], e = (t + 1 == n_tiles) ? total : offsets[(t + 1) * SUB];
+        mx = max(mx, e - b);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 0; k < 16; ++k) mx = max(mx, red[k]);
+        status->max_tile_len = mx;
+    }
+}
+
+// order-preserving u32 of an f32 (ascending z == far first in a right-handed view)
+__device__ __forceinline__ unsigned int depth_key(float z) {
+    unsigned int u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// K2 -- one thread per Gaussian: claim a slot in every overlapped tile's bucket and write the
+// 64-bit key (depth_key << 32 | index).  Bucket order is arbitrary; K3 fixes it.
+__global__ __launch_bounds__(256) void emit_kernel(uint64_t n, FrameConst fc, const float* __restrict__ depth,
+                                                   const ushort4* __restrict__ rect, unsigned int* __restrict__ cursor,
+                                                   unsigned long long* __restrict__ keys,
+                                                   const FrameStatus* __restrict__ status) {
+    if (status->overflow) return;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ushort4 rc = rect[i];
+    if (rc.x > rc.y) return;
+    int y0 = max((int)rc.z, fc.row_px0), y1 = min((int)rc.w, fc.row_px1 - 1);
+    if (y0 > y1) return;
+    unsigned long long key = ((unsigned long long)depth_key(depth[i]) << 32) | (unsigned long long)(unsigned int)i;
+    int tx0 = rc.x >> 4, tx1 = rc.y >> 4, ty0 = (y0 >> 4) - fc.tile_row0, ty1 = (y1 >> 4) - fc.tile_row0;
+    unsigned int sub = (unsigned int)i & (SUB - 1);
+    for (int tyy = ty0; tyy <= ty1; ++tyy)
+        for (int txx = tx0; txx <= tx1; ++txx) {
+            unsigned int slot = atomicAdd(&cursor[(unsigned int)(tyy * fc.tiles_x + txx) * SUB + sub], 1u);
+            keys[slot] = key;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// K3 -- per-tile sort of the 64-bit keys (ascending depth key, ties by index == the
+// reference's stable ascending-z order).  Bitonic network in its all-ascending "flip" form, so
+// that a list of any length n sorts in place: slots >= n behave as +inf and never move.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void cmp_swap(T* s, unsigned int i, unsigned int p) {
+    T a = s[i], b = s[p];
+    if (a > b) { s[i] = b; s[p] = a; }
+}
+
+template <typename T>
+__device__ __forceinline__ void bitonic_sort(T* s, unsigned int n, unsigned int tid, unsigned int nt) {
+    unsigned int P = 1;
+    while (P < n) P <<= 1;
+    const unsigned int half = P >> 1;
+    for (unsigned int k = 2; k <= P; k <<= 1) {
+        const unsigned int hk = k >> 1;
+        for (unsigned int t = tid; t < half; t += nt) {
+            unsigned int off = t & (hk - 1), base = (t - off) << 1;   // block start = (t / hk) * k
+            unsigned int i = base + off, p = base + (k - 1 - off);
+            if (p < n) cmp_swap(s, i, p);
+        }
+        __syncthreads();
+        for (unsigned int j = k >> 2; j > 0; j >>= 1) {
+            for (unsigned int t = tid; t < half; t += nt) {
+                unsigned int lowbits = t & (j - 1);
+                unsigned int i = ((t - lowbits) << 1) | lowbits, p = i + j;
+                if (p < n) cmp_swap(s, i, p);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr unsigned int SORT_SMALL_CAP = 2048;    // 16 KB LDS, 256 threads
+constexpr unsigned int SORT_BIG_CAP = 16384;     // 128 KB LDS, 1024 threads
+
+__global__ __launch_bounds__(256) void sort_tiles_small_kernel(const unsigned int* __restrict__ offsets,
+                                                               unsigned long long* __restrict__ keys,
+                                                               const FrameStatus* __restrict__ status) {
+    __shared__ unsigned long long s[SORT_SMALL_CAP];
+    if (status->overflow) return;
+    const unsigned int tile = blockIdx.x;
+    const unsigned int b = offsets[tile * SUB], e = offsets[(tile + 1) * SUB];
+    const unsigned int n = e - b;
+    if (n < 2 || n > SORT_SMALL_CAP) return;
+    for (unsigned int t = threadIdx.x; t < n; t += 256) s[t] = keys[b + t];
+    __syncthreads();
+    bitonic_sort(s, n, threadIdx.x, 256);
+    for (unsigned int t = threadIdx.x; t < n; t += 256) keys[b + t] = s[t];
+}
+
+__global__ __launch_bounds__(1024) void sort_tiles_big_kernel(const unsigned int* __restrict__ offsets,
+                                                              unsigned long long* __restrict__ keys,
+                                                              const FrameStatus* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
+    if (status->overflow) return;
+    const unsigned int tile = blockIdx.x;
+    const unsigned int b = offsets[tile * SUB], e = offsets[(tile + 1) * SUB];
+    const unsigned int n = e - b;
+    if (n <= SORT_SMALL_CAP) return;
+    if (n <= SORT_BIG_CAP) {
+        for (unsigned int t = threadIdx.x; t < n; t += 1024) s[t] = keys[b + t];
+        __syncthreads();
+        bitonic_sort(s, n, threadIdx.x, 1024);
+        for (unsigned int t = threadIdx.x; t < n; t += 1024) keys[b + t] = s[t];
+    } else {
+        // longer than LDS: same network straight on the bucket in global memory (L2-resident);
+        // one workgroup, so __syncthreads() orders its own global accesses.
+        bitonic_sort(keys + b, n, threadIdx.x, 1024);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4 -- compositor, exact mode.  One 256-thread workgroup per 16x16 tile, one pixel per thread
+// (wave w owns tile rows 4w..4w+3).  The tile's list is streamed far -> near through LDS in
+// batches of 256 records; every covered sample runs fragment() and the 8-bit truncating
+// blend() of src/pipelines.rs:127-168 in registers.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float div255(float k) {
+    // == k / 255.0f (IEEE) for every integer k in [0,255]: one multiply + two fma refinement steps
+    // (checked exhaustively in tests/test_host_math.py::test_div255_identity)
+    const float r = 1.0f / 255.0f;
+    float q = k * r;
+    float e = fmaf(-255.0f, q, k);
+    return fmaf(e, r, q);
+}
+__device__ __forceinline__ float quant_u8(float v) {
+    // Rust `(v) as u8` kept as a float: NaN/negative -> 0, >= 255 -> 255, else truncate
+    return truncf(fminf(fmaxf(v, 0.0f), 255.0f));
+}
+
+__global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+                                                              const unsigned long long* __restrict__ keys,
+                                                              const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
+                                                              const FrameStatus* __restrict__ status) {
+    __shared__ float4 sA[256];
+    __shared__ float4 sB[256];
+    __shared__ float4 sC[256];
+    if (status->overflow) return;
+    const unsigned int tile = blockIdx.x;
+    const unsigned int tid = threadIdx.x;
+    const int txx = (int)(tile % (unsigned int)fc.tiles_x), tyy = (int)(tile / (unsigned int)fc.tiles_x) + fc.tile_row0;
+    const int px = txx * TILE + (int)(tid & 15u), py = tyy * TILE + (int)(tid >> 4);
+    const bool inside = px < fc.W && py < fc.H && py >= fc.row_px0 && py < fc.row_px1;
+    const unsigned int beg = offsets[tile * SUB], end = offsets[(tile + 1) * SUB];
+    if (beg == end) return;
+    const float off = fc.sample_half ? 0.5f : 0.0f;
+    const float sx = (float)px + off, sy = (float)py + off;
+    uint32_t old = inside ? argb[(size_t)py * fc.W + px] : 0u;
+    float R = (float)((old >> 16) & 0xffu), G = (float)((old >> 8) & 0xffu), B = (float)(old & 0xffu);
+    float A = (float)(old >> 24);
+    for (unsigned int base = beg; base < end; base += 256) {
+        const unsigned int cnt = min(256u, end - base);
+        if (tid < cnt) {
+            unsigned int gi = (unsigned int)keys[base + tid];
+            Rec r = recs[gi];
+            sA[tid] = r.a; sB[tid] = r.b; sC[tid] = r.c;
+        }
+        __syncthreads();
+        for (unsigned int j = 0; j < cnt; ++j) {
+            float4 a = sA[j];
+            float dx = sx - a.x;
+            float dy = fc.y_up ? (a.y - sy) : (sy - a.y);   // coordxy.y grows with NDC y
+            bool cov = inside && (fabsf(dx) <= a.z) && (fabsf(dy) <= a.w);
+            if (!__any(cov)) continue;
+            float4 b = sB[j];
+            float4 c = sC[j];
+            // fragment(): src/pipelines.rs:134-143
+            float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+            float alpha = fminf(0.99f, b.w * expf(power));
+            bool accept = cov && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (accept) {
+                // blend(): src/pipelines.rs:147-167
+                float ia = 1.0f - alpha;
+                float br = ia * div255(R) + alpha * c.x;
+                float bg = ia * div255(G) + alpha * c.y;
+                float bb = ia * div255(B) + alpha * c.z;
+                R = quant_u8(br * 255.0f);
+                G = quant_u8(bg * 255.0f);
+                B = quant_u8(bb * 255.0f);
+                A = quant_u8(alpha * 255.0f);
+            } else if (cov) {
+                A = 0.0f;   // rejected fragments are (0,0,0,0) and still blended: RGB unchanged, A := 0
+            }
+        }
+        __syncthreads();
+    }
+    if (inside)
+        argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------
+static inline unsigned int blocks_for(uint64_t n, unsigned int bs) { return (unsigned int)((n + bs - 1) / bs); }
+
+void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
+                       const float* sh, float4* planes) {
+    if (!n) return;
+    hipLaunchKernelGGL(pack_scene_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, pos4, cov3d, opacity, sh, planes);
+}
+void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d) {
+    if (!n) return;
+    hipLaunchKernelGGL(cov3d_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, scales3, rot4, cov3d);
+}
+void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, FrameConst fc, Rec* recs, float* depth,
+                       ushort4* rect, unsigned int* counts, FrameStatus* status) {
+    if (!n) return;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, fc, recs, depth, rect,
+                       counts, status);
+}
+void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
+                 FrameStatus* status, unsigned long long capacity) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, status, capacity);
+}
+void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect,
+                 unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
+    if (!n) return;
+    hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, fc, depth, rect, cursor, keys, status);
+}
+void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, unsigned long long* keys,
+                 const FrameStatus* status) {
+    if (!n_tiles) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_big_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SORT_BIG_CAP * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, keys, status);
+    hipLaunchKernelGGL(sort_tiles_big_kernel, dim3(n_tiles), dim3(1024), SORT_BIG_CAP * 8, s, offsets, keys, status);
+}
+void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
+                      const unsigned long long* keys, const Rec* recs, uint32_t* argb, const FrameStatus* status) {
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), 0, s, fc, offsets, keys, recs, argb, status);
+}
+
+}  // namespace splat

@@ -1,0 +1,171 @@
+"""Scene containers and loaders: host-side mirror of src/gaussians.rs.
+
+`GaussianList` keeps the reference's SoA layout (src/gaussians.rs:408-416) -- each Gaussian one
+contiguous column -- which is exactly what `splat_upload_scene` takes.
+"""
+import numpy as np
+
+f32 = np.float32
+HALF = f32(0.5)
+
+
+class GaussianList:
+    """positions [n,4] (x,y,z,1) - scales [n,3] - opacities [n] - rotations [n,4] in nalgebra coords
+    order (i,j,k,w) - sh [n,48] (f_dc then f_rest, un-transposed) - cov3d [n,9] column-major 3x3."""
+
+    def __init__(self, positions, scales, opacities, rotations, sh, cov3d=None):
+        n = len(positions)
+        self.positions = np.ascontiguousarray(positions, f32).reshape(n, 4)
+        self.scales = np.ascontiguousarray(scales, f32).reshape(n, 3)
+        self.opacities = np.ascontiguousarray(opacities, f32).reshape(n)
+        self.rotations = np.ascontiguousarray(rotations, f32).reshape(n, 4)
+        self.sh = np.ascontiguousarray(sh, f32).reshape(n, 48)
+        # Gaussian::new leaves cov3d all-zero until compute_cov3d runs (src/gaussians.rs:254)
+        self.cov3d = np.zeros((n, 9), f32) if cov3d is None else np.ascontiguousarray(cov3d, f32).reshape(n, 9)
+        self.num_gaussians = n
+
+    def __len__(self):
+        return self.num_gaussians
+
+    def compute_cov3d(self, renderer):
+        """src/gaussians.rs:446-462, on the GPU (kernel K0 via splat_compute_cov3d)."""
+        self.cov3d = renderer.compute_cov3d(self.scales, self.rotations)
+        return self
+
+    def subset(self, idx):
+        return GaussianList(self.positions[idx], self.scales[idx], self.opacities[idx], self.rotations[idx],
+                            self.sh[idx], self.cov3d[idx])
+
+
+def naive_gaussians():
+    """The 4-splat test scene, src/gaussians.rs:319-374 (== notes/util_gau.py:25-60)."""
+    pos = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1], [0, 0, 1, 1]], f32)
+    scales = np.array([[0.03, 0.03, 0.03], [0.2, 0.03, 0.03], [0.03, 0.2, 0.03], [0.03, 0.03, 0.2]], f32)
+    rot = np.tile(np.array([0, 0, 0, 1], f32), (4, 1))           # Quaternion::new(w=1, 0, 0, 0)
+    col = np.array([[1, 0, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1]], f32)
+    sh = np.zeros((4, 48), f32)
+    sh[:, :3] = (col - HALF) / f32(0.28209)
+    return GaussianList(pos, scales, np.ones(4, f32), rot, sh)
+
+
+# ---- INRIA 3DGS PLY schema ---------------------------------------------
+PLY_PROPS = (["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] +
+             ["f_rest_%d" % i for i in range(45)] + ["opacity"] + ["scale_%d" % i for i in range(3)] +
+             ["rot_%d" % i for i in range(4)])
+_NP_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2",
+             "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4",
+             "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def _activate_and_recentre(raw):
+    """set_property activations (src/gaussians.rs:258-282) + mean recentring (:394-402).
+    raw: dict name -> f32 array (missing names keep Gaussian::new defaults)."""
+    n = len(next(iter(raw.values()))) if raw else 0
+    get = lambda k, d=0.0: np.asarray(raw[k], f32) if k in raw else np.full(n, d, f32)  # noqa: E731
+    pos = np.stack([get("x"), get("y"), get("z"), np.ones(n, f32)], 1)
+    scales = np.stack([np.exp(raw[k], dtype=f32) if k in raw else np.zeros(n, f32)
+                       for k in ("scale_0", "scale_1", "scale_2")], 1)
+    if "opacity" in raw:
+        opac = (f32(1.0) / (f32(1.0) + np.exp(-np.asarray(raw["opacity"], f32), dtype=f32))).astype(f32)
+    else:
+        opac = np.zeros(n, f32)
+    # rot_0 -> w = coords[3]; rot_1..3 -> i,j,k = coords[0..2]; identity when absent
+    rot = np.stack([get("rot_1"), get("rot_2"), get("rot_3"), get("rot_0", 1.0)], 1)
+    sh = np.zeros((n, 48), f32)
+    for i in range(3):
+        if "f_dc_%d" % i in raw:
+            sh[:, i] = raw["f_dc_%d" % i]
+    for k, v in raw.items():
+        if k.startswith("f_rest_"):
+            idx = int(k[7:])
+            if idx > 44:
+                raise IndexError("f_rest index %d out of range (the reference panics)" % idx)
+            sh[:, 3 + idx] = v
+    if n:
+        # sequential f32 sum (cumsum is sequential), then / n as f32
+        avg = (np.cumsum(pos[:, :3], axis=0, dtype=f32)[-1] / f32(n)).astype(f32)
+        pos[:, :3] -= avg
+    return GaussianList(pos, scales, opac, rot, sh)
+
+
+def load_from_ply(filename):
+    """load_from_ply, src/gaussians.rs:375-405: vectorised decode of the whole vertex block
+    (binary little/big endian or ascii).  Only `float` properties are consumed; a non-"vertex"
+    element raises (the reference panics)."""
+    with open(filename, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError("%s: not a PLY file" % filename)
+        fmt, n, props = None, None, []
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError("%s: unterminated PLY header" % filename)
+            t = line.decode("ascii", "replace").split()
+            if not t:
+                continue
+            if t[0] == "format":
+                fmt = t[1]
+            elif t[0] == "element":
+                if t[1] != "vertex":
+                    raise ValueError("Unexpected element!")
+                n = int(t[2])
+            elif t[0] == "property":
+                if t[1] == "list":
+                    raise ValueError("list properties in the vertex element are not supported by the fast loader")
+                props.append((t[2], _NP_TYPES[t[1]], t[1] in ("float", "float32")))
+            elif t[0] == "end_header":
+                break
+        if fmt is None or n is None:
+            raise ValueError("%s: incomplete PLY header" % filename)
+        if fmt == "ascii":
+            data = np.loadtxt(f, dtype=np.float64, ndmin=2)[:n]
+            cols = {name: data[:, k].astype(f32) for k, (name, _, isf) in enumerate(props) if isf}
+        else:
+            end = "<" if fmt == "binary_little_endian" else ">"
+            dt = np.dtype([(name, end + ty) for name, ty, _ in props])
+            data = np.fromfile(f, dtype=dt, count=n)
+            if len(data) != n:
+                raise ValueError("%s: truncated payload" % filename)
+            cols = {name: np.ascontiguousarray(data[name]).astype(f32) for name, _, isf in props if isf}
+    return _activate_and_recentre(cols)
+
+
+def write_ply(filename, raw, n):
+    """Write the 62-float INRIA layout (binary little endian).  raw: name -> array; missing -> 0."""
+    dt = np.dtype([(p, "<f4") for p in PLY_PROPS])
+    data = np.zeros(n, dt)
+    for k, v in raw.items():
+        data[k] = v
+    with open(filename, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n)
+        for p in PLY_PROPS:
+            f.write(("property float %s\n" % p).encode())
+        f.write(b"end_header\n")
+        data.tofile(f)
+
+
+def synthetic_raw(n, seed):
+    """Seeded stand-in for a trained scene, in PLY (pre-activation) units -- SURVEY.md section 8(d)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    raw = {}
+    xyz = np.clip(rng.standard_normal((n, 3)) * 1.5, -6.0, 6.0).astype(f32)
+    raw["x"], raw["y"], raw["z"] = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy()
+    ls = (rng.standard_normal((n, 3)) * 0.8 - 4.0).astype(f32)
+    for i in range(3):
+        raw["scale_%d" % i] = ls[:, i].copy()
+    q = rng.standard_normal((n, 4)).astype(f32)
+    for i in range(4):
+        raw["rot_%d" % i] = q[:, i].copy()
+    raw["opacity"] = (rng.standard_normal(n) * 2.5).astype(f32)
+    dc = rng.standard_normal((n, 3)).astype(f32)
+    for i in range(3):
+        raw["f_dc_%d" % i] = dc[:, i].copy()
+    rest = (rng.standard_normal((n, 45)) * 0.15).astype(f32)
+    for i in range(45):
+        raw["f_rest_%d" % i] = rest[:, i].copy()
+    return raw
+
+
+def synthetic_scene(n, seed):
+    """synthetic_raw pushed through the loader's activations + recentring (no file round trip)."""
+    return _activate_and_recentre(synthetic_raw(n, seed))

@@ -1,0 +1,122 @@
+"""Thin object wrapper over the C ABI context (include/splat_hip.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+f32 = np.float32
+
+
+class SplatError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("splat error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _fp(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Renderer:
+    """One context = one GPU = one stream.  `conventions` overrides splat_default_config fields
+    (y_up, sample_half, zclip, zmin, zmax)."""
+
+    def __init__(self, device=0, pair_capacity=0, **conventions):
+        self._L = _lib.lib()
+        cfg = _lib.Config()
+        self._L.splat_default_config(C.byref(cfg))
+        cfg.device = int(device)
+        cfg.pair_capacity = int(pair_capacity)
+        for k, v in conventions.items():
+            if not hasattr(cfg, k):
+                raise TypeError("unknown convention %r" % k)
+            setattr(cfg, k, v)
+        self.config = cfg
+        h = C.c_void_p()
+        rc = self._L.splat_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise SplatError(rc, (self._L.splat_last_error(None) or b"").decode())
+        self._h = h
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.splat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SplatError(rc, (self._L.splat_last_error(self._h) or b"").decode())
+
+    # ---- scene ------------------------------------------------------------------------
+    def upload(self, gaussians):
+        g = gaussians
+        self._check(self._L.splat_upload_scene(self._h, len(g), _fp(g.positions), _fp(g.cov3d), _fp(g.opacities),
+                                               _fp(g.sh)))
+        self.n = len(g)
+
+    def compute_cov3d(self, scales, rotations):
+        scales = np.ascontiguousarray(scales, f32)
+        rotations = np.ascontiguousarray(rotations, f32)
+        n = scales.shape[0]
+        out = np.zeros((n, 9), f32)
+        self._check(self._L.splat_compute_cov3d(self._h, n, _fp(scales), _fp(rotations), _fp(out)))
+        return out
+
+    def set_slab(self, tile_row0=0, tile_row1=-1):
+        self._check(self._L.splat_set_slab(self._h, int(tile_row0), int(tile_row1)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._L.splat_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # ---- frames -----------------------------------------------------------------------
+    def render(self, cam_c, argb, want_stats=True):
+        """argb: uint32 [h,w] host array, blended in place."""
+        assert argb.dtype == np.uint32 and argb.flags.c_contiguous
+        assert argb.shape == (int(cam_c.h), int(cam_c.w))
+        st = _lib.Stats()
+        self._check(self._L.splat_render(self._h, C.byref(cam_c), argb.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         C.byref(st) if want_stats else None))
+        return st
+
+    def render_device(self, cam_c, d_ptr, sync=False, want_stats=False):
+        """d_ptr: device address of a w*h u32 image (e.g. torch_tensor.data_ptr())."""
+        st = _lib.Stats() if want_stats else None
+        self._check(self._L.splat_render_device(self._h, C.byref(cam_c), C.c_void_p(d_ptr), 1 if sync else 0,
+                                                C.byref(st) if want_stats else None))
+        return st
+
+    def sync(self):
+        self._check(self._L.splat_sync(self._h))
+
+    def timing(self, reset=True):
+        ms = (C.c_double * 6)()
+        frames = C.c_uint64()
+        self._check(self._L.splat_get_timing(self._h, ms, C.byref(frames), 1 if reset else 0))
+        names = ("preprocess", "scan", "emit", "sort", "composite", "status")
+        return {k: ms[i] for i, k in enumerate(names)}, frames.value
+
+    # ---- debug / stage parity -----------------------------------------------------------
+    def records(self):
+        dt = np.dtype([("cx", "f4"), ("cy", "f4"), ("hx", "f4"), ("hy", "f4"), ("conic", "f4", 3),
+                       ("opacity", "f4"), ("rgb", "f4", 3), ("depth", "f4"), ("px0", "i4"), ("px1", "i4"),
+                       ("py0", "i4"), ("py1", "i4")])
+        assert dt.itemsize == C.sizeof(_lib.Record)
+        out = np.zeros(self.n, dt)
+        self._check(self._L.splat_get_records(self._h, out.ctypes.data_as(C.POINTER(_lib.Record)), self.n))
+        return out
+
+    def tile_lists(self, n_tiles, n_pairs):
+        off = np.zeros(n_tiles + 1, np.uint32)
+        order = np.zeros(n_pairs, np.uint32)
+        self._check(self._L.splat_get_tile_lists(self._h, off.ctypes.data_as(C.POINTER(C.c_uint32)), n_tiles + 1,
+                                                 order.ctypes.data_as(C.POINTER(C.c_uint32)), n_pairs))
+        return off, order

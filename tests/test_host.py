@@ -1,0 +1,145 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol the header
+declares, the Camera mirror equals the oracle's restatement, the PLY loader equals the oracle's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import splat_amd
+from splat_amd import _lib
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "splat_hip.h")).read()
+    declared = set(re.findall(r"\b(splat_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 14
+    L = _lib.lib()                     # CDLL load works without a GPU
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == {s[0] for s in _lib.SYMBOLS}
+
+
+def test_struct_sizes_match_header():
+    # layouts are plain C; sizes computed by hand from include/splat_hip.h
+    assert C.sizeof(_lib.CameraC) == 4 * (16 + 16 + 2 + 3 + 3 + 1 + 1)
+    assert C.sizeof(_lib.Record) == 64
+    assert C.sizeof(_lib.Config) == 40
+    assert C.sizeof(_lib.Stats) == 6 * 8 + 6 * 4
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(splat_amd.SplatError):
+        splat_amd.Renderer()
+
+
+@pytest.mark.parametrize("pos,yaw,pitch", [((0, 0, 5), 0.0, 0.0), ((0, 0, 3), 0.0, 0.0),
+                                           ((-0.57651054, 2.99040512, -0.03924271), 0.0, 0.0),
+                                           ((0, 0, 5), 10 * np.pi / 180, 0.0), ((0, 0, 5), -0.5, 0.3),
+                                           ((1, 2, 3), 1.2, -0.7)])
+def test_camera_matches_oracle(pos, yaw, pitch):
+    cam = splat_amd.Camera(600, 800, pos)
+    cam.update_yaw_angle(yaw)
+    cam.update_pitch_angle(pitch)
+    cam.update_camera_pose()
+    assert not cam.is_pose_dirty
+    oc = O.camera(600, 800, pos, yaw=yaw, pitch=pitch)
+    c = cam.to_c(0.01)
+    # sin/cos/tan come from different libms (numpy vs glibc): allow an ulp or two
+    np.testing.assert_allclose(np.array(c.view[:]), np.array(oc.view[:]), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.array(c.proj[:]), np.array(oc.proj[:]), rtol=1e-6)
+    assert (c.w, c.h) == (oc.w, oc.h)
+    np.testing.assert_allclose([c.htanx, c.htany, c.focal], [oc.htanx, oc.htany, oc.focal], rtol=1e-6)
+    assert list(c.cam_pos) == list(oc.cam_pos)          # Q8: the position FIELD, not the orbit eye
+
+
+def test_camera_defaults_and_identity_before_update():
+    cam = splat_amd.Camera(720, 1280)
+    assert cam.position.tolist() == [0, 0, 3] and cam.up.tolist() == [0, -1, 0]
+    assert np.array_equal(cam.get_view_matrix(), np.eye(4)) and np.array_equal(cam.get_project_matrix(), np.eye(4))
+    assert cam.is_pose_dirty
+    ht = cam.get_htanfovxy_focal()
+    assert ht[1] == 1.0 and ht[2] == 360.0 and abs(ht[0] - 1280 / 720) < 1e-6
+
+
+def test_naive_gaussians_literals():
+    g = splat_amd.naive_gaussians()
+    assert len(g) == 4
+    assert g.positions[:, :3].tolist() == [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    assert g.rotations.tolist() == [[0, 0, 0, 1]] * 4
+    assert np.allclose(g.sh[0, :3], (np.array([1, 0, 1]) - 0.5) / 0.28209)
+    assert not g.cov3d.any()                            # all-zero until compute_cov3d (gaussians.rs:254)
+
+
+def _write_fixture(tmp_path, n=257, seed=11):
+    raw = splat_amd.gaussians.synthetic_raw(n, seed)
+    raw["nx"] = np.arange(n, dtype=np.float32)          # ignored properties
+    p = str(tmp_path / "scene.ply")
+    splat_amd.write_ply(p, raw, n)
+    return p, raw
+
+
+def test_ply_loader_matches_oracle(tmp_path):
+    p, raw = _write_fixture(tmp_path)
+    g = splat_amd.load_from_ply(p)
+    o = O.load_ply(p)
+    assert len(g) == 257
+    assert np.array_equal(g.positions, o["pos4"])       # incl. sequential-f32 mean recentring
+    assert np.array_equal(g.rotations, o["rot"])        # rot_0 -> w (coords[3]), NOT normalised
+    assert np.array_equal(g.sh, o["sh"])                # f_rest_k -> sh[3+k], no transpose (Q6)
+    # exp/sigmoid: numpy's f32 exp vs libm expf may differ in the last bit
+    np.testing.assert_allclose(g.scales, o["scales"], rtol=3e-7)
+    np.testing.assert_allclose(g.opacities, o["opacity"], rtol=3e-7)
+    assert np.array_equal(g.sh[:, 3], raw["f_rest_0"]) and np.array_equal(g.sh[:, 47], raw["f_rest_44"])
+    assert np.array_equal(g.rotations[:, 3], raw["rot_0"]) and np.array_equal(g.rotations[:, 0], raw["rot_1"])
+
+
+def test_ply_ascii_and_ignored_types(tmp_path):
+    p = str(tmp_path / "a.ply")
+    with open(p, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\n"
+                "property double opacity\nproperty float scale_0\nproperty uchar red\nend_header\n"
+                "1 2 3 0.5 0.0 7\n3 2 1 0.25 1.0 9\n")
+    g = splat_amd.load_from_ply(p)
+    o = O.load_ply(p)
+    assert np.array_equal(g.positions, o["pos4"]) and g.positions[:, :3].tolist() == [[-1, 0, 1], [1, 0, -1]]
+    assert not g.opacities.any() and not o["opacity"].any()     # `double` is not Property::Float: ignored
+    np.testing.assert_allclose(g.scales[:, 0], [1.0, np.e], rtol=1e-6)
+    assert g.rotations.tolist() == [[0, 0, 0, 1]] * 2           # Quaternion::identity()
+
+
+def test_ply_unexpected_element_raises(tmp_path):
+    p = str(tmp_path / "b.ply")
+    with open(p, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement face 1\nproperty float x\nend_header\n1\n")
+    with pytest.raises(ValueError):
+        splat_amd.load_from_ply(p)
+    with pytest.raises(RuntimeError):
+        O.load_ply(p)
+
+
+def test_golden_c1_fixture_loader():
+    """tests/golden/c1_head.ply: first 64 vertices of the C1 synthetic scene (seed 1)."""
+    p = os.path.join(ROOT, "tests", "golden", "c1_head.ply")
+    g = splat_amd.load_from_ply(p)
+    o = O.load_ply(p)
+    assert len(g) == 64 and np.array_equal(g.positions, o["pos4"]) and np.array_equal(g.sh, o["sh"])
+
+
+def test_div255_identity():
+    """The compositor replaces k/255.0f by mul+fma+fma; exact for every byte (checked in f32)."""
+    k = np.arange(256, dtype=np.float32)
+    want = k / np.float32(255)
+    r = np.float32(1) / np.float32(255)
+    q = k * r
+    e = (np.float64(k) - np.float64(255) * np.float64(q)).astype(np.float32)        # fma(-255,q,k): exact in f64
+    got = (np.float64(q) + np.float64(e) * np.float64(r)).astype(np.float32)        # fma(e,r,q): one rounding
+    assert np.array_equal(got, want)
+    assert np.array_equal((want * np.float32(255)).astype(np.int32), np.arange(256))    # /255*255 round trip
