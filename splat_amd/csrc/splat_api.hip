@@ -33,10 +33,13 @@ struct splat_ctx {
     Rec* recs = nullptr;
     float* depth = nullptr;
     ushort4* rect = nullptr;
+    unsigned int* orig = nullptr;      // slot -> original Gaussian index (Morton order of position)
+    std::vector<unsigned int> h_orig;
     // binning
     unsigned int* counts = nullptr;
     unsigned int* offsets = nullptr;
     unsigned int* cursor = nullptr;
+    unsigned int* order = nullptr;     // tile ids, longest list first
     unsigned int m_alloc = 0;
     unsigned long long* keys = nullptr;
     uint64_t cap = 0;
@@ -77,6 +80,40 @@ int fail(splat_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// Upload-time ordering: 30-bit Morton code of the position inside the scene's bounding box.
+// order[j] = original index stored in slot j.  Ties keep index order; non-finite positions go first.
+inline uint32_t spread3(uint32_t v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+void morton_order(uint64_t n, const float* pos4, std::vector<unsigned int>& order) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint64_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            float v = pos4[4 * i + a];
+            if (std::isfinite(v)) { lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
+        }
+    float sc[3];
+    for (int a = 0; a < 3; ++a) sc[a] = (hi[a] > lo[a]) ? 1023.0f / (hi[a] - lo[a]) : 0.0f;
+    std::vector<uint64_t> keyed(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t code = 0;
+        for (int a = 0; a < 3; ++a) {
+            float v = pos4[4 * i + a];
+            uint32_t q = std::isfinite(v) ? (uint32_t)std::min(1023.0f, std::max(0.0f, (v - lo[a]) * sc[a])) : 0u;
+            code |= spread3(q) << a;
+        }
+        keyed[i] = ((uint64_t)code << 32) | (uint64_t)i;
+    }
+    std::sort(keyed.begin(), keyed.end());
+    order.resize(n);
+    for (uint64_t j = 0; j < n; ++j) order[j] = (unsigned int)keyed[j];
+}
+
 template <typename T>
 void dfree(T*& p) {
     if (p) { (void)hipFree(p); p = nullptr; }
@@ -98,11 +135,12 @@ void harvest(splat_ctx* c, int slot) {
 
 int ensure_bins(splat_ctx* c, unsigned int m) {
     if (m + 1 <= c->m_alloc) return SPLAT_OK;
-    dfree(c->counts); dfree(c->offsets); dfree(c->cursor);
+    dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->order);
     c->m_alloc = 0;
     HIP_TRY(c, hipMalloc(&c->counts, sizeof(unsigned int) * (size_t)(m + 1)));
     HIP_TRY(c, hipMalloc(&c->offsets, sizeof(unsigned int) * (size_t)(m + 1)));
     HIP_TRY(c, hipMalloc(&c->cursor, sizeof(unsigned int) * (size_t)(m + 1)));
+    HIP_TRY(c, hipMalloc(&c->order, sizeof(unsigned int) * (size_t)(m + 1)));
     HIP_TRY(c, hipMemsetAsync(c->counts, 0, sizeof(unsigned int) * (size_t)(m + 1), c->stream));
     c->m_alloc = m + 1;
     return SPLAT_OK;
@@ -151,18 +189,18 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
     EvSet& ev = c->ring[slot];
     c->ring_next = (c->ring_next + 1) % EV_RING;
     harvest(c, slot);
-    const unsigned int m = c->n_tiles * SUB;
+    const unsigned int m = c->n_tiles;
     HIP_TRY(c, hipEventRecord(ev.e[0], c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(FrameStatus), c->stream));
-    launch_preprocess(c->stream, c->n, c->planes, c->fc, c->recs, c->depth, c->rect, c->counts, c->d_status);
+    launch_preprocess(c->stream, c->n, c->planes, c->orig, c->fc, c->recs, c->depth, c->rect, c->counts, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[1], c->stream));
-    launch_scan(c->stream, m, c->counts, c->offsets, c->cursor, c->d_status, c->cap);
+    launch_scan(c->stream, m, c->counts, c->offsets, c->cursor, c->order, c->d_status, c->cap);
     HIP_TRY(c, hipEventRecord(ev.e[2], c->stream));
-    launch_emit(c->stream, c->n, c->fc, c->depth, c->rect, c->cursor, c->keys, c->d_status);
+    launch_emit(c->stream, c->n, c->fc, c->depth, c->rect, c->orig, c->cursor, c->keys, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[3], c->stream));
-    launch_sort(c->stream, c->n_tiles, c->offsets, c->keys, c->d_status);
+    launch_sort(c->stream, c->n_tiles, c->offsets, c->order, c->keys, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[4], c->stream));
-    launch_composite(c->stream, c->n_tiles, c->fc, c->offsets, c->keys, c->recs, d_argb, c->d_status);
+    launch_composite(c->stream, c->n_tiles, c->fc, c->offsets, c->order, c->keys, c->recs, d_argb, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[5], c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[slot], c->d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[6], c->stream));
@@ -261,8 +299,8 @@ void splat_destroy(splat_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect);
-    dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->keys);
-    dfree(c->d_status); dfree(c->d_img);
+    dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->order); dfree(c->keys);
+    dfree(c->d_status); dfree(c->d_img); dfree(c->orig);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto& s : c->ring)
         for (auto& ev : s.e)
@@ -292,9 +330,11 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     (void)finish_frame(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect);
+    dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect); dfree(c->orig);
     c->n = 0;
+    c->h_orig.clear();
     if (n == 0) return SPLAT_OK;
+    morton_order(n, pos4, c->h_orig);
     float *d_pos = nullptr, *d_cov = nullptr, *d_op = nullptr, *d_sh = nullptr;
     auto cleanup = [&] { dfree(d_pos); dfree(d_cov); dfree(d_op); dfree(d_sh); };
     hipError_t e;
@@ -307,6 +347,8 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     UP_TRY(hipMalloc(&c->recs, sizeof(Rec) * n));
     UP_TRY(hipMalloc(&c->depth, sizeof(float) * n));
     UP_TRY(hipMalloc(&c->rect, sizeof(ushort4) * n));
+    UP_TRY(hipMalloc(&c->orig, sizeof(unsigned int) * n));
+    UP_TRY(hipMemcpyAsync(c->orig, c->h_orig.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, c->stream));
     UP_TRY(hipMalloc(&d_pos, sizeof(float) * 4 * n));
     UP_TRY(hipMalloc(&d_cov, sizeof(float) * 9 * n));
     UP_TRY(hipMalloc(&d_op, sizeof(float) * n));
@@ -315,7 +357,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     UP_TRY(hipMemcpyAsync(d_cov, cov3d, sizeof(float) * 9 * n, hipMemcpyHostToDevice, c->stream));
     UP_TRY(hipMemcpyAsync(d_op, opacity, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     UP_TRY(hipMemcpyAsync(d_sh, sh, sizeof(float) * 48 * n, hipMemcpyHostToDevice, c->stream));
-    launch_pack_scene(c->stream, n, d_pos, d_cov, d_op, d_sh, c->planes);
+    launch_pack_scene(c->stream, n, d_pos, d_cov, d_op, d_sh, c->orig, c->planes);
     UP_TRY(hipGetLastError());
     UP_TRY(hipStreamSynchronize(c->stream));
 #undef UP_TRY
@@ -373,7 +415,7 @@ int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int
     rc = build_frame_const(c, cam, &c->fc, &c->n_tiles);
     if (rc != SPLAT_OK) return rc;
     if (c->n_tiles == 0) { if (stats) { c->last = FrameStatus{}; fill_stats(c, stats); } return SPLAT_OK; }
-    rc = ensure_bins(c, c->n_tiles * SUB);
+    rc = ensure_bins(c, c->n_tiles);
     if (rc != SPLAT_OK) return rc;
     for (int attempt = 0; attempt < 3; ++attempt) {
         rc = enqueue_frame(c, (uint32_t*)d_argb);
@@ -436,12 +478,13 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     HIP_TRY(c, hipMemcpy(r.data(), c->recs, sizeof(Rec) * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(d.data(), c->depth, sizeof(float) * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(q.data(), c->rect, sizeof(ushort4) * n, hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; ++i) {
+    for (uint64_t j = 0; j < n; ++j) {          // depth/rect live in slot order, records in original order
+        const uint64_t i = c->h_orig[j];
         splat_record& o = out[i];
         o.cx = r[i].a.x; o.cy = r[i].a.y; o.hx = r[i].a.z; o.hy = r[i].a.w;
         o.conic_a = r[i].b.x; o.conic_b = r[i].b.y; o.conic_c = r[i].b.z; o.opacity = r[i].b.w;
-        o.r = r[i].c.x; o.g = r[i].c.y; o.b = r[i].c.z; o.depth = d[i];
-        o.px0 = q[i].x; o.px1 = q[i].y; o.py0 = q[i].z; o.py1 = q[i].w;
+        o.r = r[i].c.x; o.g = r[i].c.y; o.b = r[i].c.z; o.depth = d[j];
+        o.px0 = q[j].x; o.px1 = q[j].y; o.py0 = q[j].z; o.py1 = q[j].w;
     }
     return SPLAT_OK;
 }
@@ -452,9 +495,7 @@ int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offset
     if (rc != SPLAT_OK) return rc;
     if (n_offsets != (uint64_t)c->n_tiles + 1 || n_order != c->last.n_pairs)
         return fail(c, SPLAT_ERR_INVALID, "tile list size mismatch");
-    std::vector<unsigned int> off((size_t)c->n_tiles * SUB + 1);
-    HIP_TRY(c, hipMemcpy(off.data(), c->offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost));
-    for (unsigned int t = 0; t <= c->n_tiles; ++t) tile_offsets[t] = off[(size_t)t * SUB];
+    HIP_TRY(c, hipMemcpy(tile_offsets, c->offsets, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), hipMemcpyDeviceToHost));
     if (n_order) {
         std::vector<unsigned long long> k(n_order);
         HIP_TRY(c, hipMemcpy(k.data(), c->keys, sizeof(unsigned long long) * n_order, hipMemcpyDeviceToHost));

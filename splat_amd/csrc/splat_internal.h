@@ -9,7 +9,6 @@
 namespace splat {
 
 constexpr int TILE = SPLAT_TILE;
-constexpr int SUB = 8;            // sub-buckets per tile: spreads same-address atomics over 8 words
 constexpr int SCENE_PLANES = 16;  // float4 planes per Gaussian (see pack_scene_kernel)
 constexpr int LIVE_PLANES = 10;   // planes read per frame at sh_dim <= 27 (160 B / Gaussian)
 
@@ -44,22 +43,23 @@ struct FrameStatus {
 struct Rec {
     float4 a;   // cx, cy, hx, hy
     float4 b;   // conic a, b, c, opacity
-    float4 c;   // r, g, b, power threshold (reserved)
+    float4 c;   // r, g, b, power below which alpha < 1/255 for certain
 };
 
 void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
-                       const float* sh, float4* planes);
+                       const float* sh, const unsigned int* perm, float4* planes);
 void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d);
-void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, FrameConst fc, Rec* recs, float* depth,
-                       ushort4* rect, unsigned int* counts, FrameStatus* status);
+void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
+                       float* depth, ushort4* rect, unsigned int* counts, FrameStatus* status);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
-                 FrameStatus* status, unsigned long long capacity);
-void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect,
+                 unsigned int* order, FrameStatus* status, unsigned long long capacity);
+void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
-void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, unsigned long long* keys,
-                 const FrameStatus* status);
+void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
+                 unsigned long long* keys, const FrameStatus* status);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
-                      const unsigned long long* keys, const Rec* recs, uint32_t* argb, const FrameStatus* status);
+                      const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
+                      const FrameStatus* status);
 
 }  // namespace splat
 #endif

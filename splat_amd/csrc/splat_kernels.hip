@@ -59,12 +59,17 @@ __device__ __forceinline__ bool finitef(float v) { return fabsf(v) <= 3.40282346
 // Float slots: 0-2 xyz, 3 opacity, 4-12 cov3d (col-major 3x3, all nine: the reference's
 // R*S*R^T is not bit-symmetric), 13-39 sh[0..27), 40-60 sh[27..48), 61-63 zero.
 // ---------------------------------------------------------------------------
+// Gaussian slot j holds original Gaussian perm[j]: the scene is stored in Morton order of position
+// so that consecutive threads project to neighbouring tiles (binning aggregates in LDS).
 __global__ __launch_bounds__(256) void pack_scene_kernel(uint64_t n, const float* __restrict__ pos4,
                                                          const float* __restrict__ cov3d,
                                                          const float* __restrict__ opacity,
-                                                         const float* __restrict__ sh, float4* __restrict__ planes) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+                                                         const float* __restrict__ sh,
+                                                         const unsigned int* __restrict__ perm,
+                                                         float4* __restrict__ planes) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t i = perm[j];
     float F[64];
     F[0] = pos4[4 * i + 0]; F[1] = pos4[4 * i + 1]; F[2] = pos4[4 * i + 2]; F[3] = opacity[i];
 #pragma unroll
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void pack_scene_kernel(uint64_t n, const float
     for (int k = 0; k < 48; ++k) F[13 + k] = sh[48 * i + k];
     F[61] = F[62] = F[63] = 0.0f;
 #pragma unroll
-    for (int p = 0; p < SCENE_PLANES; ++p) planes[(uint64_t)p * n + i] = make_float4(F[4 * p], F[4 * p + 1], F[4 * p + 2], F[4 * p + 3]);
+    for (int p = 0; p < SCENE_PLANES; ++p) planes[(uint64_t)p * n + j] = make_float4(F[4 * p], F[4 * p + 1], F[4 * p + 2], F[4 * p + 3]);
 }
 
 // K0 -- compute_cov3d, src/gaussians.rs:101-113.  rot = (i,j,k,w).
@@ -132,182 +137,96 @@ __device__ __forceinline__ bool covered_interval(float c, float h, float off, in
 #define SH_C3_5 1.445305721320277f
 #define SH_C3_6 (-0.5900435899266435f)
 
-// K1 -- one thread per Gaussian: the whole vertex stage, a 48-B record, the exactly covered
-// pixel rectangle, and the per-(tile,sub-bucket) counts.
-__global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes, FrameConst fc,
-                                                         Rec* __restrict__ recs, float* __restrict__ depth,
-                                                         ushort4* __restrict__ rect, unsigned int* __restrict__ counts,
-                                                         FrameStatus* __restrict__ status) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float F[64];
-#pragma unroll
-    for (int p = 0; p < LIVE_PLANES; ++p) {
-        float4 v = planes[(uint64_t)p * n + i];
-        F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
-    }
-    const float px = F[0], py = F[1], pz = F[2], opacity = F[3];
-    const float* sh = F + 13;
+// ---------------------------------------------------------------------------
+// Block-cooperative binning shared by K1 (count) and K2 (emit).
+// The scene is stored in Morton order, so the 256 Gaussians of a block overlap a small set of
+// tiles.  Their (Gaussian, tile) pairs are first accumulated in an LDS table over the block's
+// tile bounding box, then ONE global atomic per touched tile adds the count (K1) or reserves a
+// slot range (K2).  Gaussians with > AGG_MAX_TILES tiles (close-ups) are expanded by the whole
+// block, one tile per thread, straight on the global counters.
+// ---------------------------------------------------------------------------
+constexpr int AGG_CAP = 4096;          // LDS table entries (16 KB)
+constexpr int AGG_MAX_TILES = 64;
 
-    // ray_direction = (position - camera.position).normalize()            src/pipelines.rs:99
-    float dxw = px - fc.cam[0], dyw = py - fc.cam[1], dzw = pz - fc.cam[2];
-    float nrm = sqrtf((dxw * dxw + dyw * dyw) + dzw * dzw);
-    float x = dxw / nrm, y = dyw / nrm, z = dzw / nrm;
+struct BinShared {
+    unsigned int table[AGG_CAP];
+    int box[4];                        // min tx, min ty, max tx, max ty of the aggregated Gaussians
+    unsigned int nbig;
+    int big[256][4];                   // tile rects of the block's big Gaussians
+    unsigned long long bigkey[256];
+};
 
-    // eval_spherical_harmonics                                           src/gaussians.rs:40-99
-    float col[3];
+template <bool EMIT>
+__device__ __forceinline__ void bin_block(BinShared& sh, bool vis, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                          unsigned int* __restrict__ gcount, unsigned long long* __restrict__ keys,
+                                          unsigned long long key) {
+    const unsigned int tid = threadIdx.x;
+    const int ntiles = vis ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
+    const bool small = vis && ntiles <= AGG_MAX_TILES;
+    const bool big = vis && !small;
+    if (tid == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
+    __syncthreads();
+    {   // block bounding box of the aggregated rectangles: wave reduce, then one LDS atomic per wave
+        int a = small ? tx0 : 0x7fffffff, b = small ? ty0 : 0x7fffffff, c = small ? tx1 : -1, d = small ? ty1 : -1;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) col[ch] = SH_C0 * sh[ch];
-    if (fc.sh_dim > 3) {
-        float k1 = SH_C1 * y, k2 = SH_C1 * z, k3 = SH_C1 * x;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) col[ch] = col[ch] - k1 * sh[3 + ch] + k2 * sh[6 + ch] - k3 * sh[9 + ch];
-        if (fc.sh_dim > 12) {
-            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            float k4 = SH_C2_0 * xy, k5 = SH_C2_1 * yz, k6 = SH_C2_2 * (2.0f * zz - xx - yy);
-            float k7 = SH_C2_3 * xz, k8 = SH_C2_4 * (xx - yy);
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
-                col[ch] = col[ch] + k4 * sh[12 + ch] + k5 * sh[15 + ch] + k6 * sh[18 + ch] + k7 * sh[21 + ch] +
-                          k8 * sh[24 + ch];
-            if (fc.sh_dim > 27) {
-#pragma unroll
-                for (int p = LIVE_PLANES; p < SCENE_PLANES; ++p) {
-                    float4 v = planes[(uint64_t)p * n + i];
-                    F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
-                }
-                float k9 = SH_C3_0 * y * (3.0f * xx - yy), k10 = SH_C3_1 * xy * z;
-                float k11 = SH_C3_2 * y * (4.0f * zz - xx - yy);
-                float k12 = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-                float k13 = SH_C3_4 * x * (4.0f * zz - xx - yy), k14 = SH_C3_5 * z * (xx - yy);
-                float k15 = SH_C3_6 * x * (xx - 3.0f * yy);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-                    col[ch] = col[ch] + k9 * sh[27 + ch] + k10 * sh[30 + ch] + k11 * sh[33 + ch] + k12 * sh[36 + ch] +
-                              k13 * sh[39 + ch] + k14 * sh[42 + ch] + k15 * sh[45 + ch];
-            }
+        for (int o = 32; o > 0; o >>= 1) {
+            a = min(a, __shfl_xor(a, o)); b = min(b, __shfl_xor(b, o));
+            c = max(c, __shfl_xor(c, o)); d = max(d, __shfl_xor(d, o));
+        }
+        if ((tid & 63u) == 0 && c >= 0) {
+            atomicMin(&sh.box[0], a); atomicMin(&sh.box[1], b); atomicMax(&sh.box[2], c); atomicMax(&sh.box[3], d);
+        }
+        if (big) {
+            unsigned int k = atomicAdd(&sh.nbig, 1u);
+            sh.big[k][0] = tx0; sh.big[k][1] = tx1; sh.big[k][2] = ty0; sh.big[k][3] = ty1;
+            sh.bigkey[k] = key;
         }
     }
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) col[ch] = col[ch] + 0.5f;   // HALF, no clamp
-
-    // project_cov3d_to_screen                                            src/gaussians.rs:114-161
-    float pc[4];
-    mat4_vec(fc.view, px, py, pz, 1.0f, pc);
-    float limx = 1.3f * fc.htanx, limy = 1.3f * fc.htany;
-    float txtz = pc[0] / pc[2], tytz = pc[1] / pc[2];
-    float tx = fminf(limx, fmaxf(-limx, txtz)) * pc[2];
-    float ty = fminf(limy, fmaxf(-limy, tytz)) * pc[2];
-    float tz = pc[2];
-    Mat3 J;
-    M3(J, 0, 0) = fc.focal / tz; M3(J, 0, 1) = 0.0f;          M3(J, 0, 2) = -(fc.focal * tx) / (tz * tz);
-    M3(J, 1, 0) = 0.0f;          M3(J, 1, 1) = fc.focal / tz; M3(J, 1, 2) = -(fc.focal * ty) / (tz * tz);
-    M3(J, 2, 0) = 0.0f;          M3(J, 2, 1) = 0.0f;          M3(J, 2, 2) = 0.0f;
-    Mat3 Wm;   // viewmatrix.fixed_view::<3,3>(0,0).transpose()
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) M3(Wm, r, c) = fc.view[r * 4 + c];
-    Mat3 T = mat3_mul(Wm, J);
-    Mat3 Sg;
-#pragma unroll
-    for (int e = 0; e < 9; ++e) Sg.m[e] = F[4 + e];
-    Mat3 cov = mat3_mul(mat3_mul(mat3_t(T), mat3_t(Sg)), T);
-    float m11 = M3(cov, 0, 0) + fc.lowpass, m21 = M3(cov, 1, 0), m12 = M3(cov, 0, 1), m22 = M3(cov, 1, 1) + fc.lowpass;
-
-    // gaussian_vertex_shader                                             src/pipelines.rs:17-51
-    float det = m11 * m22 - m21 * m12;       // nalgebra 2x2 try_inverse
-    float q[4];
-    mat4_vec(fc.proj, pc[0], pc[1], pc[2], pc[3], q);
-    float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];
-    float ca = m22 / det, cb = -m12 / det, cc = m11 / det;
-    float hx = 3.0f * sqrtf(m11), hy = 3.0f * sqrtf(m22);
-    // euc: NDC -> target pixels
-    float cx = (ndcx * 0.5f + 0.5f) * fc.w;
-    float cy = fc.y_up ? (ndcy * -0.5f + 0.5f) * fc.h : (ndcy * 0.5f + 0.5f) * fc.h;
-
-    bool singular = (det == 0.0f);
-    bool vis = !singular && finitef(cx) && finitef(cy) && finitef(hx) && finitef(hy) && finitef(ca) && finitef(cb) &&
-               finitef(cc) && finitef(ndcz);
-    if (vis && fc.zclip) vis = (fc.zmin <= ndcz) && (ndcz <= fc.zmax);
-    // pixel ranges that can be covered at all on this target (the slab bounds the y range only)
-    int x0 = 1, x1 = 0, y0 = 1, y1 = 0, fx0 = 1, fx1 = 0, fy0 = 1, fy1 = 0;
-    const float off = fc.sample_half ? 0.5f : 0.0f;
-    bool on_target = vis && covered_interval(cx, hx, off, 0, fc.W - 1, &fx0, &fx1) &&
-                     covered_interval(cy, hy, off, 0, fc.H - 1, &fy0, &fy1);
-    bool in_slab = false;
-    if (on_target) {
-        x0 = fx0; x1 = fx1;
-        y0 = max(fy0, fc.row_px0); y1 = min(fy1, fc.row_px1 - 1);
-        in_slab = y0 <= y1;
-    }
-    Rec r;
-    r.a = make_float4(cx, cy, hx, hy);
-    r.b = make_float4(ca, cb, cc, opacity);
-    r.c = make_float4(col[0], col[1], col[2], 0.0f);
-    recs[i] = r;
-    depth[i] = pc[2];
-    // the rectangle kept for debug/parity is the whole-target one; tiles are emitted for the slab part
-    rect[i] = on_target ? make_ushort4((unsigned short)fx0, (unsigned short)fx1, (unsigned short)fy0, (unsigned short)fy1)
-                        : make_ushort4(1, 0, 1, 0);
-    if (singular) atomicAdd(&status->n_singular, 1ull);
-    if (!in_slab) return;
-    atomicAdd(&status->n_visible, 1ull);
-    int tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = (y0 >> 4) - fc.tile_row0, ty1 = (y1 >> 4) - fc.tile_row0;
-    unsigned int sub = (unsigned int)i & (SUB - 1);
-    for (int tyy = ty0; tyy <= ty1; ++tyy)
-        for (int txx = tx0; txx <= tx1; ++txx)
-            atomicAdd(&counts[(unsigned int)(tyy * fc.tiles_x + txx) * SUB + sub], 1u);
-}
-
-// Exclusive scan of the m = n_tiles*SUB counters by ONE 1024-thread workgroup (m <= ~1M).
-// Writes offsets[0..m] and cursor[0..m), zeroes counts for the next frame, reports D.
-__global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int* __restrict__ counts,
-                                                    unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor,
-                                                    FrameStatus* __restrict__ status, unsigned long long capacity) {
-    __shared__ unsigned int part[1024];
-    __shared__ unsigned int red[16];
-    const unsigned int tid = threadIdx.x;
-    const unsigned int chunk = (m + 1023u) / 1024u;
-    const unsigned int lo = min(tid * chunk, m), hi = min(lo + chunk, m);
-    unsigned int sum = 0;
-    for (unsigned int k = lo; k < hi; ++k) sum += counts[k];
-    part[tid] = sum;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
-    for (unsigned int d = 1; d < 1024; d <<= 1) {
-        unsigned int v = (tid >= d) ? part[tid - d] : 0u;
+    const int bx0 = sh.box[0], by0 = sh.box[1], bw = sh.box[2] - bx0 + 1, bh = sh.box[3] - by0 + 1;
+    const int area = (sh.box[2] >= 0) ? bw * bh : 0;
+    const bool agg = area > 0 && area <= AGG_CAP;
+    const unsigned int nbig = sh.nbig;
+    if (agg) {
+        for (int e = (int)tid; e < area; e += 256) sh.table[e] = 0;
         __syncthreads();
-        part[tid] += v;
+        if (small)
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&sh.table[(ty - by0) * bw + (tx - bx0)], 1u);
         __syncthreads();
+        for (int e = (int)tid; e < area; e += 256) {
+            unsigned int c = sh.table[e];
+            if (c) {
+                unsigned int tile = (unsigned int)((by0 + e / bw) * tiles_x + bx0 + e % bw);
+                unsigned int base = atomicAdd(&gcount[tile], c);
+                if (EMIT) sh.table[e] = base;
+            }
+        }
+        if (EMIT) {
+            __syncthreads();
+            if (small)
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) {
+                        unsigned int slot = atomicAdd(&sh.table[(ty - by0) * bw + (tx - bx0)], 1u);
+                        keys[slot] = key;
+                    }
+        }
+    } else if (small) {   // bounding box larger than the table (incoherent block): direct
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) {
+                unsigned int slot = atomicAdd(&gcount[(unsigned int)(ty * tiles_x + tx)], 1u);
+                if (EMIT) keys[slot] = key;
+            }
     }
-    unsigned int run = part[tid] - sum;
-    for (unsigned int k = lo; k < hi; ++k) {
-        unsigned int c = counts[k];
-        counts[k] = 0;
-        offsets[k] = run;
-        cursor[k] = run;
-        run += c;
-    }
-    const unsigned int total = part[1023];
-    if (tid == 0) {
-        offsets[m] = total;
-        status->n_pairs = total;
-        status->overflow = ((unsigned long long)total > capacity) ? 1u : 0u;
-    }
-    __syncthreads();   // offsets[] written by this workgroup are visible to it
-    unsigned int mx = 0;
-    const unsigned int n_tiles = m / SUB;
-    for (unsigned int t = tid; t < n_tiles; t += 1024) {
-        unsigned int b = offsets[t * SUB], e = (t + 1 == n_tiles) ? total : offsets[(t + 1) * SUB];
-        mx = max(mx, e - b);
-    }
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    if (tid == 0) {
-        for (int k = 0; k < 16; ++k) mx = max(mx, red[k]);
-        status->max_tile_len = mx;
+    // close-ups: every thread takes tiles of each big rectangle
+    for (unsigned int k = 0; k < nbig; ++k) {
+        const int X0 = sh.big[k][0], X1 = sh.big[k][1], Y0 = sh.big[k][2], Y1 = sh.big[k][3];
+        const int w = X1 - X0 + 1, cnt = w * (Y1 - Y0 + 1);
+        const unsigned long long kk = sh.bigkey[k];
+        for (int e = (int)tid; e < cnt; e += 256) {
+            unsigned int slot = atomicAdd(&gcount[(unsigned int)((Y0 + e / w) * tiles_x + X0 + e % w)], 1u);
+            if (EMIT) keys[slot] = kk;
+        }
     }
 }
 
@@ -317,27 +236,226 @@ __device__ __forceinline__ unsigned int depth_key(float z) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// K2 -- one thread per Gaussian: claim a slot in every overlapped tile's bucket and write the
-// 64-bit key (depth_key << 32 | index).  Bucket order is arbitrary; K3 fixes it.
-__global__ __launch_bounds__(256) void emit_kernel(uint64_t n, FrameConst fc, const float* __restrict__ depth,
-                                                   const ushort4* __restrict__ rect, unsigned int* __restrict__ cursor,
-                                                   unsigned long long* __restrict__ keys,
-                                                   const FrameStatus* __restrict__ status) {
-    if (status->overflow) return;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    ushort4 rc = rect[i];
-    if (rc.x > rc.y) return;
-    int y0 = max((int)rc.z, fc.row_px0), y1 = min((int)rc.w, fc.row_px1 - 1);
-    if (y0 > y1) return;
-    unsigned long long key = ((unsigned long long)depth_key(depth[i]) << 32) | (unsigned long long)(unsigned int)i;
-    int tx0 = rc.x >> 4, tx1 = rc.y >> 4, ty0 = (y0 >> 4) - fc.tile_row0, ty1 = (y1 >> 4) - fc.tile_row0;
-    unsigned int sub = (unsigned int)i & (SUB - 1);
-    for (int tyy = ty0; tyy <= ty1; ++tyy)
-        for (int txx = tx0; txx <= tx1; ++txx) {
-            unsigned int slot = atomicAdd(&cursor[(unsigned int)(tyy * fc.tiles_x + txx) * SUB + sub], 1u);
-            keys[slot] = key;
+// K1 -- one thread per Gaussian (slot j of the Morton-ordered scene, original index orig[j]): the
+// whole vertex stage, a 48-B record, the exactly covered pixel rectangle, and per-tile counts.
+__global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes,
+                                                         const unsigned int* __restrict__ orig, FrameConst fc,
+                                                         Rec* __restrict__ recs, float* __restrict__ depth,
+                                                         ushort4* __restrict__ rect, unsigned int* __restrict__ counts,
+                                                         FrameStatus* __restrict__ status) {
+    __shared__ BinShared sh;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool singular = false, in_slab = false;
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    if (i < n) {
+    float F[64];
+#pragma unroll
+        for (int p = 0; p < LIVE_PLANES; ++p) {
+            float4 v = planes[(uint64_t)p * n + i];
+            F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
+        const float px = F[0], py = F[1], pz = F[2], opacity = F[3];
+        const float* sh = F + 13;
+
+        // ray_direction = (position - camera.position).normalize()            src/pipelines.rs:99
+        float dxw = px - fc.cam[0], dyw = py - fc.cam[1], dzw = pz - fc.cam[2];
+        float nrm = sqrtf((dxw * dxw + dyw * dyw) + dzw * dzw);
+        float x = dxw / nrm, y = dyw / nrm, z = dzw / nrm;
+
+        // eval_spherical_harmonics                                           src/gaussians.rs:40-99
+        float col[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) col[ch] = SH_C0 * sh[ch];
+        if (fc.sh_dim > 3) {
+            float k1 = SH_C1 * y, k2 = SH_C1 * z, k3 = SH_C1 * x;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) col[ch] = col[ch] - k1 * sh[3 + ch] + k2 * sh[6 + ch] - k3 * sh[9 + ch];
+            if (fc.sh_dim > 12) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                float k4 = SH_C2_0 * xy, k5 = SH_C2_1 * yz, k6 = SH_C2_2 * (2.0f * zz - xx - yy);
+                float k7 = SH_C2_3 * xz, k8 = SH_C2_4 * (xx - yy);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    col[ch] = col[ch] + k4 * sh[12 + ch] + k5 * sh[15 + ch] + k6 * sh[18 + ch] + k7 * sh[21 + ch] +
+                              k8 * sh[24 + ch];
+                if (fc.sh_dim > 27) {
+#pragma unroll
+                    for (int p = LIVE_PLANES; p < SCENE_PLANES; ++p) {
+                        float4 v = planes[(uint64_t)p * n + i];
+                        F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
+                    }
+                    float k9 = SH_C3_0 * y * (3.0f * xx - yy), k10 = SH_C3_1 * xy * z;
+                    float k11 = SH_C3_2 * y * (4.0f * zz - xx - yy);
+                    float k12 = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                    float k13 = SH_C3_4 * x * (4.0f * zz - xx - yy), k14 = SH_C3_5 * z * (xx - yy);
+                    float k15 = SH_C3_6 * x * (xx - 3.0f * yy);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)
+                        col[ch] = col[ch] + k9 * sh[27 + ch] + k10 * sh[30 + ch] + k11 * sh[33 + ch] + k12 * sh[36 + ch] +
+                                  k13 * sh[39 + ch] + k14 * sh[42 + ch] + k15 * sh[45 + ch];
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) col[ch] = col[ch] + 0.5f;   // HALF, no clamp
+
+        // project_cov3d_to_screen                                            src/gaussians.rs:114-161
+        float pc[4];
+        mat4_vec(fc.view, px, py, pz, 1.0f, pc);
+        float limx = 1.3f * fc.htanx, limy = 1.3f * fc.htany;
+        float txtz = pc[0] / pc[2], tytz = pc[1] / pc[2];
+        float tx = fminf(limx, fmaxf(-limx, txtz)) * pc[2];
+        float ty = fminf(limy, fmaxf(-limy, tytz)) * pc[2];
+        float tz = pc[2];
+        Mat3 J;
+        M3(J, 0, 0) = fc.focal / tz; M3(J, 0, 1) = 0.0f;          M3(J, 0, 2) = -(fc.focal * tx) / (tz * tz);
+        M3(J, 1, 0) = 0.0f;          M3(J, 1, 1) = fc.focal / tz; M3(J, 1, 2) = -(fc.focal * ty) / (tz * tz);
+        M3(J, 2, 0) = 0.0f;          M3(J, 2, 1) = 0.0f;          M3(J, 2, 2) = 0.0f;
+        Mat3 Wm;   // viewmatrix.fixed_view::<3,3>(0,0).transpose()
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) M3(Wm, r, c) = fc.view[r * 4 + c];
+        Mat3 T = mat3_mul(Wm, J);
+        Mat3 Sg;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Sg.m[e] = F[4 + e];
+        Mat3 cov = mat3_mul(mat3_mul(mat3_t(T), mat3_t(Sg)), T);
+        float m11 = M3(cov, 0, 0) + fc.lowpass, m21 = M3(cov, 1, 0), m12 = M3(cov, 0, 1), m22 = M3(cov, 1, 1) + fc.lowpass;
+
+        // gaussian_vertex_shader                                             src/pipelines.rs:17-51
+        float det = m11 * m22 - m21 * m12;       // nalgebra 2x2 try_inverse
+        float q[4];
+        mat4_vec(fc.proj, pc[0], pc[1], pc[2], pc[3], q);
+        float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];
+        float ca = m22 / det, cb = -m12 / det, cc = m11 / det;
+        float hx = 3.0f * sqrtf(m11), hy = 3.0f * sqrtf(m22);
+        // euc: NDC -> target pixels
+        float cx = (ndcx * 0.5f + 0.5f) * fc.w;
+        float cy = fc.y_up ? (ndcy * -0.5f + 0.5f) * fc.h : (ndcy * 0.5f + 0.5f) * fc.h;
+
+
+        singular = (det == 0.0f);
+        bool vis = !singular && finitef(cx) && finitef(cy) && finitef(hx) && finitef(hy) && finitef(ca) && finitef(cb) &&
+                   finitef(cc) && finitef(ndcz);
+        if (vis && fc.zclip) vis = (fc.zmin <= ndcz) && (ndcz <= fc.zmax);
+        // exactly covered pixel ranges on the whole target; the slab then bounds the rows
+        int fx0 = 1, fx1 = 0, fy0 = 1, fy1 = 0;
+        const float off = fc.sample_half ? 0.5f : 0.0f;
+        bool on_target = vis && covered_interval(cx, hx, off, 0, fc.W - 1, &fx0, &fx1) &&
+                         covered_interval(cy, hy, off, 0, fc.H - 1, &fy0, &fy1);
+        if (on_target) {
+            int y0 = max(fy0, fc.row_px0), y1 = min(fy1, fc.row_px1 - 1);
+            in_slab = y0 <= y1;
+            tx0 = fx0 >> 4; tx1 = fx1 >> 4; ty0 = (y0 >> 4) - fc.tile_row0; ty1 = (y1 >> 4) - fc.tile_row0;
+        }
+        // fragments with power < pthr have alpha < 1/255 for certain (margin 1e-3 >> f32 error)
+        float pthr = (opacity > 0.0f) ? (logf(1.0f / (255.0f * opacity)) - 1e-3f)
+                                      : ((opacity <= 0.0f) ? 3.0e38f : -3.0e38f);
+        Rec r;
+        r.a = make_float4(cx, cy, hx, hy);
+        r.b = make_float4(ca, cb, cc, opacity);
+        r.c = make_float4(col[0], col[1], col[2], pthr);
+        recs[orig[i]] = r;
+        depth[i] = pc[2];
+        rect[i] = on_target ? make_ushort4((unsigned short)fx0, (unsigned short)fx1, (unsigned short)fy0, (unsigned short)fy1)
+                            : make_ushort4(1, 0, 1, 0);
+    }
+    const int nvis = __syncthreads_count(in_slab), nsing = __syncthreads_count(singular);
+    if (threadIdx.x == 0) {
+        if (nvis) atomicAdd(&status->n_visible, (unsigned long long)nvis);
+        if (nsing) atomicAdd(&status->n_singular, (unsigned long long)nsing);
+    }
+    bin_block<false>(sh, in_slab, tx0, tx1, ty0, ty1, fc.tiles_x, counts, nullptr, 0ull);
+}
+
+// Exclusive scan of the per-tile counts by ONE 1024-thread workgroup, 1024 tiles per step with a
+// running carry.  Writes offsets[0..m] and cursor[0..m), zeroes counts for the next frame,
+// reports D / overflow / longest list, and emits `order`: tile ids by descending list-length
+// class, so the sort and composite grids start their longest tiles first (no long tail).
+__global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int* __restrict__ counts,
+                                                    unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor,
+                                                    unsigned int* __restrict__ order, FrameStatus* __restrict__ status,
+                                                    unsigned long long capacity) {
+    constexpr int NCLS = 64;
+    __shared__ unsigned int wsum[16];
+    __shared__ unsigned int hist[NCLS];
+    __shared__ unsigned int start[NCLS];
+    const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid < NCLS) hist[tid] = 0;
+    unsigned int carry = 0, mx = 0;
+    auto cls_of = [](unsigned int c) -> unsigned int {
+        if (c == 0) return 0u;
+        unsigned int msb = 31u - (unsigned int)__clz((int)c);
+        unsigned int half = msb ? ((c >> (msb - 1)) & 1u) : 0u;
+        return min(1u + 2u * msb + half, (unsigned int)NCLS - 1u);
+    };
+    __syncthreads();
+    for (unsigned int base = 0; base < m; base += 1024) {
+        const unsigned int k = base + tid;
+        unsigned int c = 0;
+        if (k < m) { c = counts[k]; counts[k] = 0; }
+        mx = max(mx, c);
+        unsigned int v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned int t = (unsigned int)__shfl_up((int)v, o);
+            if ((int)lane >= o) v += t;
+        }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        unsigned int woff = 0, total = 0;
+#pragma unroll
+        for (unsigned int w = 0; w < 16; ++w) { unsigned int x = wsum[w]; total += x; if (w < wave) woff += x; }
+        const unsigned int excl = carry + woff + v - c;
+        if (k < m) { offsets[k] = excl; cursor[k] = excl; atomicAdd(&hist[cls_of(c)], 1u); }
+        carry += total;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+    if (lane == 0) wsum[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 0; w < 16; ++w) mx = max(mx, wsum[w]);
+        offsets[m] = carry;
+        status->n_pairs = carry;
+        status->overflow = ((unsigned long long)carry > capacity) ? 1u : 0u;
+        status->max_tile_len = mx;
+        unsigned int run = 0;
+        for (int cidx = NCLS - 1; cidx >= 0; --cidx) { start[cidx] = run; run += hist[cidx]; }
+    }
+    __syncthreads();   // offsets[] written above by this workgroup are visible to it
+    for (unsigned int k = tid; k < m; k += 1024) {
+        unsigned int b = offsets[k], e = (k + 1 == m) ? carry : offsets[k + 1];
+        order[atomicAdd(&start[cls_of(e - b)], 1u)] = k;
+    }
+}
+
+// K2 -- one thread per Gaussian slot: claim a slot in every overlapped tile's bucket and write the
+// 64-bit key (depth_key << 32 | ORIGINAL index).  Bucket order is arbitrary; K3 fixes it.
+__global__ __launch_bounds__(256) void emit_kernel(uint64_t n, FrameConst fc, const float* __restrict__ depth,
+                                                   const ushort4* __restrict__ rect, const unsigned int* __restrict__ orig,
+                                                   unsigned int* __restrict__ cursor, unsigned long long* __restrict__ keys,
+                                                   const FrameStatus* __restrict__ status) {
+    __shared__ BinShared sh;
+    if (status->overflow) return;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool vis = false;
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    unsigned long long key = 0;
+    if (i < n) {
+        ushort4 rc = rect[i];
+        if (rc.x <= rc.y) {
+            int y0 = max((int)rc.z, fc.row_px0), y1 = min((int)rc.w, fc.row_px1 - 1);
+            if (y0 <= y1) {
+                vis = true;
+                tx0 = rc.x >> 4; tx1 = rc.y >> 4; ty0 = (y0 >> 4) - fc.tile_row0; ty1 = (y1 >> 4) - fc.tile_row0;
+                key = ((unsigned long long)depth_key(depth[i]) << 32) | (unsigned long long)orig[i];
+            }
+        }
+    }
+    bin_block<true>(sh, vis, tx0, tx1, ty0, ty1, fc.tiles_x, cursor, keys, key);
 }
 
 // ---------------------------------------------------------------------------
@@ -379,12 +497,13 @@ constexpr unsigned int SORT_SMALL_CAP = 2048;    // 16 KB LDS, 256 threads
 constexpr unsigned int SORT_BIG_CAP = 16384;     // 128 KB LDS, 1024 threads
 
 __global__ __launch_bounds__(256) void sort_tiles_small_kernel(const unsigned int* __restrict__ offsets,
+                                                               const unsigned int* __restrict__ order,
                                                                unsigned long long* __restrict__ keys,
                                                                const FrameStatus* __restrict__ status) {
     __shared__ unsigned long long s[SORT_SMALL_CAP];
     if (status->overflow) return;
-    const unsigned int tile = blockIdx.x;
-    const unsigned int b = offsets[tile * SUB], e = offsets[(tile + 1) * SUB];
+    const unsigned int tile = order[blockIdx.x];
+    const unsigned int b = offsets[tile], e = offsets[tile + 1];
     const unsigned int n = e - b;
     if (n < 2 || n > SORT_SMALL_CAP) return;
     for (unsigned int t = threadIdx.x; t < n; t += 256) s[t] = keys[b + t];
@@ -394,13 +513,14 @@ __global__ __launch_bounds__(256) void sort_tiles_small_kernel(const unsigned in
 }
 
 __global__ __launch_bounds__(1024) void sort_tiles_big_kernel(const unsigned int* __restrict__ offsets,
+                                                              const unsigned int* __restrict__ order,
                                                               unsigned long long* __restrict__ keys,
                                                               const FrameStatus* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
     if (status->overflow) return;
-    const unsigned int tile = blockIdx.x;
-    const unsigned int b = offsets[tile * SUB], e = offsets[(tile + 1) * SUB];
+    const unsigned int tile = order[blockIdx.x];
+    const unsigned int b = offsets[tile], e = offsets[tile + 1];
     const unsigned int n = e - b;
     if (n <= SORT_SMALL_CAP) return;
     if (n <= SORT_BIG_CAP) {
@@ -423,7 +543,7 @@ __global__ __launch_bounds__(1024) void sort_tiles_big_kernel(const unsigned int
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float div255(float k) {
     // == k / 255.0f (IEEE) for every integer k in [0,255]: one multiply + two fma refinement steps
-    // (checked exhaustively in tests/test_host_math.py::test_div255_identity)
+    // (checked exhaustively in tests/test_host.py::test_div255_identity)
     const float r = 1.0f / 255.0f;
     float q = k * r;
     float e = fmaf(-255.0f, q, k);
@@ -435,6 +555,7 @@ __device__ __forceinline__ float quant_u8(float v) {
 }
 
 __global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+                                                              const unsigned int* __restrict__ order,
                                                               const unsigned long long* __restrict__ keys,
                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                               const FrameStatus* __restrict__ status) {
@@ -442,13 +563,13 @@ __global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, con
     __shared__ float4 sB[256];
     __shared__ float4 sC[256];
     if (status->overflow) return;
-    const unsigned int tile = blockIdx.x;
+    const unsigned int tile = order[blockIdx.x];
     const unsigned int tid = threadIdx.x;
+    const unsigned int beg = offsets[tile], end = offsets[tile + 1];
+    if (beg == end) return;
     const int txx = (int)(tile % (unsigned int)fc.tiles_x), tyy = (int)(tile / (unsigned int)fc.tiles_x) + fc.tile_row0;
     const int px = txx * TILE + (int)(tid & 15u), py = tyy * TILE + (int)(tid >> 4);
     const bool inside = px < fc.W && py < fc.H && py >= fc.row_px0 && py < fc.row_px1;
-    const unsigned int beg = offsets[tile * SUB], end = offsets[(tile + 1) * SUB];
-    if (beg == end) return;
     const float off = fc.sample_half ? 0.5f : 0.0f;
     const float sx = (float)px + off, sy = (float)py + off;
     uint32_t old = inside ? argb[(size_t)py * fc.W + px] : 0u;
@@ -472,21 +593,25 @@ __global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, con
             float4 c = sC[j];
             // fragment(): src/pipelines.rs:134-143
             float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-            float alpha = fminf(0.99f, b.w * expf(power));
-            bool accept = cov && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (accept) {
-                // blend(): src/pipelines.rs:147-167
-                float ia = 1.0f - alpha;
-                float br = ia * div255(R) + alpha * c.x;
-                float bg = ia * div255(G) + alpha * c.y;
-                float bb = ia * div255(B) + alpha * c.z;
-                R = quant_u8(br * 255.0f);
-                G = quant_u8(bg * 255.0f);
-                B = quant_u8(bb * 255.0f);
-                A = quant_u8(alpha * 255.0f);
-            } else if (cov) {
-                A = 0.0f;   // rejected fragments are (0,0,0,0) and still blended: RGB unchanged, A := 0
+            // c.w: below this power alpha < 1/255 for certain -> no lane of the wave needs exp()
+            bool maybe = cov && !(power > 0.0f) && !(power < c.w);
+            bool accept = false;
+            if (__any(maybe)) {
+                float alpha = fminf(0.99f, b.w * expf(power));
+                accept = maybe && !(alpha < 1.0f / 255.0f);
+                if (accept) {
+                    // blend(): src/pipelines.rs:147-167
+                    float ia = 1.0f - alpha;
+                    float br = ia * div255(R) + alpha * c.x;
+                    float bg = ia * div255(G) + alpha * c.y;
+                    float bb = ia * div255(B) + alpha * c.z;
+                    R = quant_u8(br * 255.0f);
+                    G = quant_u8(bg * 255.0f);
+                    B = quant_u8(bb * 255.0f);
+                    A = quant_u8(alpha * 255.0f);
+                }
             }
+            if (cov && !accept) A = 0.0f;   // rejected fragments are (0,0,0,0), still blended: RGB unchanged, A := 0
         }
         __syncthreads();
     }
@@ -500,31 +625,31 @@ __global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, con
 static inline unsigned int blocks_for(uint64_t n, unsigned int bs) { return (unsigned int)((n + bs - 1) / bs); }
 
 void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
-                       const float* sh, float4* planes) {
+                       const float* sh, const unsigned int* perm, float4* planes) {
     if (!n) return;
-    hipLaunchKernelGGL(pack_scene_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, pos4, cov3d, opacity, sh, planes);
+    hipLaunchKernelGGL(pack_scene_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, pos4, cov3d, opacity, sh, perm, planes);
 }
 void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d) {
     if (!n) return;
     hipLaunchKernelGGL(cov3d_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, scales3, rot4, cov3d);
 }
-void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, FrameConst fc, Rec* recs, float* depth,
-                       ushort4* rect, unsigned int* counts, FrameStatus* status) {
+void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
+                       float* depth, ushort4* rect, unsigned int* counts, FrameStatus* status) {
     if (!n) return;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, fc, recs, depth, rect,
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth, rect,
                        counts, status);
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
-                 FrameStatus* status, unsigned long long capacity) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, status, capacity);
+                 unsigned int* order, FrameStatus* status, unsigned long long capacity) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, status, capacity);
 }
-void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect,
+void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
     if (!n) return;
-    hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, fc, depth, rect, cursor, keys, status);
+    hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, fc, depth, rect, orig, cursor, keys, status);
 }
-void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, unsigned long long* keys,
-                 const FrameStatus* status) {
+void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
+                 unsigned long long* keys, const FrameStatus* status) {
     if (!n_tiles) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -532,13 +657,14 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offset
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SORT_BIG_CAP * 8);
         attr_set = true;
     }
-    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, keys, status);
-    hipLaunchKernelGGL(sort_tiles_big_kernel, dim3(n_tiles), dim3(1024), SORT_BIG_CAP * 8, s, offsets, keys, status);
+    hipLaunchKernelGGL(sort_tiles_big_kernel, dim3(n_tiles), dim3(1024), SORT_BIG_CAP * 8, s, offsets, order, keys, status);
+    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, order, keys, status);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
-                      const unsigned long long* keys, const Rec* recs, uint32_t* argb, const FrameStatus* status) {
+                      const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
+                      const FrameStatus* status) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), 0, s, fc, offsets, keys, recs, argb, status);
+    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), 0, s, fc, offsets, order, keys, recs, argb, status);
 }
 
 }  // namespace splat
