@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsplat_hip.so")
+LIB_PATH = os.environ.get("SPLAT_AMD_LIB") or os.path.join(_HERE, "libsplat_hip.so")   # override: A/B builds
 
 SPLAT_OK, ERR_INVALID, ERR_HIP, ERR_NO_SCENE, ERR_CAPACITY = 0, -1, -2, -3, -4
 TILE = 16

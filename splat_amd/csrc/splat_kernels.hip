@@ -554,6 +554,15 @@ __device__ __forceinline__ float quant_u8(float v) {
     return truncf(fminf(fmaxf(v, 0.0f), 255.0f));
 }
 
+// Does ANY sample s = lo + k (k = 0..count-1, all exactly representable) satisfy |s - c| <= h ?
+// |s - c| grows monotonically (also after f32 rounding) away from c, so testing the one or two
+// samples nearest to c is exact.
+__device__ __forceinline__ bool any_sample_covered(float c, float h, float lo, float hi, float off) {
+    float s1 = fminf(fmaxf(floorf(c - off) + off, lo), hi);
+    float s2 = fminf(s1 + 1.0f, hi);
+    return (int)(fabsf(s1 - c) <= h) | (int)(fabsf(s2 - c) <= h);
+}
+
 __global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned long long* __restrict__ keys,
@@ -562,56 +571,92 @@ __global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, con
     __shared__ float4 sA[256];
     __shared__ float4 sB[256];
     __shared__ float4 sC[256];
+    __shared__ unsigned long long smask[4][4];   // [target wave][loader wave]: records touching the wave's 16x4 pixels
     if (status->overflow) return;
     const unsigned int tile = order[blockIdx.x];
     const unsigned int tid = threadIdx.x;
-    const unsigned int beg = offsets[tile], end = offsets[tile + 1];
+    const unsigned int beg = __builtin_amdgcn_readfirstlane(offsets[tile]);
+    const unsigned int end = __builtin_amdgcn_readfirstlane(offsets[tile + 1]);
     if (beg == end) return;
+    const unsigned int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const int txx = (int)(tile % (unsigned int)fc.tiles_x), tyy = (int)(tile / (unsigned int)fc.tiles_x) + fc.tile_row0;
     const int px = txx * TILE + (int)(tid & 15u), py = tyy * TILE + (int)(tid >> 4);
     const bool inside = px < fc.W && py < fc.H && py >= fc.row_px0 && py < fc.row_px1;
     const float off = fc.sample_half ? 0.5f : 0.0f;
     const float sx = (float)px + off, sy = (float)py + off;
+    // sample extents of the tile (x) and of each wave's four rows (y), clipped to the target
+    const float xlo = (float)(txx * TILE) + off, xhi = (float)min(txx * TILE + TILE - 1, fc.W - 1) + off;
+    const int ylim = min(fc.H, fc.row_px1) - 1;
     uint32_t old = inside ? argb[(size_t)py * fc.W + px] : 0u;
     float R = (float)((old >> 16) & 0xffu), G = (float)((old >> 8) & 0xffu), B = (float)(old & 0xffu);
     float A = (float)(old >> 24);
     for (unsigned int base = beg; base < end; base += 256) {
         const unsigned int cnt = min(256u, end - base);
-        if (tid < cnt) {
-            unsigned int gi = (unsigned int)keys[base + tid];
-            Rec r = recs[gi];
-            sA[tid] = r.a; sB[tid] = r.b; sC[tid] = r.c;
-        }
-        __syncthreads();
-        for (unsigned int j = 0; j < cnt; ++j) {
-            float4 a = sA[j];
-            float dx = sx - a.x;
-            float dy = fc.y_up ? (a.y - sy) : (sy - a.y);   // coordxy.y grows with NDC y
-            bool cov = inside && (fabsf(dx) <= a.z) && (fabsf(dy) <= a.w);
-            if (!__any(cov)) continue;
-            float4 b = sB[j];
-            float4 c = sC[j];
-            // fragment(): src/pipelines.rs:134-143
-            float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-            // c.w: below this power alpha < 1/255 for certain -> no lane of the wave needs exp()
-            bool maybe = cov && !(power > 0.0f) && !(power < c.w);
-            bool accept = false;
-            if (__any(maybe)) {
-                float alpha = fminf(0.99f, b.w * expf(power));
-                accept = maybe && !(alpha < 1.0f / 255.0f);
-                if (accept) {
-                    // blend(): src/pipelines.rs:147-167
-                    float ia = 1.0f - alpha;
-                    float br = ia * div255(R) + alpha * c.x;
-                    float bg = ia * div255(G) + alpha * c.y;
-                    float bb = ia * div255(B) + alpha * c.z;
-                    R = quant_u8(br * 255.0f);
-                    G = quant_u8(bg * 255.0f);
-                    B = quant_u8(bb * 255.0f);
-                    A = quant_u8(alpha * 255.0f);
+        {
+            bool ok = tid < cnt;
+            bool ov[4] = {false, false, false, false};
+            if (ok) {
+                unsigned int gi = (unsigned int)keys[base + tid];
+                Rec r = recs[gi];
+                sA[tid] = r.a; sB[tid] = r.b; sC[tid] = r.c;
+                bool ovx = any_sample_covered(r.a.x, r.a.z, xlo, xhi, off);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    int y0 = tyy * TILE + 4 * w, y1 = min(y0 + 3, ylim);
+                    ov[w] = ovx && y0 <= y1 && any_sample_covered(r.a.y, r.a.w, (float)y0 + off, (float)y1 + off, off);
                 }
             }
-            if (cov && !accept) A = 0.0f;   // rejected fragments are (0,0,0,0), still blended: RGB unchanged, A := 0
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long m = __ballot(ov[w]);
+                if (lane == 0) smask[w][wave] = m;
+            }
+        }
+        __syncthreads();
+        const unsigned int nlw = (cnt + 63u) >> 6;
+        for (unsigned int lw = 0; lw < nlw; ++lw) {
+            unsigned long long mm = smask[wave][lw];
+            // (readfirstlane returns int: go through unsigned, or the low word sign-extends)
+            unsigned long long m = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(mm >> 32)) << 32) |
+                                   (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)mm);
+            if (!m) continue;
+            unsigned int j = lw * 64u + (unsigned int)__builtin_ctzll(m);
+            m &= m - 1;
+            float4 a = sA[j], b = sB[j], c = sC[j];
+            while (true) {
+                // prefetch the next overlapping record while this one is evaluated
+                const bool more = m != 0;
+                unsigned int jn = j;
+                if (more) { jn = lw * 64u + (unsigned int)__builtin_ctzll(m); m &= m - 1; }
+                float4 an = sA[jn], bn = sB[jn], cn = sC[jn];
+
+                float dx = sx - a.x;
+                float dy = fc.y_up ? (a.y - sy) : (sy - a.y);   // coordxy.y grows with NDC y
+                bool cov = inside & (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
+                // fragment(): src/pipelines.rs:134-143
+                float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+                // c.w: below this power alpha < 1/255 for certain -> no lane of the wave needs exp()
+                bool maybe = cov & !(power > 0.0f) & !(power < c.w);
+                bool accept = false;
+                if (__any(maybe)) {
+                    float alpha = fminf(0.99f, b.w * expf(power));
+                    accept = maybe & !(alpha < 1.0f / 255.0f);
+                    if (accept) {
+                        // blend(): src/pipelines.rs:147-167
+                        float ia = 1.0f - alpha;
+                        float br = ia * div255(R) + alpha * c.x;
+                        float bg = ia * div255(G) + alpha * c.y;
+                        float bb = ia * div255(B) + alpha * c.z;
+                        R = quant_u8(br * 255.0f);
+                        G = quant_u8(bg * 255.0f);
+                        B = quant_u8(bb * 255.0f);
+                        A = quant_u8(alpha * 255.0f);
+                    }
+                }
+                if (cov && !accept) A = 0.0f;   // rejected fragments are (0,0,0,0), still blended: RGB unchanged, A := 0
+                if (!more) break;
+                j = jn; a = an; b = bn; c = cn;
+            }
         }
         __syncthreads();
     }
