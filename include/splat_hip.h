@@ -68,6 +68,9 @@ typedef struct {
     uint64_t bytes_algorithmic; /* N*148 + n_visible*48 + D*60 + w*h*4   */
     /* device time of the last frame per kernel, ms (HIP events on the context's stream)  */
     float ms_preprocess, ms_scan, ms_emit, ms_sort, ms_composite, ms_total;
+    uint64_t n_fallback;   /* compositor waves whose early-out could not be proven exact and were redone in full */
+    uint64_t n_iter_scan;  /* compositor (wave, record) iterations spent in the front-to-back scan           */
+    uint64_t n_iter_blend; /* ... and in exact blending                                                      */
 } splat_stats;
 
 /* Projected per-Gaussian record as the kernels keep it (debug / stage parity). */

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -61,6 +62,9 @@ struct splat_ctx {
     int last_slot = -1;
     uint64_t overflow_want = 0;        // a harvested frame overflowed the pair buffer: grow to this
     FrameStatus last{};
+    float early_eps = 1e-7f;           // SPLAT_EARLY_EPS overrides (0 disables the early-out)
+    int early_min = 256;               // SPLAT_EARLY_MIN
+    int prio_len = 0x3fffffff;         // SPLAT_PRIO_LEN
     std::string err;
 };
 
@@ -171,6 +175,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->lowpass = cam->lowpass; fc->sh_dim = cam->sh_dim;
     fc->y_up = c->cfg.y_up; fc->sample_half = c->cfg.sample_half; fc->zclip = c->cfg.zclip;
     fc->zmin = c->cfg.zmin; fc->zmax = c->cfg.zmax;
+    fc->early_eps = c->early_eps; fc->early_min = c->early_min; fc->prio_len = c->prio_len;
     fc->W = (int)cam->w; fc->H = (int)cam->h;
     fc->tiles_x = (fc->W + TILE - 1) / TILE;
     int tiles_y = (fc->H + TILE - 1) / TILE;
@@ -233,6 +238,9 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->n_singular = c->last.n_singular;
     st->n_pairs = c->last.n_pairs;
     st->max_tile_len = c->last.max_tile_len;
+    st->n_fallback = c->last.n_fallback;
+    st->n_iter_scan = c->last.n_iter_scan;
+    st->n_iter_blend = c->last.n_iter_blend;
     st->bytes_algorithmic = c->n * 148ull + c->last.n_visible * 48ull + c->last.n_pairs * 60ull +
                             (uint64_t)c->fc.W * (uint64_t)(c->fc.row_px1 - c->fc.row_px0) * 4ull;
     float t[N_EV - 1] = {0};
@@ -276,6 +284,9 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     splat_ctx* c = new (std::nothrow) splat_ctx();
     if (!c) return fail(nullptr, SPLAT_ERR_INVALID, "out of host memory");
     c->cfg = *cfg;
+    if (const char* e1 = std::getenv("SPLAT_EARLY_EPS")) c->early_eps = (float)std::atof(e1);
+    if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
+    if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         splat_destroy(c);
@@ -482,7 +493,7 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
         const uint64_t i = c->h_orig[j];
         splat_record& o = out[i];
         o.cx = r[i].a.x; o.cy = r[i].a.y; o.hx = r[i].a.z; o.hy = r[i].a.w;
-        o.conic_a = r[i].b.x; o.conic_b = r[i].b.y; o.conic_c = r[i].b.z; o.opacity = r[i].b.w;
+        o.conic_a = r[i].b.x; o.conic_b = c->fc.y_up ? r[i].b.y : -r[i].b.y; o.conic_c = r[i].b.z; o.opacity = r[i].b.w;
         o.r = r[i].c.x; o.g = r[i].c.y; o.b = r[i].c.z; o.depth = d[j];
         o.px0 = q[j].x; o.px1 = q[j].y; o.py0 = q[j].z; o.py1 = q[j].w;
     }

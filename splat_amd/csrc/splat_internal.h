@@ -28,6 +28,9 @@ struct FrameConst {
     int tile_row0;         // slab: first tile row
     int n_tile_rows;       // slab: tile rows in this context
     int row_px0, row_px1;  // slab pixel rows [row_px0, row_px1)
+    float early_eps;       // compositor early-out: transmittance below which a pixel stops needing layers; 0 = off
+    int early_min;         // shortest list the early-out is tried on
+    int prio_len;          // lists >= prio_len / 2x / 4x run at wave priority 1 / 2 / 3
 };
 
 // Device-side frame status, read back once per frame.
@@ -37,6 +40,9 @@ struct FrameStatus {
     unsigned long long n_pairs;
     unsigned int max_tile_len;
     unsigned int overflow;   // 1: n_pairs > capacity, emit/sort/composite skipped
+    unsigned long long n_fallback;   // waves whose early-out bracket did not close (redone in full)
+    unsigned long long n_iter_scan;  // compositor (wave, record) iterations: phase A (front-to-back scan)
+    unsigned long long n_iter_blend; //                                       phase B (exact blend)
 };
 
 // 48-byte projected record (3 x float4), gathered by the compositor.
@@ -59,7 +65,7 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offset
                  unsigned long long* keys, const FrameStatus* status);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
-                      const FrameStatus* status);
+                      FrameStatus* status);
 
 }  // namespace splat
 #endif

@@ -9,6 +9,9 @@
 //   K2 emit_kernel        instance expansion            src/pipelines.rs:69-79 (+ euc bbox clamp)
 //   K3 sort_tiles_*       per-tile painter's order      src/gaussians.rs:302-303 (stable asc. z)
 //   K4 composite_kernel   euc raster + fragment + blend src/pipelines.rs:127-168
+#include <algorithm>
+#include <cstdlib>
+
 #include "splat_internal.h"
 
 namespace splat {
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                       : ((opacity <= 0.0f) ? 3.0e38f : -3.0e38f);
         Rec r;
         r.a = make_float4(cx, cy, hx, hy);
-        r.b = make_float4(ca, cb, cc, opacity);
+        r.b = make_float4(ca, fc.y_up ? cb : -cb, cc, opacity);   // cross term carries the y-axis sign (exact)
         r.c = make_float4(col[0], col[1], col[2], pthr);
         recs[orig[i]] = r;
         depth[i] = pc[2];
@@ -541,19 +544,6 @@ __global__ __launch_bounds__(1024) void sort_tiles_big_kernel(const unsigned int
 // batches of 256 records; every covered sample runs fragment() and the 8-bit truncating
 // blend() of src/pipelines.rs:127-168 in registers.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float div255(float k) {
-    // == k / 255.0f (IEEE) for every integer k in [0,255]: one multiply + two fma refinement steps
-    // (checked exhaustively in tests/test_host.py::test_div255_identity)
-    const float r = 1.0f / 255.0f;
-    float q = k * r;
-    float e = fmaf(-255.0f, q, k);
-    return fmaf(e, r, q);
-}
-__device__ __forceinline__ float quant_u8(float v) {
-    // Rust `(v) as u8` kept as a float: NaN/negative -> 0, >= 255 -> 255, else truncate
-    return truncf(fminf(fmaxf(v, 0.0f), 255.0f));
-}
-
 // Does ANY sample s = lo + k (k = 0..count-1, all exactly representable) satisfy |s - c| <= h ?
 // |s - c| grows monotonically (also after f32 rounding) away from c, so testing the one or two
 // samples nearest to c is exact.
@@ -563,15 +553,66 @@ __device__ __forceinline__ bool any_sample_covered(float c, float h, float lo, f
     return (int)(fabsf(s1 - c) <= h) | (int)(fabsf(s2 - c) <= h);
 }
 
-__global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    // (readfirstlane returns int: go through unsigned, or the low word sign-extends)
+    return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+}
+
+// exp(x) for the compositor: the same reduction ocml's expf performs (2^(x*log2e) with a
+// compensated product, v_exp_f32 on the fractional part, ldexp) without its overflow/underflow
+// selects -- x is a Gaussian exponent, <= 0 and far above -100 wherever the result is used.
+__device__ __forceinline__ float exp_neg(float x) {
+    const float L2E_HI = __uint_as_float(0x3fb8aa3bu), L2E_LO = __uint_as_float(0x32a5705fu);
+    float ph = x * L2E_HI;
+    float e = rintf(ph);
+    float pl = fmaf(x, L2E_HI, -ph);
+    pl = fmaf(x, L2E_LO, pl);
+    float a = (ph - e) + pl;
+    return ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
+
+// k / 255.0f (IEEE) for every integer k in [0,255] in two instructions: 1/255 split into
+// hi + lo floats, fma(k, hi, k*lo) rounds once (checked exhaustively in tests/test_host.py).
+__device__ __forceinline__ float div255(float k) {
+    const float RH = 0x1.010102p-8f, RL = -0x1.fdfdfep-33f;
+    return fmaf(k, RH, k * RL);
+}
+__device__ __forceinline__ float quant_u8(float v) {
+    // Rust `(v) as u8` kept as a float: NaN/negative -> 0, >= 255 -> 255, else truncate
+    return truncf(fminf(fmaxf(v, 0.0f), 255.0f));
+}
+// One channel of blend(): src/pipelines.rs:157-161.  Monotone non-decreasing in the state k for
+// fixed alpha/colour (every step -- /255, *ia, +const, *255, clamp, trunc -- is monotone under
+// round-to-nearest), which is what makes the [lo,hi] bracket of the early-out exact.
+__device__ __forceinline__ float blend_channel(float k, float ia, float ac) {
+    return quant_u8((ia * div255(k) + ac) * 255.0f);
+}
+
+struct WaveLds { float4 a[64]; float4 b[64]; float4 c[64]; };   // one batch of 64 records, private to a wave
+
+// K4 -- compositor.  One wave = one 16x4 pixel strip of a 16x16 tile (4 waves per workgroup, but
+// they never synchronise: each wave streams the tile's list through its own 3 KB of LDS, 64
+// records at a time, fetching the next batch into registers while it walks the current one).
+// A batch's 64-bit mask (ballot) keeps only the records that cover a sample of the strip; the
+// wave walks them with a scalar bit-scan, one uniform LDS broadcast per record.
+//
+// EARLY-OUT, exactness preserved:
+//   phase A  walks the list near -> far with a cheap approximate alpha until every pixel of the
+//            strip has transmittance < eps; the farthest such layer is the wave's start.
+//   phase B  composites far -> near from that start.  Skipped layers are bracketed: the state
+//            is carried twice, from 0 and from 255; blend() is monotone in the state, so once
+//            lo == hi the result provably does not depend on anything skipped and the walk
+//            continues single-state.  A wave that ends with lo != hi redoes the whole list.
+#ifndef SPLAT_COMP_WAVES
+#define SPLAT_COMP_WAVES 1
+#endif
+__global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned long long* __restrict__ keys,
                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
-                                                              const FrameStatus* __restrict__ status) {
-    __shared__ float4 sA[256];
-    __shared__ float4 sB[256];
-    __shared__ float4 sC[256];
-    __shared__ unsigned long long smask[4][4];   // [target wave][loader wave]: records touching the wave's 16x4 pixels
+                                                              FrameStatus* __restrict__ status) {
+    __shared__ WaveLds slds[4];
     if (status->overflow) return;
     const unsigned int tile = order[blockIdx.x];
     const unsigned int tid = threadIdx.x;
@@ -579,87 +620,183 @@ __global__ __launch_bounds__(256) void composite_exact_kernel(FrameConst fc, con
     const unsigned int end = __builtin_amdgcn_readfirstlane(offsets[tile + 1]);
     if (beg == end) return;
     const unsigned int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    // The longest lists are the critical path of the launch: let their waves win VALU arbitration
+    // against the short-list waves that share their SIMD (priority 0..3 by list length).
+    {
+        const unsigned int len = end - beg;
+        if (len >= (unsigned int)fc.prio_len * 4u) __builtin_amdgcn_s_setprio(3);
+        else if (len >= (unsigned int)fc.prio_len * 2u) __builtin_amdgcn_s_setprio(2);
+        else if (len >= (unsigned int)fc.prio_len) __builtin_amdgcn_s_setprio(1);
+    }
+    WaveLds& L = slds[wave];
     const int txx = (int)(tile % (unsigned int)fc.tiles_x), tyy = (int)(tile / (unsigned int)fc.tiles_x) + fc.tile_row0;
     const int px = txx * TILE + (int)(tid & 15u), py = tyy * TILE + (int)(tid >> 4);
     const bool inside = px < fc.W && py < fc.H && py >= fc.row_px0 && py < fc.row_px1;
     const float off = fc.sample_half ? 0.5f : 0.0f;
-    const float sx = (float)px + off, sy = (float)py + off;
-    // sample extents of the tile (x) and of each wave's four rows (y), clipped to the target
+    // sample extents of this wave's strip, clipped to the target / slab
     const float xlo = (float)(txx * TILE) + off, xhi = (float)min(txx * TILE + TILE - 1, fc.W - 1) + off;
-    const int ylim = min(fc.H, fc.row_px1) - 1;
-    uint32_t old = inside ? argb[(size_t)py * fc.W + px] : 0u;
+    const int y0w = tyy * TILE + 4 * (int)wave, y1w = min(y0w + 3, min(fc.H, fc.row_px1) - 1);
+    if (y0w > y1w) return;                        // strip entirely below the target: nothing to do (no barriers below)
+    const float ylo = (float)y0w + off, yhi = (float)y1w + off;
+    const float sx = (float)px + off, sy = (float)py + off;
+    const uint32_t old = inside ? argb[(size_t)py * fc.W + px] : 0u;
+
+    // fetch: lane l pulls record (base + l) into registers;  stage: registers -> this wave's LDS + mask
+    auto fetch = [&](unsigned int base, unsigned int cnt, Rec& r) {
+        if (lane < cnt) r = recs[(unsigned int)keys[base + lane]];
+    };
+    auto stage = [&](const Rec& r, unsigned int cnt) -> unsigned long long {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier LDS reads of this wave are done
+        __builtin_amdgcn_wave_barrier();
+        bool ov = false;
+        if (lane < cnt) {
+            L.a[lane] = r.a; L.b[lane] = r.b; L.c[lane] = r.c;
+            ov = any_sample_covered(r.a.x, r.a.z, xlo, xhi, off) && any_sample_covered(r.a.y, r.a.w, ylo, yhi, off);
+        }
+        unsigned long long m = __ballot(ov);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return m;
+    };
+
+    unsigned int itA = 0, itB = 0;               // (wave, record) iterations per phase, for the stats
+    // K1 stores the conic cross term with the sign of the y axis folded in (exact: negation),
+    // so coordxy.y is always (centre_y - sample_y) here.
+    // ---------------- phase A: where must the exact walk start? ----------------
+    unsigned int ws = beg;                       // this wave's start position (uniform)
+    if (fc.early_eps > 0.0f && end - beg >= (unsigned int)fc.early_min) {
+        float T = 1.0f;
+        bool done = !inside;
+        unsigned int sp = inside ? beg : 0xffffffffu;    // per lane: first layer the lane needs
+        bool wdone = false;
+        // a strip that has not saturated after half of its list will not save enough to pay for the scan
+        const unsigned int giveup = beg + ((end - beg) >> 1);
+        Rec r;
+        unsigned int cntN = min(64u, end - beg), bsN = end - cntN;
+        fetch(bsN, cntN, r);
+        auto scan = [&](const float4& a, const float4& b, const float4& c, unsigned int pos) {
+            ++itA;
+            float dx = sx - a.x, dy = a.y - sy;
+            bool cov = inside & (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
+            float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+            bool maybe = cov & !(power > 0.0f) & !(power < c.w);
+            if (__ballot(maybe) != 0ull) {
+                float alpha = fminf(0.99f, b.w * __expf(power));              // approximate is enough here
+                if (maybe & !(alpha < 1.0f / 255.0f)) T *= (1.0f - alpha);
+                if (!done && T < fc.early_eps) { done = true; sp = pos; }
+                if (__ballot(!done) == 0ull) wdone = true;
+            }
+        };
+        while (true) {
+            const unsigned int bs = bsN, cnt = cntN;
+            unsigned long long m = stage(r, cnt);
+            if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }   // prefetch farther batch
+            if (m) {
+                unsigned int j = 63u - (unsigned int)__builtin_clzll(m);   // nearest first
+                m &= ~(1ull << j);
+                float4 a = L.a[j], b = L.b[j], c = L.c[j];
+                while (true) {
+                    const bool more = m != 0;
+                    unsigned int j2 = j;
+                    if (more) { j2 = 63u - (unsigned int)__builtin_clzll(m); m &= ~(1ull << j2); }
+                    float4 a2 = L.a[j2], b2 = L.b[j2], c2 = L.c[j2];
+                    scan(a, b, c, bs + j);
+                    if (!more || wdone) break;
+                    const bool more2 = m != 0;
+                    if (more2) { j = 63u - (unsigned int)__builtin_clzll(m); m &= ~(1ull << j); }
+                    a = L.a[j]; b = L.b[j]; c = L.c[j];
+                    scan(a2, b2, c2, bs + j2);
+                    if (!more2 || wdone) break;
+                }
+            }
+            if (wdone || bs == beg) break;
+            if (bs <= giveup) break;              // not saturating: stop scanning, composite everything
+        }
+        unsigned int need = (inside && !done) ? beg : sp;   // lanes that never saturated need the whole list
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) need = min(need, (unsigned int)__shfl_xor((int)need, o));
+        ws = (unsigned int)__builtin_amdgcn_readfirstlane((int)need);
+        if (ws == 0xffffffffu) ws = end;          // no pixel of this strip is on the target
+    }
+
+    // ---------------- phase B: exact compositing from the start layer ----------------
+    bool bracket = ws > beg;                      // uniform per wave
     float R = (float)((old >> 16) & 0xffu), G = (float)((old >> 8) & 0xffu), B = (float)(old & 0xffu);
     float A = (float)(old >> 24);
-    for (unsigned int base = beg; base < end; base += 256) {
-        const unsigned int cnt = min(256u, end - base);
-        {
-            bool ok = tid < cnt;
-            bool ov[4] = {false, false, false, false};
-            if (ok) {
-                unsigned int gi = (unsigned int)keys[base + tid];
-                Rec r = recs[gi];
-                sA[tid] = r.a; sB[tid] = r.b; sC[tid] = r.c;
-                bool ovx = any_sample_covered(r.a.x, r.a.z, xlo, xhi, off);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    int y0 = tyy * TILE + 4 * w, y1 = min(y0 + 3, ylim);
-                    ov[w] = ovx && y0 <= y1 && any_sample_covered(r.a.y, r.a.w, (float)y0 + off, (float)y1 + off, off);
+    float R2 = R, G2 = G, B2 = B;                 // upper end of the bracket
+    if (bracket) { R = G = B = 0.0f; R2 = G2 = B2 = 255.0f; }
+    auto shade = [&](const float4& a, const float4& b, const float4& c) {
+        ++itB;
+        float dx = sx - a.x, dy = a.y - sy;
+        bool cov = inside & (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
+        // fragment(): src/pipelines.rs:134-143
+        float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+        // c.w: below this power alpha < 1/255 for certain -> no lane of the wave needs exp()
+        bool maybe = cov & !(power > 0.0f) & !(power < c.w);
+        bool accept = false;
+        if (__ballot(maybe) != 0ull) {
+            float alpha = fminf(0.99f, b.w * exp_neg(power));
+            accept = maybe & !(alpha < 1.0f / 255.0f);
+            if (accept) {
+                // blend(): src/pipelines.rs:147-167
+                float ia = 1.0f - alpha;
+                float ar = alpha * c.x, ag = alpha * c.y, ab = alpha * c.z;
+                R = blend_channel(R, ia, ar);
+                G = blend_channel(G, ia, ag);
+                B = blend_channel(B, ia, ab);
+                A = truncf(alpha * 255.0f);            // alpha in [1/255, 0.99]: no clamp needed
+                if (bracket) {
+                    R2 = blend_channel(R2, ia, ar);
+                    G2 = blend_channel(G2, ia, ag);
+                    B2 = blend_channel(B2, ia, ab);
                 }
             }
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                unsigned long long m = __ballot(ov[w]);
-                if (lane == 0) smask[w][wave] = m;
-            }
+            if (bracket && __ballot(inside & ((R != R2) | (G != G2) | (B != B2))) == 0ull) bracket = false;
         }
-        __syncthreads();
-        const unsigned int nlw = (cnt + 63u) >> 6;
-        for (unsigned int lw = 0; lw < nlw; ++lw) {
-            unsigned long long mm = smask[wave][lw];
-            // (readfirstlane returns int: go through unsigned, or the low word sign-extends)
-            unsigned long long m = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(mm >> 32)) << 32) |
-                                   (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)mm);
+        if (cov && !accept) A = 0.0f;   // rejected fragments are (0,0,0,0), still blended: A := 0
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {                          // fallback: the whole list, from the real pixel
+            R = (float)((old >> 16) & 0xffu); G = (float)((old >> 8) & 0xffu); B = (float)(old & 0xffu);
+            A = (float)(old >> 24);
+            bracket = false; ws = beg;
+        }
+        Rec r;
+        unsigned int bsN = ws, cntN = min(64u, end - ws);
+        if (cntN) fetch(bsN, cntN, r);
+        while (cntN) {
+            const unsigned int bs = bsN, cnt = cntN;
+            unsigned long long m = stage(r, cnt);
+            bsN = bs + cnt; cntN = min(64u, end - bsN);
+            if (cntN) fetch(bsN, cntN, r);                  // prefetch the next (nearer) batch
             if (!m) continue;
-            unsigned int j = lw * 64u + (unsigned int)__builtin_ctzll(m);
+            unsigned int j = (unsigned int)__builtin_ctzll(m);
             m &= m - 1;
-            float4 a = sA[j], b = sB[j], c = sC[j];
-            while (true) {
-                // prefetch the next overlapping record while this one is evaluated
-                const bool more = m != 0;
-                unsigned int jn = j;
-                if (more) { jn = lw * 64u + (unsigned int)__builtin_ctzll(m); m &= m - 1; }
-                float4 an = sA[jn], bn = sB[jn], cn = sC[jn];
-
-                float dx = sx - a.x;
-                float dy = fc.y_up ? (a.y - sy) : (sy - a.y);   // coordxy.y grows with NDC y
-                bool cov = inside & (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
-                // fragment(): src/pipelines.rs:134-143
-                float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-                // c.w: below this power alpha < 1/255 for certain -> no lane of the wave needs exp()
-                bool maybe = cov & !(power > 0.0f) & !(power < c.w);
-                bool accept = false;
-                if (__any(maybe)) {
-                    float alpha = fminf(0.99f, b.w * expf(power));
-                    accept = maybe & !(alpha < 1.0f / 255.0f);
-                    if (accept) {
-                        // blend(): src/pipelines.rs:147-167
-                        float ia = 1.0f - alpha;
-                        float br = ia * div255(R) + alpha * c.x;
-                        float bg = ia * div255(G) + alpha * c.y;
-                        float bb = ia * div255(B) + alpha * c.z;
-                        R = quant_u8(br * 255.0f);
-                        G = quant_u8(bg * 255.0f);
-                        B = quant_u8(bb * 255.0f);
-                        A = quant_u8(alpha * 255.0f);
-                    }
-                }
-                if (cov && !accept) A = 0.0f;   // rejected fragments are (0,0,0,0), still blended: RGB unchanged, A := 0
+            float4 a = L.a[j], b = L.b[j], c = L.c[j];
+            while (true) {                                  // 2x unrolled ping-pong: the next record's LDS
+                const bool more = m != 0;                   // broadcast is in flight while this one is shaded
+                if (more) { j = (unsigned int)__builtin_ctzll(m); m &= m - 1; }
+                float4 a2 = L.a[j], b2 = L.b[j], c2 = L.c[j];
+                shade(a, b, c);
                 if (!more) break;
-                j = jn; a = an; b = bn; c = cn;
+                const bool more2 = m != 0;
+                if (more2) { j = (unsigned int)__builtin_ctzll(m); m &= m - 1; }
+                a = L.a[j]; b = L.b[j]; c = L.c[j];
+                shade(a2, b2, c2);
+                if (!more2) break;
             }
         }
-        __syncthreads();
+        if (!bracket) break;                      // proven (or exact from the start)
+        if (lane == 0) atomicAdd(&status->n_fallback, 1ull);   // lo != hi somewhere: redo in full
     }
+#ifdef SPLAT_STATS_ITERS   // two same-address atomics per wave cost ~0.2 ms/frame: debug builds only
+    if (lane == 0) {
+        atomicAdd(&status->n_iter_scan, (unsigned long long)itA);
+        atomicAdd(&status->n_iter_blend, (unsigned long long)itB);
+    }
+#else
+    (void)itA; (void)itB;
+#endif
     if (inside)
         argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
 }
@@ -707,8 +844,10 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offset
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
-                      const FrameStatus* status) {
+                      FrameStatus* status) {
     if (!n_tiles) return;
+    static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
+    if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
     hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), 0, s, fc, offsets, order, keys, recs, argb, status);
 }
 

@@ -29,7 +29,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.CameraC) == 4 * (16 + 16 + 2 + 3 + 3 + 1 + 1)
     assert C.sizeof(_lib.Record) == 64
     assert C.sizeof(_lib.Config) == 40
-    assert C.sizeof(_lib.Stats) == 6 * 8 + 6 * 4
+    assert C.sizeof(_lib.Stats) == 6 * 8 + 6 * 4 + 3 * 8
 
 
 def test_create_fails_loudly_without_gpu():
@@ -134,12 +134,13 @@ def test_golden_c1_fixture_loader():
 
 
 def test_div255_identity():
-    """The compositor replaces k/255.0f by mul+fma+fma; exact for every byte (checked in f32)."""
+    """The compositor replaces k/255.0f by fma(k, hi, k*lo) with hi+lo = 1/255; exact for every byte."""
     k = np.arange(256, dtype=np.float32)
     want = k / np.float32(255)
-    r = np.float32(1) / np.float32(255)
-    q = k * r
-    e = (np.float64(k) - np.float64(255) * np.float64(q)).astype(np.float32)        # fma(-255,q,k): exact in f64
-    got = (np.float64(q) + np.float64(e) * np.float64(r)).astype(np.float32)        # fma(e,r,q): one rounding
+    hi = np.float32(float.fromhex("0x1.010102p-8"))
+    lo = np.float32(float.fromhex("-0x1.fdfdfep-33"))
+    assert hi == np.float32(1.0 / 255.0)
+    t = k * lo                                                           # rounded f32 product
+    got = (np.float64(k) * np.float64(hi) + np.float64(t)).astype(np.float32)   # fma: exact product, one rounding
     assert np.array_equal(got, want)
     assert np.array_equal((want * np.float32(255)).astype(np.int32), np.arange(256))    # /255*255 round trip
