@@ -62,7 +62,7 @@ struct splat_ctx {
     int last_slot = -1;
     uint64_t overflow_want = 0;        // a harvested frame overflowed the pair buffer: grow to this
     FrameStatus last{};
-    float early_eps = 1e-7f;           // SPLAT_EARLY_EPS overrides (0 disables the early-out)
+    float early_eps = 1e-6f;           // SPLAT_EARLY_EPS overrides (0 disables the early-out)
     int early_min = 256;               // SPLAT_EARLY_MIN
     int prio_len = 0x3fffffff;         // SPLAT_PRIO_LEN
     std::string err;

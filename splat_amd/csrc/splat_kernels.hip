@@ -11,6 +11,7 @@
 //   K4 composite_kernel   euc raster + fragment + blend src/pipelines.rs:127-168
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "splat_internal.h"
 
@@ -641,78 +642,73 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
     const float sx = (float)px + off, sy = (float)py + off;
     const uint32_t old = inside ? argb[(size_t)py * fc.W + px] : 0u;
 
-    // fetch: lane l pulls record (base + l) into registers;  stage: registers -> this wave's LDS + mask
+    // Pixels outside the target never pass the coverage test: NaN sample coordinates.
+    const float sxm = inside ? sx : __uint_as_float(0x7fc00000u), sym = inside ? sy : __uint_as_float(0x7fc00000u);
+
+    // fetch: lane l pulls record (base + l) into registers.
+    // stage: registers -> this wave's LDS, COMPACTED to the records that cover a sample of the strip
+    //        (order kept); returns how many.  The walkers are then plain counted loops -- a lone wave
+    //        issues one instruction per ~4 cycles whatever its type, so scalar bookkeeping per record
+    //        is as expensive as vector work on the launch's critical path.
     auto fetch = [&](unsigned int base, unsigned int cnt, Rec& r) {
         if (lane < cnt) r = recs[(unsigned int)keys[base + lane]];
     };
-    auto stage = [&](const Rec& r, unsigned int cnt) -> unsigned long long {
+    auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base) -> unsigned int {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier LDS reads of this wave are done
         __builtin_amdgcn_wave_barrier();
         bool ov = false;
-        if (lane < cnt) {
-            L.a[lane] = r.a; L.b[lane] = r.b; L.c[lane] = r.c;
+        if (lane < cnt)
             ov = any_sample_covered(r.a.x, r.a.z, xlo, xhi, off) && any_sample_covered(r.a.y, r.a.w, ylo, yhi, off);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ov);
+        if (ov) {
+            const unsigned int slot = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            L.a[slot] = r.a; L.b[slot] = r.b;
+            L.c[slot] = make_float4(r.c.x, r.c.y, r.c.z, __uint_as_float(base + lane));   // .w: list position
         }
-        unsigned long long m = __ballot(ov);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        return m;
+        return (unsigned int)__builtin_popcountll(m);
+    };
+    // fragment(): src/pipelines.rs:134-143, branch-free.  Returns alpha, forced to 0 where the
+    // fragment is rejected or the sample is not covered; `cov` reports coverage.
+    auto frag_alpha = [&](const float4& a, const float4& b, float e_of_power(float), bool& cov) -> float {
+        float dx = sxm - a.x, dy = a.y - sym;          // K1 folded the y-axis sign into b.y
+        cov = (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
+        float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+        float alpha = fminf(0.99f, b.w * e_of_power(power));
+        bool accept = cov & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+        return accept ? alpha : 0.0f;
     };
 
     unsigned int itA = 0, itB = 0;               // (wave, record) iterations per phase, for the stats
-    // K1 stores the conic cross term with the sign of the y axis folded in (exact: negation),
-    // so coordxy.y is always (centre_y - sample_y) here.
     // ---------------- phase A: where must the exact walk start? ----------------
     unsigned int ws = beg;                       // this wave's start position (uniform)
     if (fc.early_eps > 0.0f && end - beg >= (unsigned int)fc.early_min) {
         float T = 1.0f;
-        bool done = !inside;
         unsigned int sp = inside ? beg : 0xffffffffu;    // per lane: first layer the lane needs
-        bool wdone = false;
+        bool done = !inside;
         // a strip that has not saturated after half of its list will not save enough to pay for the scan
         const unsigned int giveup = beg + ((end - beg) >> 1);
         Rec r;
         unsigned int cntN = min(64u, end - beg), bsN = end - cntN;
         fetch(bsN, cntN, r);
-        auto scan = [&](const float4& a, const float4& b, const float4& c, unsigned int pos) {
-            ++itA;
-            float dx = sx - a.x, dy = a.y - sy;
-            bool cov = inside & (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
-            float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-            bool maybe = cov & !(power > 0.0f) & !(power < c.w);
-            if (__ballot(maybe) != 0ull) {
-                float alpha = fminf(0.99f, b.w * __expf(power));              // approximate is enough here
-                if (maybe & !(alpha < 1.0f / 255.0f)) T *= (1.0f - alpha);
-                if (!done && T < fc.early_eps) { done = true; sp = pos; }
-                if (__ballot(!done) == 0ull) wdone = true;
-            }
-        };
         while (true) {
             const unsigned int bs = bsN, cnt = cntN;
-            unsigned long long m = stage(r, cnt);
+            const unsigned int k = stage(r, cnt, bs);
             if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }   // prefetch farther batch
-            if (m) {
-                unsigned int j = 63u - (unsigned int)__builtin_clzll(m);   // nearest first
-                m &= ~(1ull << j);
-                float4 a = L.a[j], b = L.b[j], c = L.c[j];
-                while (true) {
-                    const bool more = m != 0;
-                    unsigned int j2 = j;
-                    if (more) { j2 = 63u - (unsigned int)__builtin_clzll(m); m &= ~(1ull << j2); }
-                    float4 a2 = L.a[j2], b2 = L.b[j2], c2 = L.c[j2];
-                    scan(a, b, c, bs + j);
-                    if (!more || wdone) break;
-                    const bool more2 = m != 0;
-                    if (more2) { j = 63u - (unsigned int)__builtin_clzll(m); m &= ~(1ull << j); }
-                    a = L.a[j]; b = L.b[j]; c = L.c[j];
-                    scan(a2, b2, c2, bs + j2);
-                    if (!more2 || wdone) break;
-                }
+            for (unsigned int j = k; j-- > 0;) {                  // nearest first
+                const float4 a = L.a[j], b = L.b[j], c = L.c[j];
+                bool cov;
+                const float alpha = frag_alpha(a, b, [](float x) { return __expf(x); }, cov);   // approximate is enough
+                T *= (1.0f - alpha);
+                const bool now = !done & (T < fc.early_eps);
+                sp = now ? __float_as_uint(c.w) : sp;
+                done = done | now;
             }
-            if (wdone || bs == beg) break;
-            if (bs <= giveup) break;              // not saturating: stop scanning, composite everything
+            itA += k;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull || bs == beg || bs <= giveup) break;
         }
-        unsigned int need = (inside && !done) ? beg : sp;   // lanes that never saturated need the whole list
+        unsigned int need = done ? sp : beg;              // lanes that never saturated need the whole list
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) need = min(need, (unsigned int)__shfl_xor((int)need, o));
         ws = (unsigned int)__builtin_amdgcn_readfirstlane((int)need);
@@ -720,75 +716,69 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
     }
 
     // ---------------- phase B: exact compositing from the start layer ----------------
-    bool bracket = ws > beg;                      // uniform per wave
     float R = (float)((old >> 16) & 0xffu), G = (float)((old >> 8) & 0xffu), B = (float)(old & 0xffu);
-    float A = (float)(old >> 24);
-    float R2 = R, G2 = G, B2 = B;                 // upper end of the bracket
-    if (bracket) { R = G = B = 0.0f; R2 = G2 = B2 = 255.0f; }
-    auto shade = [&](const float4& a, const float4& b, const float4& c) {
-        ++itB;
-        float dx = sx - a.x, dy = a.y - sy;
-        bool cov = inside & (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
-        // fragment(): src/pipelines.rs:134-143
-        float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-        // c.w: below this power alpha < 1/255 for certain -> no lane of the wave needs exp()
-        bool maybe = cov & !(power > 0.0f) & !(power < c.w);
-        bool accept = false;
-        if (__ballot(maybe) != 0ull) {
-            float alpha = fminf(0.99f, b.w * exp_neg(power));
-            accept = maybe & !(alpha < 1.0f / 255.0f);
-            if (accept) {
-                // blend(): src/pipelines.rs:147-167
-                float ia = 1.0f - alpha;
-                float ar = alpha * c.x, ag = alpha * c.y, ab = alpha * c.z;
-                R = blend_channel(R, ia, ar);
-                G = blend_channel(G, ia, ag);
-                B = blend_channel(B, ia, ab);
-                A = truncf(alpha * 255.0f);            // alpha in [1/255, 0.99]: no clamp needed
-                if (bracket) {
-                    R2 = blend_channel(R2, ia, ar);
-                    G2 = blend_channel(G2, ia, ag);
-                    B2 = blend_channel(B2, ia, ab);
-                }
-            }
-            if (bracket && __ballot(inside & ((R != R2) | (G != G2) | (B != B2))) == 0ull) bracket = false;
+    float R2 = 255.0f, G2 = 255.0f, B2 = 255.0f;  // upper end of the bracket
+    float alast = -1.0f;                          // alpha of the last covering fragment (0 if rejected); < 0: none
+    // blend(): src/pipelines.rs:147-167.  With alpha == 0 it is the identity on the 8-bit state
+    // (k/255*255 truncates back to k for every byte), so it runs unconditionally.
+    // BR = true: carry the state twice (lo from 0, hi from 255).  Compile-time flag.
+    auto shade = [&](auto BRt, const float4& a, const float4& b, const float4& c) {
+        constexpr bool BR = decltype(BRt)::value;
+        bool cov;
+        const float alpha = frag_alpha(a, b, exp_neg, cov);
+        const float ia = 1.0f - alpha;
+        const float ar = alpha * c.x, ag = alpha * c.y, ab = alpha * c.z;
+        R = blend_channel(R, ia, ar);
+        G = blend_channel(G, ia, ag);
+        B = blend_channel(B, ia, ab);
+        if (BR) {
+            R2 = blend_channel(R2, ia, ar);
+            G2 = blend_channel(G2, ia, ag);
+            B2 = blend_channel(B2, ia, ab);
         }
-        if (cov && !accept) A = 0.0f;   // rejected fragments are (0,0,0,0), still blended: A := 0
+        alast = cov ? alpha : alast;              // rejected fragments are still blended: A := 0
     };
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {                          // fallback: the whole list, from the real pixel
-            R = (float)((old >> 16) & 0xffu); G = (float)((old >> 8) & 0xffu); B = (float)(old & 0xffu);
-            A = (float)(old >> 24);
-            bracket = false; ws = beg;
-        }
+    // Walk batches [start, end).  In bracket mode stop at the first batch boundary where every
+    // pixel has lo == hi and return that position; otherwise return `end`.
+    auto run = [&](auto BRt, unsigned int start) -> unsigned int {
+        constexpr bool BR = decltype(BRt)::value;
         Rec r;
-        unsigned int bsN = ws, cntN = min(64u, end - ws);
+        unsigned int bsN = start, cntN = min(64u, end - start);
         if (cntN) fetch(bsN, cntN, r);
         while (cntN) {
             const unsigned int bs = bsN, cnt = cntN;
-            unsigned long long m = stage(r, cnt);
+            const unsigned int k = stage(r, cnt, bs);
             bsN = bs + cnt; cntN = min(64u, end - bsN);
             if (cntN) fetch(bsN, cntN, r);                  // prefetch the next (nearer) batch
-            if (!m) continue;
-            unsigned int j = (unsigned int)__builtin_ctzll(m);
-            m &= m - 1;
-            float4 a = L.a[j], b = L.b[j], c = L.c[j];
-            while (true) {                                  // 2x unrolled ping-pong: the next record's LDS
-                const bool more = m != 0;                   // broadcast is in flight while this one is shaded
-                if (more) { j = (unsigned int)__builtin_ctzll(m); m &= m - 1; }
-                float4 a2 = L.a[j], b2 = L.b[j], c2 = L.c[j];
-                shade(a, b, c);
-                if (!more) break;
-                const bool more2 = m != 0;
-                if (more2) { j = (unsigned int)__builtin_ctzll(m); m &= m - 1; }
-                a = L.a[j]; b = L.b[j]; c = L.c[j];
-                shade(a2, b2, c2);
-                if (!more2) break;
-            }
+            for (unsigned int j = 0; j < k; ++j) shade(BRt, L.a[j], L.b[j], L.c[j]);
+            itB += k;
+            if (BR && __builtin_amdgcn_ballot_w64(inside & ((R != R2) | (G != G2) | (B != B2))) == 0ull) return bsN;
         }
-        if (!bracket) break;                      // proven (or exact from the start)
-        if (lane == 0) atomicAdd(&status->n_fallback, 1ull);   // lo != hi somewhere: redo in full
+        return end;
+    };
+    unsigned int start = ws;
+    while (true) {
+        if (start <= beg) {                           // nothing skipped: exact from the real pixel
+            R = (float)((old >> 16) & 0xffu); G = (float)((old >> 8) & 0xffu); B = (float)(old & 0xffu);
+            alast = -1.0f;
+            run(std::false_type{}, beg);
+            break;
+        }
+        // skipped layers [beg, start): bracket them
+        R = G = B = 0.0f; R2 = G2 = B2 = 255.0f; alast = -1.0f;
+        const unsigned int pos = run(std::true_type{}, start);
+        const bool open = __builtin_amdgcn_ballot_w64(inside & ((R != R2) | (G != G2) | (B != B2))) != 0ull;
+        if (!open) {
+            if (pos < end) run(std::false_type{}, pos);    // closed: continue single-state
+            break;
+        }
+        // lo != hi somewhere at the end of the list: not proven.  Retry from twice the depth
+        // (geometric, so a long list is not redone in full for one stubborn LSB).
+        if (lane == 0) atomicAdd(&status->n_fallback, 1ull);
+        const unsigned int depth = end - start;
+        start = (start - beg > depth) ? start - depth : beg;
     }
+    const float A = (alast < 0.0f) ? (float)(old >> 24) : truncf(alast * 255.0f);   // alpha in {0} U [1/255, .99]
 #ifdef SPLAT_STATS_ITERS   // two same-address atomics per wave cost ~0.2 ms/frame: debug builds only
     if (lane == 0) {
         atomicAdd(&status->n_iter_scan, (unsigned long long)itA);
