@@ -69,6 +69,7 @@ typedef struct {
     /* device time of the last frame per kernel, ms (HIP events on the context's stream)  */
     float ms_preprocess, ms_scan, ms_emit, ms_sort, ms_composite, ms_total;
     uint64_t n_fallback;   /* compositor waves whose early-out could not be proven exact and were redone in full */
+    uint64_t n_sort_fallback; /* tiles re-sorted by the exact bitonic network because depth ties were out of index order */
     uint64_t n_iter_scan;  /* compositor (wave, record) iterations spent in the front-to-back scan           */
     uint64_t n_iter_blend; /* ... and in exact blending                                                      */
 } splat_stats;

@@ -239,6 +239,7 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->n_pairs = c->last.n_pairs;
     st->max_tile_len = c->last.max_tile_len;
     st->n_fallback = c->last.n_fallback;
+    st->n_sort_fallback = c->last.n_sort_fallback;
     st->n_iter_scan = c->last.n_iter_scan;
     st->n_iter_blend = c->last.n_iter_blend;
     st->bytes_algorithmic = c->n * 148ull + c->last.n_visible * 48ull + c->last.n_pairs * 60ull +

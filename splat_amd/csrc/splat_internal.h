@@ -41,6 +41,7 @@ struct FrameStatus {
     unsigned int max_tile_len;
     unsigned int overflow;   // 1: n_pairs > capacity, emit/sort/composite skipped
     unsigned long long n_fallback;   // waves whose early-out bracket did not close (redone in full)
+    unsigned long long n_sort_fallback; // tiles whose radix-by-depth order failed the 64-bit check (depth ties): bitonic redo
     unsigned long long n_iter_scan;  // compositor (wave, record) iterations: phase A (front-to-back scan)
     unsigned long long n_iter_blend; //                                       phase B (exact blend)
 };
@@ -62,7 +63,7 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
-                 unsigned long long* keys, const FrameStatus* status);
+                 unsigned long long* keys, FrameStatus* status);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
                       FrameStatus* status);

@@ -497,14 +497,149 @@ __device__ __forceinline__ void bitonic_sort(T* s, unsigned int n, unsigned int 
     }
 }
 
-constexpr unsigned int SORT_SMALL_CAP = 2048;    // 16 KB LDS, 256 threads
-constexpr unsigned int SORT_BIG_CAP = 16384;     // 128 KB LDS, 1024 threads
+constexpr unsigned int SORT_SMALL_CAP = 2048;    // 16 KB of keys, 256 threads
+constexpr unsigned int SORT_BIG_CAP = 16384;     // 128 KB of keys, 1024 threads
+
+// In-LDS LSD radix sort of the keys by their DEPTH half (upper 32 bits): four 8-bit passes.
+// Wave w owns the contiguous chunk [w*C, (w+1)*C) of the array, striped over its lanes, so the
+// (wave, round, lane) processing order is the memory order and the sort is stable:
+//   count    per-wave digit histogram; lanes with the same digit find each other with 8 ballots
+//   scan     per-digit exclusive offsets over waves, then over digits
+//   scatter  keys (held in registers since the load) go to offset + rank-within-round
+// Depth ties are left in bucket order, which is arbitrary; the caller checks the full 64-bit
+// order afterwards and falls back to the exact bitonic network if anything is out of place.
+template <int NT, int EMAX>
+__device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned int* hist /*[NT/64][256]*/,
+                                                 unsigned int* tot /*[256]*/, unsigned int* dbase /*[256]*/,
+                                                 unsigned int n, unsigned int tid) {
+    constexpr unsigned int NW = NT / 64;
+    const unsigned int wave = tid >> 6, lane = tid & 63u;
+    const unsigned int C = (((n + NW - 1) / NW) + 63u) & ~63u;       // chunk per wave, multiple of 64
+    const unsigned int w0 = wave * C, w1 = min(w0 + C, n);
+    const unsigned int E = C >> 6;                                   // rounds per wave (<= EMAX)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned int* myhist = hist + wave * 256u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 32 + 8 * pass;
+        unsigned long long k[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const unsigned int i = w0 + (unsigned int)e * 64u + lane;
+            k[e] = ((unsigned int)e < E && i < w1) ? s[i] : ~0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) myhist[lane * 4u + q] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // count
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            if ((unsigned int)e < E) {
+                const unsigned int i = w0 + (unsigned int)e * 64u + lane;
+                const bool valid = i < w1;
+                const unsigned int d = (unsigned int)(k[e] >> shift) & 255u;
+                unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const bool bit = (d >> bb) & 1u;
+                    const unsigned long long mb = __builtin_amdgcn_ballot_w64(bit);
+                    same &= bit ? mb : ~mb;
+                }
+                if (valid && (same & lt) == 0ull) myhist[d] += (unsigned int)__builtin_popcountll(same);   // group leader
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        // scan over waves (thread d handles digit d), then over digits (wave 0)
+        if (tid < 256) {
+            unsigned int acc = 0;
+#pragma unroll
+            for (unsigned int w = 0; w < NW; ++w) {
+                const unsigned int t = hist[w * 256u + tid];
+                hist[w * 256u + tid] = acc;
+                acc += t;
+            }
+            tot[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned int t0 = tot[4 * tid], t1 = tot[4 * tid + 1], t2 = tot[4 * tid + 2], t3 = tot[4 * tid + 3];
+            unsigned int v = t0 + t1 + t2 + t3;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int t = (unsigned int)__shfl_up((int)v, o);
+                if ((int)tid >= o) v += t;
+            }
+            const unsigned int ex = v - (t0 + t1 + t2 + t3);
+            dbase[4 * tid] = ex; dbase[4 * tid + 1] = ex + t0; dbase[4 * tid + 2] = ex + t0 + t1; dbase[4 * tid + 3] = ex + t0 + t1 + t2;
+        }
+        __syncthreads();
+        // scatter (every key of the array is in registers by now, so writing in place is safe)
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            if ((unsigned int)e < E) {
+                const unsigned int i = w0 + (unsigned int)e * 64u + lane;
+                const bool valid = i < w1;
+                const unsigned int d = (unsigned int)(k[e] >> shift) & 255u;
+                unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const bool bit = (d >> bb) & 1u;
+                    const unsigned long long mb = __builtin_amdgcn_ballot_w64(bit);
+                    same &= bit ? mb : ~mb;
+                }
+                unsigned int off = 0;
+                if (valid) off = myhist[d];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (valid) {
+                    const unsigned int rank = (unsigned int)__builtin_popcountll(same & lt);
+                    s[dbase[d] + off + rank] = k[e];
+                    if (rank == 0) myhist[d] = off + (unsigned int)__builtin_popcountll(same);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Radix by depth, then put depth ties into index order.  With thousands of keys per tile exact f32
+// depth ties are routine (birthday effect) but the tied runs are 2-3 keys long: a few odd-even
+// transposition passes over adjacent keys fix them (any inversion left after the radix passes is
+// between equal depths, so swapping inverted neighbours is exactly a bubble sort of those runs).
+// Long runs (many Gaussians at one depth) fall back to the exact bitonic network.
+template <int NT, int EMAX>
+__device__ __forceinline__ void sort_keys_lds(unsigned long long* s, unsigned int* hist, unsigned int* tot,
+                                              unsigned int* dbase, unsigned int n, unsigned int tid,
+                                              FrameStatus* status) {
+    radix_sort_depth<NT, EMAX>(s, hist, tot, dbase, n, tid);
+    for (int it = 0; it < 6; ++it) {
+        bool swapped = false;
+#pragma unroll
+        for (unsigned int parity = 0; parity < 2; ++parity) {
+            for (unsigned int i = parity + 2u * tid; i + 1 < n; i += 2u * NT) {
+                const unsigned long long x = s[i], y = s[i + 1];
+                if (x > y) { s[i] = y; s[i + 1] = x; swapped = true; }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(swapped ? 1 : 0)) return;      // a full pass without swaps: sorted
+    }
+    if (tid == 0) atomicAdd(&status->n_sort_fallback, 1ull);
+    bitonic_sort(s, n, tid, NT);
+}
 
 __global__ __launch_bounds__(256) void sort_tiles_small_kernel(const unsigned int* __restrict__ offsets,
                                                                const unsigned int* __restrict__ order,
                                                                unsigned long long* __restrict__ keys,
-                                                               const FrameStatus* __restrict__ status) {
+                                                               FrameStatus* __restrict__ status, unsigned int radix_min) {
     __shared__ unsigned long long s[SORT_SMALL_CAP];
+    __shared__ unsigned int hist[4 * 256];
+    __shared__ unsigned int tot[256];
+    __shared__ unsigned int dbase[256];
     if (status->overflow) return;
     const unsigned int tile = order[blockIdx.x];
     const unsigned int b = offsets[tile], e = offsets[tile + 1];
@@ -512,16 +647,20 @@ __global__ __launch_bounds__(256) void sort_tiles_small_kernel(const unsigned in
     if (n < 2 || n > SORT_SMALL_CAP) return;
     for (unsigned int t = threadIdx.x; t < n; t += 256) s[t] = keys[b + t];
     __syncthreads();
-    bitonic_sort(s, n, threadIdx.x, 256);
+    if (n <= radix_min) bitonic_sort(s, n, threadIdx.x, 256);   // few steps: cheaper than four radix passes
+    else sort_keys_lds<256, SORT_SMALL_CAP / 256>(s, hist, tot, dbase, n, threadIdx.x, status);
     for (unsigned int t = threadIdx.x; t < n; t += 256) keys[b + t] = s[t];
 }
 
 __global__ __launch_bounds__(1024) void sort_tiles_big_kernel(const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               unsigned long long* __restrict__ keys,
-                                                              const FrameStatus* __restrict__ status) {
+                                                              FrameStatus* __restrict__ status, unsigned int radix_min) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)SORT_BIG_CAP * 8);
+    unsigned int* tot = hist + 16 * 256;
+    unsigned int* dbase = tot + 256;
     if (status->overflow) return;
     const unsigned int tile = order[blockIdx.x];
     const unsigned int b = offsets[tile], e = offsets[tile + 1];
@@ -530,21 +669,17 @@ __global__ __launch_bounds__(1024) void sort_tiles_big_kernel(const unsigned int
     if (n <= SORT_BIG_CAP) {
         for (unsigned int t = threadIdx.x; t < n; t += 1024) s[t] = keys[b + t];
         __syncthreads();
-        bitonic_sort(s, n, threadIdx.x, 1024);
+        if (n <= radix_min) bitonic_sort(s, n, threadIdx.x, 1024);
+        else sort_keys_lds<1024, SORT_BIG_CAP / 1024>(s, hist, tot, dbase, n, threadIdx.x, status);
         for (unsigned int t = threadIdx.x; t < n; t += 1024) keys[b + t] = s[t];
     } else {
-        // longer than LDS: same network straight on the bucket in global memory (L2-resident);
+        // longer than LDS: the bitonic network straight on the bucket in global memory (L2-resident);
         // one workgroup, so __syncthreads() orders its own global accesses.
         bitonic_sort(keys + b, n, threadIdx.x, 1024);
     }
 }
+constexpr unsigned int SORT_BIG_LDS = SORT_BIG_CAP * 8 + (16 * 256 + 256 + 256) * 4;
 
-// ---------------------------------------------------------------------------
-// K4 -- compositor, exact mode.  One 256-thread workgroup per 16x16 tile, one pixel per thread
-// (wave w owns tile rows 4w..4w+3).  The tile's list is streamed far -> near through LDS in
-// batches of 256 records; every covered sample runs fragment() and the 8-bit truncating
-// blend() of src/pipelines.rs:127-168 in registers.
-// ---------------------------------------------------------------------------
 // Does ANY sample s = lo + k (k = 0..count-1, all exactly representable) satisfy |s - c| <= h ?
 // |s - c| grows monotonically (also after f32 rounding) away from c, so testing the one or two
 // samples nearest to c is exact.
@@ -821,16 +956,18 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
     hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, fc, depth, rect, orig, cursor, keys, status);
 }
 void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
-                 unsigned long long* keys, const FrameStatus* status) {
+                 unsigned long long* keys, FrameStatus* status) {
     if (!n_tiles) return;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_big_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SORT_BIG_CAP * 8);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SORT_BIG_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(sort_tiles_big_kernel, dim3(n_tiles), dim3(1024), SORT_BIG_CAP * 8, s, offsets, order, keys, status);
-    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, order, keys, status);
+    static const char* rm = std::getenv("SPLAT_SORT_RADIX_MIN");     // lists up to this length use the bitonic network
+    static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
+    hipLaunchKernelGGL(sort_tiles_big_kernel, dim3(n_tiles), dim3(1024), SORT_BIG_LDS, s, offsets, order, keys, status, radix_min);
+    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, order, keys, status, radix_min);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
