@@ -87,7 +87,11 @@ def main():
     cam_c = pipe.camera_constants()
     R.upload(g)
 
-    slabs = sdist.slab_partition(H, world)
+    if world > 1:
+        # balanced contiguous slabs from per-tile-row pair counts; every rank derives the same partition
+        slabs = sdist.slab_partition_balanced(R.tile_row_loads(cam_c), world, row_overhead=2000.0)
+    else:
+        slabs = sdist.slab_partition(H, world)
     R.set_slab(*slabs[rank])
     stream = torch.cuda.Stream()
     R.set_stream(stream.cuda_stream)
@@ -154,7 +158,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d Gaussians @%dx%d, synthetic seed %d, Camera(0,0,5), Pipeline01 "
                                    "(lowpass 0.01, sh_dim 15), exact mode" % (args.workload, n, W, H, seed),
-                       "partition": "tile-row slabs x%d + RCCL gather" % world if world > 1 else "single GPU",
+                       "partition": ("load-balanced tile-row slabs %s + RCCL gather" % [b - a for a, b in slabs]) if world > 1 else "single GPU",
                        "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len), "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback), "wave_iters_scan": int(st.n_iter_scan), "wave_iters_blend": int(st.n_iter_blend)},
             "roofline": {"bound": "hbm", "kernel": "composite_exact_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

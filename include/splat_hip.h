@@ -101,6 +101,11 @@ int splat_compute_cov3d(splat_ctx* ctx, uint64_t n, const float* scales3, const 
 /* Restrict rendering to tile rows [tile_row0, tile_row1) (multi-GPU slabs); (0,-1) = all. */
 int splat_set_slab(splat_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
 
+/* Load estimate for balancing slabs: (Gaussian,tile) pair count of every tile row of the FULL
+ * frame for this camera (the slab setting is ignored and left unchanged).  Runs only the
+ * preprocess + scan kernels.  n_rows must be ceil(h / SPLAT_TILE). */
+int splat_tile_row_loads(splat_ctx* ctx, const splat_camera* cam, uint64_t* row_pairs, int32_t n_rows);
+
 /* render_to_buffer: blends the scene onto `argb` (in/out, host, w*h u32).  stats may be NULL. */
 int splat_render(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb, splat_stats* stats);
 

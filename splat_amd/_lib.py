@@ -49,6 +49,7 @@ SYMBOLS = [
     ("splat_upload_scene", C.c_int, [C.c_void_p, C.c_uint64, _fp, _fp, _fp, _fp]),
     ("splat_compute_cov3d", C.c_int, [C.c_void_p, C.c_uint64, _fp, _fp, _fp]),
     ("splat_set_slab", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("splat_tile_row_loads", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint64), C.c_int32]),
     ("splat_render", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
     ("splat_render_device", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     ("splat_sync", C.c_int, [C.c_void_p]),

@@ -414,6 +414,35 @@ int splat_set_slab(splat_ctx* c, int32_t tile_row0, int32_t tile_row1) {
     return SPLAT_OK;
 }
 
+int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pairs, int32_t n_rows) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (!row_pairs) return fail(c, SPLAT_ERR_INVALID, "row_pairs is NULL");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc = finish_frame(c);
+    if (rc != SPLAT_OK && rc != SPLAT_ERR_CAPACITY) return rc;
+    const int s0 = c->slab0, s1 = c->slab1;
+    c->slab0 = 0; c->slab1 = -1;
+    FrameConst fc; unsigned int nt = 0;
+    rc = build_frame_const(c, cam, &fc, &nt);
+    c->slab0 = s0; c->slab1 = s1;
+    if (rc != SPLAT_OK) return rc;
+    if (n_rows != fc.n_tile_rows) return fail(c, SPLAT_ERR_INVALID, "n_rows must be ceil(h/16)");
+    for (int r = 0; r < n_rows; ++r) row_pairs[r] = 0;
+    if (c->n == 0 || nt == 0) return SPLAT_OK;
+    rc = ensure_bins(c, nt);
+    if (rc != SPLAT_OK) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(FrameStatus), c->stream));
+    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, c->recs, c->depth, c->rect, c->counts, c->d_status);
+    launch_scan(c->stream, nt, c->counts, c->offsets, c->cursor, c->order, c->d_status, ~0ull);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<unsigned int> off((size_t)nt + 1);
+    HIP_TRY(c, hipMemcpyAsync(off.data(), c->offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < n_rows; ++r)
+        row_pairs[r] = (uint64_t)off[(size_t)(r + 1) * fc.tiles_x] - (uint64_t)off[(size_t)r * fc.tiles_x];
+    return SPLAT_OK;
+}
+
 int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats) {
     if (!c) return SPLAT_ERR_INVALID;
     if (!d_argb) return fail(c, SPLAT_ERR_INVALID, "d_argb is NULL");

@@ -19,6 +19,52 @@ def slab_partition(height, world_size):
     return out
 
 
+def slab_partition_balanced(row_loads, world_size, row_overhead=0.0):
+    """Contiguous tile-row slabs minimising the heaviest slab (classic linear partition, by bisection
+    on the bottleneck).  row_loads: per-tile-row cost estimate (Renderer.tile_row_loads); every rank
+    computes the same partition from the same numbers, so nothing is exchanged.  Ranks get at least
+    one row while rows last."""
+    loads = [float(v) + float(row_overhead) for v in row_loads]
+    n = len(loads)
+    if world_size >= n:
+        return [(min(k, n), min(k + 1, n)) for k in range(world_size)]
+
+    def cuts(limit):
+        out, acc, start = [], 0.0, 0
+        for i, v in enumerate(loads):
+            if acc + v > limit and i > start:
+                out.append((start, i))
+                start, acc = i, 0.0
+            acc += v
+        out.append((start, n))
+        return out
+
+    lo, hi = max(loads), sum(loads)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if len(cuts(mid)) <= world_size:
+            hi = mid
+        else:
+            lo = mid
+    slabs = cuts(hi)
+    # fewer slabs than ranks: split the longest ones so that every rank has rows
+    while len(slabs) < world_size:
+        k = max(range(len(slabs)), key=lambda j: (slabs[j][1] - slabs[j][0] > 1, sum(loads[slabs[j][0]:slabs[j][1]])))
+        a, b = slabs[k]
+        if b - a < 2:
+            break
+        acc, half, cut = 0.0, 0.5 * sum(loads[a:b]), a + 1
+        for i in range(a, b - 1):
+            acc += loads[i]
+            cut = i + 1
+            if acc >= half:
+                break
+        slabs[k:k + 1] = [(a, cut), (cut, b)]
+    while len(slabs) < world_size:
+        slabs.append((n, n))
+    return slabs
+
+
 def slab_pixel_rows(slab, height):
     return min(slab[0] * TILE, int(height)), min(slab[1] * TILE, int(height))
 

@@ -74,6 +74,14 @@ class Renderer:
     def set_slab(self, tile_row0=0, tile_row1=-1):
         self._check(self._L.splat_set_slab(self._h, int(tile_row0), int(tile_row1)))
 
+    def tile_row_loads(self, cam_c):
+        """(Gaussian, tile) pairs per tile row of the full frame: the load estimate for slab balancing."""
+        n_rows = (int(cam_c.h) + _lib.TILE - 1) // _lib.TILE
+        out = np.zeros(n_rows, np.uint64)
+        self._check(self._L.splat_tile_row_loads(self._h, C.byref(cam_c), out.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                 n_rows))
+        return out
+
     def set_stream(self, stream_ptr):
         self._check(self._L.splat_set_stream(self._h, C.c_void_p(stream_ptr)))
 

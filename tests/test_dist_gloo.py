@@ -73,3 +73,23 @@ def test_slab_partition_covers_all_tile_rows():
     # 1080p on 8 GPUs -> 9,9,9,9,8,8,8,8 tile rows
     assert [b - a for a, b in slab_partition(1080, 8)] == [9, 9, 9, 9, 8, 8, 8, 8]
     assert [b - a for a, b in slab_partition(2160, 8)] == [17, 17, 17, 17, 17, 17, 17, 16]
+
+
+def test_balanced_partition_properties():
+    from splat_amd.dist import slab_partition_balanced
+    rng = np.random.default_rng(0)
+    for n in (1, 5, 68, 135):
+        for world in (1, 2, 4, 8):
+            loads = np.exp(-0.5 * ((np.arange(n) - n / 2) / (n / 6 + 1)) ** 2) * 1e5 + rng.integers(0, 100, n)
+            slabs = slab_partition_balanced(loads, world)
+            assert len(slabs) == world
+            assert slabs[0][0] == 0 and max(b for _, b in slabs) == n
+            assert all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]) if b[1] > b[0])
+            covered = sum(b - a for a, b in slabs)
+            assert covered == n
+            if world <= n:
+                assert all(b > a for a, b in slabs)
+            # balanced beats (or ties) the equal-rows split on the bottleneck
+            eq = [(n * k // world, n * (k + 1) // world) for k in range(world)]
+            worst = lambda ss: max(loads[a:b].sum() if b > a else 0 for a, b in ss)
+            assert worst(slabs) <= worst(eq) * 1.0001 + 1e-9

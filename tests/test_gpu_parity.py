@@ -248,3 +248,48 @@ def test_slabs_equal_full_frame(R):
         R.render(cam.to_c(0.01), parts)               # each slab only touches its rows
     R.set_slab(0, -1)
     assert np.array_equal(full, parts)
+
+
+def test_tile_row_loads_and_balanced_slabs(R):
+    """the load estimate used to balance multi-GPU slabs, and byte-equality of a balanced partition"""
+    from splat_amd import dist as sdist
+    g = gpu_scene(R, 30000, 19)
+    cam = make_camera(200, 320)
+    R.upload(g)
+    cam_c = cam.to_c(0.01)
+    R.set_slab(3, 7)                                   # must be ignored by, and survive, the load query
+    loads = R.tile_row_loads(cam_c)
+    R.set_slab(0, -1)
+    full = np.zeros((200, 320), np.uint32)
+    st = R.render(cam_c, full)
+    assert len(loads) == 13 and int(loads.sum()) == st.n_pairs
+    want = O.preprocess(scene_dict(g), oracle_camera(cam, 0.01))
+    v = want[want["visible"] == 1]
+    for r in range(13):
+        m = (v["py0"] // 16 <= r) & (v["py1"] // 16 >= r)
+        assert int(loads[r]) == int(((v["px1"][m] // 16) - (v["px0"][m] // 16) + 1).sum())
+    for world in (2, 3, 8):
+        slabs = sdist.slab_partition_balanced(loads, world)
+        parts = np.zeros_like(full)
+        for s in slabs:
+            R.set_slab(*s)
+            R.render(cam_c, parts)
+        R.set_slab(0, -1)
+        assert np.array_equal(full, parts), world
+
+
+def test_depth_ties_keep_index_order(R):
+    """many Gaussians at exactly the same view depth: the per-tile order must still be the reference's
+    stable (index) order -- exercises the radix tie fix-up and its bitonic fallback"""
+    g = splat_amd.synthetic_scene(6000, 31)
+    g.positions[:, 2] = np.float32(0.25)               # one depth for everyone
+    g.positions[:4500, :2] *= 0.02                     # a dense cluster: thousands of ties in one tile
+    g.compute_cov3d(R)
+    cam = make_camera(128, 128)
+    img, st, ref, ost = render_both(R, g, cam, 0.01)
+    assert st.n_pairs == ost.n_tile_pairs and st.max_tile_len > 2048
+    assert image_diff(img, ref)[0] <= TOL_LSB
+    off, order = R.tile_lists(64, st.n_pairs)
+    for t in range(64):
+        lst = order[off[t]:off[t + 1]].astype(np.int64)
+        assert np.all(np.diff(lst) > 0), t             # equal depth everywhere => ascending index

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Predict multi-GPU strong scaling on ONE GPU: render every slab of a k-way partition separately and
+take the slowest slab's GPU time (+ nothing for the gather, which is ~20-40 us over xGMI).
+Usage: python tools/slab_scaling.py [workload]"""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+import splat_amd
+from splat_amd import dist as sdist
+from bench import WORKLOADS
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
+n, W, H, seed = WORKLOADS[wl]
+R = splat_amd.Renderer()
+g = splat_amd.synthetic_scene(n, seed); g.compute_cov3d(R)
+cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0)); cam.update_camera_pose()
+cam_c = cam.to_c(0.01, 15)
+R.upload(g)
+img = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+loads = R.tile_row_loads(cam_c)
+print("row loads: total %d, max row %d" % (loads.sum(), loads.max()))
+
+
+def slab_time(slab, reps=10):
+    R.set_slab(*slab)
+    for _ in range(3):
+        R.render_device(cam_c, img.data_ptr(), sync=True)
+    R.timing(reset=True)
+    for _ in range(reps):
+        img.zero_()
+        R.render_device(cam_c, img.data_ptr())
+    ms, frames = R.timing(reset=True)
+    return sum(ms[k] for k in ("preprocess", "scan", "emit", "sort", "composite")) / frames
+
+
+for world in (1, 2, 4, 8):
+    for name, slabs in (("equal", sdist.slab_partition(H, world)),
+                        ("balanced", sdist.slab_partition_balanced(loads, world, row_overhead=2000.0))):
+        t = [slab_time(s) for s in slabs]
+        print("world %d %-8s rows %s  slab ms %s  -> max %.3f ms = %.0f fps (gpu time only)" %
+              (world, name, [b - a for a, b in slabs], ["%.2f" % x for x in t], max(t), 1000.0 / max(t)))
+        if world == 1:
+            break
