@@ -1,0 +1,49 @@
+// splat_cli -- the reference's main loop (src/main.rs:41-80) without the window: load a PLY (or the
+// naive scene), orbit the camera in 10-degree yaw steps, time "pose update + clear + render" exactly
+// like src/main.rs:71-77 and print it; optionally write the last frame as a PPM.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../../include/splat_host.hpp"
+
+int main(int argc, char** argv) {
+    const char* ply = nullptr; const char* out = nullptr;
+    int W = 800, H = 600, frames = 36;
+    for (int i = 1; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--ply") && i + 1 < argc) ply = argv[++i];
+        else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+        else if (!std::strcmp(argv[i], "--size") && i + 2 < argc) { W = std::atoi(argv[++i]); H = std::atoi(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
+        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--out frame.ppm]\n"); return 2; }
+    }
+    try {
+        std::printf("Loading gaussians from %s\n", ply ? ply : "naive_gaussians()");
+        std::vector<splat::Gaussian> g = ply ? splat::load_from_ply(ply) : splat::naive_gaussians();
+        std::printf("Computing cov3d for each gaussian\n");
+        for (auto& x : g) x.compute_cov3d();
+        splat::Vec3 pos{0.0f, 0.0f, 5.0f};                    // CAMERA_POSITION, src/main.rs:13
+        splat::GaussianSplatPipeline01 pipeline(g, splat::Camera((float)H, (float)W, &pos));
+        std::vector<uint32_t> color((size_t)W * H, 0u);
+        for (int f = 0; f < frames; ++f) {
+            auto t0 = std::chrono::steady_clock::now();
+            pipeline.camera.update_camera_pose();
+            std::fill(color.begin(), color.end(), 0u);        // Buffer2d::fill([W,H], 0)
+            pipeline.render_to_buffer(color.data());
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("Rendering took %.3f ms (gpu %.3f ms, %llu visible, %llu pairs)\n", ms, pipeline.last_stats.ms_total,
+                        (unsigned long long)pipeline.last_stats.n_visible, (unsigned long long)pipeline.last_stats.n_pairs);
+            pipeline.camera.update_yaw_angle(10.0f * 3.14159265f / 180.0f);   // Key::Right
+        }
+        if (out) {
+            FILE* fp = std::fopen(out, "wb");
+            if (!fp) { std::perror(out); return 1; }
+            std::fprintf(fp, "P6\n%d %d\n255\n", W, H);
+            for (uint32_t p : color) { unsigned char rgb[3] = {(unsigned char)(p >> 16), (unsigned char)(p >> 8), (unsigned char)p}; std::fwrite(rgb, 1, 3, fp); }
+            std::fclose(fp);
+        }
+    } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    return 0;
+}

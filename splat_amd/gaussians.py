@@ -89,45 +89,28 @@ def _activate_and_recentre(raw):
 
 
 def load_from_ply(filename):
-    """load_from_ply, src/gaussians.rs:375-405: vectorised decode of the whole vertex block
-    (binary little/big endian or ascii).  Only `float` properties are consumed; a non-"vertex"
-    element raises (the reference panics)."""
-    with open(filename, "rb") as f:
-        if f.readline().strip() != b"ply":
-            raise ValueError("%s: not a PLY file" % filename)
-        fmt, n, props = None, None, []
-        while True:
-            line = f.readline()
-            if not line:
-                raise ValueError("%s: unterminated PLY header" % filename)
-            t = line.decode("ascii", "replace").split()
-            if not t:
-                continue
-            if t[0] == "format":
-                fmt = t[1]
-            elif t[0] == "element":
-                if t[1] != "vertex":
-                    raise ValueError("Unexpected element!")
-                n = int(t[2])
-            elif t[0] == "property":
-                if t[1] == "list":
-                    raise ValueError("list properties in the vertex element are not supported by the fast loader")
-                props.append((t[2], _NP_TYPES[t[1]], t[1] in ("float", "float32")))
-            elif t[0] == "end_header":
-                break
-        if fmt is None or n is None:
-            raise ValueError("%s: incomplete PLY header" % filename)
-        if fmt == "ascii":
-            data = np.loadtxt(f, dtype=np.float64, ndmin=2)[:n]
-            cols = {name: data[:, k].astype(f32) for k, (name, _, isf) in enumerate(props) if isf}
-        else:
-            end = "<" if fmt == "binary_little_endian" else ">"
-            dt = np.dtype([(name, end + ty) for name, ty, _ in props])
-            data = np.fromfile(f, dtype=dt, count=n)
-            if len(data) != n:
-                raise ValueError("%s: truncated payload" % filename)
-            cols = {name: np.ascontiguousarray(data[name]).astype(f32) for name, _, isf in props if isf}
-    return _activate_and_recentre(cols)
+    """load_from_ply, src/gaussians.rs:375-405 -- the C++ host mirror's loader (libsplat_host.so:
+    mmap + direct decode, libm exp/sigmoid, sequential-f32 recentring; bit-identical to the oracle's
+    reader).  Only `float` properties are consumed; a non-"vertex" element raises (the reference panics)."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsplat_host.so")
+    if not os.path.exists(path):
+        raise RuntimeError("splat_amd: %s is missing -- run __graft_entry__.build()" % path)
+    L = C.CDLL(path)
+    fp = C.POINTER(C.c_float)
+    L.splat_host_load_ply.argtypes = [C.c_char_p, fp, fp, fp, fp, fp, C.c_char_p, C.c_int]
+    L.splat_host_load_ply.restype = C.c_longlong
+    err = C.create_string_buffer(512)
+    n = L.splat_host_load_ply(str(filename).encode(), None, None, None, None, None, err, 512)
+    if n < 0:
+        raise ValueError(err.value.decode() or "load_from_ply failed")
+    pos4, sc, op = np.zeros((n, 4), f32), np.zeros((n, 3), f32), np.zeros(n, f32)
+    rot, sh = np.zeros((n, 4), f32), np.zeros((n, 48), f32)
+    g = lambda a: a.ctypes.data_as(fp)  # noqa: E731
+    if L.splat_host_load_ply(str(filename).encode(), g(pos4), g(sc), g(op), g(rot), g(sh), err, 512) != n:
+        raise ValueError(err.value.decode() or "load_from_ply failed")
+    return GaussianList(pos4, sc, op, rot, sh)
 
 
 def write_ply(filename, raw, n):

@@ -94,9 +94,7 @@ def test_ply_loader_matches_oracle(tmp_path):
     assert np.array_equal(g.positions, o["pos4"])       # incl. sequential-f32 mean recentring
     assert np.array_equal(g.rotations, o["rot"])        # rot_0 -> w (coords[3]), NOT normalised
     assert np.array_equal(g.sh, o["sh"])                # f_rest_k -> sh[3+k], no transpose (Q6)
-    # exp/sigmoid: numpy's f32 exp vs libm expf may differ in the last bit
-    np.testing.assert_allclose(g.scales, o["scales"], rtol=3e-7)
-    np.testing.assert_allclose(g.opacities, o["opacity"], rtol=3e-7)
+    assert np.array_equal(g.scales, o["scales"]) and np.array_equal(g.opacities, o["opacity"])   # libm both sides
     assert np.array_equal(g.sh[:, 3], raw["f_rest_0"]) and np.array_equal(g.sh[:, 47], raw["f_rest_44"])
     assert np.array_equal(g.rotations[:, 3], raw["rot_0"]) and np.array_equal(g.rotations[:, 0], raw["rot_1"])
 
