@@ -497,8 +497,6 @@ __device__ __forceinline__ void bitonic_sort(T* s, unsigned int n, unsigned int 
     }
 }
 
-constexpr unsigned int SORT_SMALL_CAP = 2048;    // 16 KB of keys, 256 threads
-constexpr unsigned int SORT_BIG_CAP = 16384;     // 128 KB of keys, 1024 threads
 
 // In-LDS LSD radix sort of the keys by their DEPTH half (upper 32 bits): four 8-bit passes.
 // Wave w owns the contiguous chunk [w*C, (w+1)*C) of the array, striped over its lanes, so the
@@ -521,34 +519,25 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
     unsigned int* myhist = hist + wave * 256u;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 32 + 8 * pass;
-        unsigned long long k[EMAX];
-#pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            const unsigned int i = w0 + (unsigned int)e * 64u + lane;
-            k[e] = ((unsigned int)e < E && i < w1) ? s[i] : ~0ull;
-        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) myhist[lane * 4u + q] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // count
+        // count (digits straight from LDS: keeps the register-resident copy out of this loop)
+        for (unsigned int e = 0; e < E; ++e) {
+            const unsigned int i = w0 + e * 64u + lane;
+            const bool valid = i < w1;
+            const unsigned int d = valid ? ((unsigned int)(s[i] >> shift) & 255u) : 0u;
+            unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            if ((unsigned int)e < E) {
-                const unsigned int i = w0 + (unsigned int)e * 64u + lane;
-                const bool valid = i < w1;
-                const unsigned int d = (unsigned int)(k[e] >> shift) & 255u;
-                unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
-#pragma unroll
-                for (int bb = 0; bb < 8; ++bb) {
-                    const bool bit = (d >> bb) & 1u;
-                    const unsigned long long mb = __builtin_amdgcn_ballot_w64(bit);
-                    same &= bit ? mb : ~mb;
-                }
-                if (valid && (same & lt) == 0ull) myhist[d] += (unsigned int)__builtin_popcountll(same);   // group leader
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+            for (int bb = 0; bb < 8; ++bb) {
+                const bool bit = (d >> bb) & 1u;
+                const unsigned long long mb = __builtin_amdgcn_ballot_w64(bit);
+                same &= bit ? mb : ~mb;
             }
+            if (valid && (same & lt) == 0ull) myhist[d] += (unsigned int)__builtin_popcountll(same);   // group leader
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         // scan over waves (thread d handles digit d), then over digits (wave 0)
@@ -574,8 +563,14 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
             const unsigned int ex = v - (t0 + t1 + t2 + t3);
             dbase[4 * tid] = ex; dbase[4 * tid + 1] = ex + t0; dbase[4 * tid + 2] = ex + t0 + t1; dbase[4 * tid + 3] = ex + t0 + t1 + t2;
         }
+        // every wave pulls its keys into registers, then (barrier) scatters them in place
+        unsigned long long k[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const unsigned int i = w0 + (unsigned int)e * 64u + lane;
+            k[e] = ((unsigned int)e < E && i < w1) ? s[i] : ~0ull;
+        }
         __syncthreads();
-        // scatter (every key of the array is in registers by now, so writing in place is safe)
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
             if ((unsigned int)e < E) {
@@ -632,53 +627,38 @@ __device__ __forceinline__ void sort_keys_lds(unsigned long long* s, unsigned in
     bitonic_sort(s, n, tid, NT);
 }
 
-__global__ __launch_bounds__(256) void sort_tiles_small_kernel(const unsigned int* __restrict__ offsets,
-                                                               const unsigned int* __restrict__ order,
-                                                               unsigned long long* __restrict__ keys,
-                                                               FrameStatus* __restrict__ status, unsigned int radix_min) {
-    __shared__ unsigned long long s[SORT_SMALL_CAP];
-    __shared__ unsigned int hist[4 * 256];
-    __shared__ unsigned int tot[256];
-    __shared__ unsigned int dbase[256];
-    if (status->overflow) return;
-    const unsigned int tile = order[blockIdx.x];
-    const unsigned int b = offsets[tile], e = offsets[tile + 1];
-    const unsigned int n = e - b;
-    if (n < 2 || n > SORT_SMALL_CAP) return;
-    for (unsigned int t = threadIdx.x; t < n; t += 256) s[t] = keys[b + t];
-    __syncthreads();
-    if (n <= radix_min) bitonic_sort(s, n, threadIdx.x, 256);   // few steps: cheaper than four radix passes
-    else sort_keys_lds<256, SORT_SMALL_CAP / 256>(s, hist, tot, dbase, n, threadIdx.x, status);
-    for (unsigned int t = threadIdx.x; t < n; t += 256) keys[b + t] = s[t];
-}
-
-__global__ __launch_bounds__(1024) void sort_tiles_big_kernel(const unsigned int* __restrict__ offsets,
-                                                              const unsigned int* __restrict__ order,
-                                                              unsigned long long* __restrict__ keys,
-                                                              FrameStatus* __restrict__ status, unsigned int radix_min) {
+// One workgroup per tile; a launch handles the lists with lo < n <= CAP (three size classes, so
+// that mid-sized lists get two workgroups per CU instead of one LDS-filling one).
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __restrict__ offsets,
+                                                         const unsigned int* __restrict__ order,
+                                                         unsigned long long* __restrict__ keys,
+                                                         FrameStatus* __restrict__ status, unsigned int lo,
+                                                         unsigned int radix_min, int last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
-    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)SORT_BIG_CAP * 8);
-    unsigned int* tot = hist + 16 * 256;
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)CAP * 8);
+    unsigned int* tot = hist + (NT / 64) * 256;
     unsigned int* dbase = tot + 256;
     if (status->overflow) return;
     const unsigned int tile = order[blockIdx.x];
     const unsigned int b = offsets[tile], e = offsets[tile + 1];
     const unsigned int n = e - b;
-    if (n <= SORT_SMALL_CAP) return;
-    if (n <= SORT_BIG_CAP) {
-        for (unsigned int t = threadIdx.x; t < n; t += 1024) s[t] = keys[b + t];
+    if (n < 2 || n <= lo) return;
+    if (n <= (unsigned int)CAP) {
+        for (unsigned int t = threadIdx.x; t < n; t += NT) s[t] = keys[b + t];
         __syncthreads();
-        if (n <= radix_min) bitonic_sort(s, n, threadIdx.x, 1024);
-        else sort_keys_lds<1024, SORT_BIG_CAP / 1024>(s, hist, tot, dbase, n, threadIdx.x, status);
-        for (unsigned int t = threadIdx.x; t < n; t += 1024) keys[b + t] = s[t];
-    } else {
+        if (n <= radix_min) bitonic_sort(s, n, threadIdx.x, NT);   // few steps: cheaper than four radix passes
+        else sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status);
+        for (unsigned int t = threadIdx.x; t < n; t += NT) keys[b + t] = s[t];
+    } else if (last) {
         // longer than LDS: the bitonic network straight on the bucket in global memory (L2-resident);
         // one workgroup, so __syncthreads() orders its own global accesses.
-        bitonic_sort(keys + b, n, threadIdx.x, 1024);
+        bitonic_sort(keys + b, n, threadIdx.x, NT);
     }
 }
-constexpr unsigned int SORT_BIG_LDS = SORT_BIG_CAP * 8 + (16 * 256 + 256 + 256) * 4;
+template <int NT, int CAP>
+constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 512) * 4; }
 
 // Does ANY sample s = lo + k (k = 0..count-1, all exactly representable) satisfy |s - c| <= h ?
 // |s - c| grows monotonically (also after f32 rounding) away from c, so testing the one or two
@@ -960,14 +940,21 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offset
     if (!n_tiles) return;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_big_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SORT_BIG_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_kernel<1024, 16384>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds_bytes<1024, 16384>());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_kernel<512, 8192>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds_bytes<512, 8192>());
         attr_set = true;
     }
     static const char* rm = std::getenv("SPLAT_SORT_RADIX_MIN");     // lists up to this length use the bitonic network
     static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
-    hipLaunchKernelGGL(sort_tiles_big_kernel, dim3(n_tiles), dim3(1024), SORT_BIG_LDS, s, offsets, order, keys, status, radix_min);
-    hipLaunchKernelGGL(sort_tiles_small_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, order, keys, status, radix_min);
+    // longest class first (the tiles are ordered longest-first too)
+    hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(n_tiles), dim3(1024), (sort_lds_bytes<1024, 16384>()), s, offsets, order,
+                       keys, status, 8192u, radix_min, 1);
+    hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(n_tiles), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
+                       keys, status, 2048u, radix_min, 0);
+    hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
+                       keys, status, 0u, radix_min, 0);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
