@@ -43,6 +43,7 @@ struct splat_ctx {
     unsigned int* order = nullptr;     // tile ids, longest list first
     unsigned int m_alloc = 0;
     unsigned long long* keys = nullptr;
+    unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
     uint64_t cap = 0;
     FrameStatus* d_status = nullptr;
     FrameStatus* h_status = nullptr;   // pinned, one per ring slot
@@ -154,9 +155,10 @@ int ensure_keys(splat_ctx* c, uint64_t want) {
     if (want <= c->cap) return SPLAT_OK;
     if (want >= 0xFFFFFFF0ull) return fail(c, SPLAT_ERR_CAPACITY, "pair count exceeds 2^32");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dfree(c->keys);
+    dfree(c->keys); dfree(c->keys2);
     c->cap = 0;
     hipError_t e = hipMalloc(&c->keys, sizeof(unsigned long long) * want);
+    if (e == hipSuccess) e = hipMalloc(&c->keys2, sizeof(unsigned long long) * want);
     if (e != hipSuccess) return fail(c, SPLAT_ERR_CAPACITY, std::string("cannot allocate pair buffer: ") + hipGetErrorString(e));
     c->cap = want;
     return SPLAT_OK;
@@ -203,7 +205,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
     HIP_TRY(c, hipEventRecord(ev.e[2], c->stream));
     launch_emit(c->stream, c->n, c->fc, c->depth, c->rect, c->orig, c->cursor, c->keys, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[3], c->stream));
-    launch_sort(c->stream, c->n_tiles, c->offsets, c->order, c->keys, c->d_status);
+    launch_sort(c->stream, c->n_tiles, c->offsets, c->order, c->keys, c->keys2, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[4], c->stream));
     launch_composite(c->stream, c->n_tiles, c->fc, c->offsets, c->order, c->keys, c->recs, d_argb, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[5], c->stream));
@@ -311,7 +313,7 @@ void splat_destroy(splat_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect);
-    dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->order); dfree(c->keys);
+    dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->order); dfree(c->keys); dfree(c->keys2);
     dfree(c->d_status); dfree(c->d_img); dfree(c->orig);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto& s : c->ring)

@@ -63,7 +63,7 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
-                 unsigned long long* keys, FrameStatus* status);
+                 unsigned long long* keys, unsigned long long* keys2, FrameStatus* status);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
                       FrameStatus* status);

@@ -627,12 +627,91 @@ __device__ __forceinline__ void sort_keys_lds(unsigned long long* s, unsigned in
     bitonic_sort(s, n, tid, NT);
 }
 
+// The same radix sort for lists that do not fit in LDS: keys stay in global memory (L2-resident),
+// each pass scatters from `src` to `dst` (a second key buffer at the same offsets); four passes
+// leave the result in `src`.  One workgroup; __syncthreads() orders its own global accesses.
+template <int NT>
+__device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src, unsigned long long* dst,
+                                                        unsigned int* hist, unsigned int* tot, unsigned int* dbase,
+                                                        unsigned int n, unsigned int tid) {
+    constexpr unsigned int NW = NT / 64;
+    const unsigned int wave = tid >> 6, lane = tid & 63u;
+    const unsigned int C = (((n + NW - 1) / NW) + 63u) & ~63u;
+    const unsigned int w0 = wave * C, w1 = min(w0 + C, n);
+    const unsigned int E = C >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned int* myhist = hist + wave * 256u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 32 + 8 * pass;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) myhist[lane * 4u + q] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int phase = 0; phase < 2; ++phase) {          // 0: count, 1: scatter
+            for (unsigned int e = 0; e < E; ++e) {
+                const unsigned int i = w0 + e * 64u + lane;
+                const bool valid = i < w1;
+                const unsigned long long key = valid ? src[i] : 0ull;
+                const unsigned int d = (unsigned int)(key >> shift) & 255u;
+                unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const bool bit = (d >> bb) & 1u;
+                    const unsigned long long mb = __builtin_amdgcn_ballot_w64(bit);
+                    same &= bit ? mb : ~mb;
+                }
+                const unsigned int cnt = (unsigned int)__builtin_popcountll(same);
+                const unsigned int rank = (unsigned int)__builtin_popcountll(same & lt);
+                unsigned int off = 0;
+                if (valid) off = myhist[d];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (valid) {
+                    if (phase == 1) dst[dbase[d] + off + rank] = key;
+                    if (rank == 0) myhist[d] = off + cnt;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (phase == 0) {
+                __syncthreads();
+                if (tid < 256) {
+                    unsigned int acc = 0;
+#pragma unroll
+                    for (unsigned int w = 0; w < NW; ++w) {
+                        const unsigned int t = hist[w * 256u + tid];
+                        hist[w * 256u + tid] = acc;
+                        acc += t;
+                    }
+                    tot[tid] = acc;
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    const unsigned int t0 = tot[4 * tid], t1 = tot[4 * tid + 1], t2 = tot[4 * tid + 2], t3 = tot[4 * tid + 3];
+                    unsigned int v = t0 + t1 + t2 + t3;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned int t = (unsigned int)__shfl_up((int)v, o);
+                        if ((int)tid >= o) v += t;
+                    }
+                    const unsigned int ex = v - (t0 + t1 + t2 + t3);
+                    dbase[4 * tid] = ex; dbase[4 * tid + 1] = ex + t0; dbase[4 * tid + 2] = ex + t0 + t1; dbase[4 * tid + 3] = ex + t0 + t1 + t2;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        unsigned long long* t = src; src = dst; dst = t;
+    }
+}
+
 // One workgroup per tile; a launch handles the lists with lo < n <= CAP (three size classes, so
 // that mid-sized lists get two workgroups per CU instead of one LDS-filling one).
 template <int NT, int CAP>
 __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __restrict__ offsets,
                                                          const unsigned int* __restrict__ order,
                                                          unsigned long long* __restrict__ keys,
+                                                         unsigned long long* __restrict__ keys2,
                                                          FrameStatus* __restrict__ status, unsigned int lo,
                                                          unsigned int radix_min, int last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -652,9 +731,26 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
         else sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status);
         for (unsigned int t = threadIdx.x; t < n; t += NT) keys[b + t] = s[t];
     } else if (last) {
-        // longer than LDS: the bitonic network straight on the bucket in global memory (L2-resident);
-        // one workgroup, so __syncthreads() orders its own global accesses.
-        bitonic_sort(keys + b, n, threadIdx.x, NT);
+        // longer than LDS: radix passes over the L2-resident bucket, then the same tie fix-up
+        unsigned long long* g = keys + b;
+        radix_sort_depth_global<NT>(g, keys2 + b, hist, tot, dbase, n, threadIdx.x);
+        bool sorted = false;
+        for (int it = 0; it < 6 && !sorted; ++it) {
+            bool swapped = false;
+#pragma unroll
+            for (unsigned int parity = 0; parity < 2; ++parity) {
+                for (unsigned int i = parity + 2u * threadIdx.x; i + 1 < n; i += 2u * NT) {
+                    const unsigned long long x = g[i], y = g[i + 1];
+                    if (x > y) { g[i] = y; g[i + 1] = x; swapped = true; }
+                }
+                __syncthreads();
+            }
+            sorted = !__syncthreads_or(swapped ? 1 : 0);
+        }
+        if (!sorted) {
+            if (threadIdx.x == 0) atomicAdd(&status->n_sort_fallback, 1ull);
+            bitonic_sort(g, n, threadIdx.x, NT);       // exact network, slow: only for long runs of equal depth
+        }
     }
 }
 template <int NT, int CAP>
@@ -936,7 +1032,7 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
     hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, fc, depth, rect, orig, cursor, keys, status);
 }
 void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
-                 unsigned long long* keys, FrameStatus* status) {
+                 unsigned long long* keys, unsigned long long* keys2, FrameStatus* status) {
     if (!n_tiles) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -950,11 +1046,11 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offset
     static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
     // longest class first (the tiles are ordered longest-first too)
     hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(n_tiles), dim3(1024), (sort_lds_bytes<1024, 16384>()), s, offsets, order,
-                       keys, status, 8192u, radix_min, 1);
+                       keys, keys2, status, 8192u, radix_min, 1);
     hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(n_tiles), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
-                       keys, status, 2048u, radix_min, 0);
+                       keys, keys2, status, 2048u, radix_min, 0);
     hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
-                       keys, status, 0u, radix_min, 0);
+                       keys, keys2, status, 0u, radix_min, 0);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
