@@ -35,6 +35,7 @@ struct splat_ctx {
     float* depth = nullptr;
     ushort4* rect = nullptr;
     unsigned int* orig = nullptr;      // slot -> original Gaussian index (Morton order of position)
+    unsigned int* vislist = nullptr;   // per frame: slots that reach this context's slab, compacted by K1
     std::vector<unsigned int> h_orig;
     // binning
     unsigned int* counts = nullptr;
@@ -199,11 +200,11 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
     const unsigned int m = c->n_tiles;
     HIP_TRY(c, hipEventRecord(ev.e[0], c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(FrameStatus), c->stream));
-    launch_preprocess(c->stream, c->n, c->planes, c->orig, c->fc, c->recs, c->depth, c->rect, c->counts, c->d_status);
+    launch_preprocess(c->stream, c->n, c->planes, c->orig, c->fc, c->recs, c->depth, c->rect, c->counts, c->vislist, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[1], c->stream));
     launch_scan(c->stream, m, c->counts, c->offsets, c->cursor, c->order, c->d_status, c->cap);
     HIP_TRY(c, hipEventRecord(ev.e[2], c->stream));
-    launch_emit(c->stream, c->n, c->fc, c->depth, c->rect, c->orig, c->cursor, c->keys, c->d_status);
+    launch_emit(c->stream, c->n, c->fc, c->depth, c->rect, c->orig, c->vislist, c->cursor, c->keys, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[3], c->stream));
     launch_sort(c->stream, c->n_tiles, c->offsets, c->order, c->keys, c->keys2, c->d_status);
     HIP_TRY(c, hipEventRecord(ev.e[4], c->stream));
@@ -314,7 +315,7 @@ void splat_destroy(splat_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect);
     dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->order); dfree(c->keys); dfree(c->keys2);
-    dfree(c->d_status); dfree(c->d_img); dfree(c->orig);
+    dfree(c->d_status); dfree(c->d_img); dfree(c->orig); dfree(c->vislist);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto& s : c->ring)
         for (auto& ev : s.e)
@@ -344,7 +345,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     (void)finish_frame(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect); dfree(c->orig);
+    dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect); dfree(c->orig); dfree(c->vislist);
     c->n = 0;
     c->h_orig.clear();
     if (n == 0) return SPLAT_OK;
@@ -362,6 +363,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     UP_TRY(hipMalloc(&c->depth, sizeof(float) * n));
     UP_TRY(hipMalloc(&c->rect, sizeof(ushort4) * n));
     UP_TRY(hipMalloc(&c->orig, sizeof(unsigned int) * n));
+    UP_TRY(hipMalloc(&c->vislist, sizeof(unsigned int) * n));
     UP_TRY(hipMemcpyAsync(c->orig, c->h_orig.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, c->stream));
     UP_TRY(hipMalloc(&d_pos, sizeof(float) * 4 * n));
     UP_TRY(hipMalloc(&d_cov, sizeof(float) * 9 * n));
@@ -434,7 +436,7 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     rc = ensure_bins(c, nt);
     if (rc != SPLAT_OK) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(FrameStatus), c->stream));
-    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, c->recs, c->depth, c->rect, c->counts, c->d_status);
+    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, c->recs, c->depth, c->rect, c->counts, c->vislist, c->d_status);
     launch_scan(c->stream, nt, c->counts, c->offsets, c->cursor, c->order, c->d_status, ~0ull);
     HIP_TRY(c, hipGetLastError());
     std::vector<unsigned int> off((size_t)nt + 1);

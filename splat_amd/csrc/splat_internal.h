@@ -57,11 +57,11 @@ void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float
                        const float* sh, const unsigned int* perm, float4* planes);
 void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d);
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
-                       float* depth, ushort4* rect, unsigned int* counts, FrameStatus* status);
+                       float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, FrameStatus* status);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, FrameStatus* status, unsigned long long capacity);
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
-                 unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
+                 const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
                  unsigned long long* keys, unsigned long long* keys2, FrameStatus* status);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,

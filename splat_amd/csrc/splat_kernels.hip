@@ -246,15 +246,83 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                                          const unsigned int* __restrict__ orig, FrameConst fc,
                                                          Rec* __restrict__ recs, float* __restrict__ depth,
                                                          ushort4* __restrict__ rect, unsigned int* __restrict__ counts,
+                                                         unsigned int* __restrict__ vislist,
                                                          FrameStatus* __restrict__ status) {
     __shared__ BinShared sh;
+    __shared__ unsigned int swave[4];
+    __shared__ unsigned int sbase;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool singular = false, in_slab = false;
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-    if (i < n) {
     float F[64];
+    float cx = 0, cy = 0, hx = 0, hy = 0, ca = 0, cb = 0, cc = 0;
+    if (i < n) {
+        // geometry first: position, opacity, cov3d live in planes 0-3 (64 B); the SH planes are
+        // only fetched for Gaussians that reach this context's slab
 #pragma unroll
-        for (int p = 0; p < LIVE_PLANES; ++p) {
+        for (int p = 0; p < 4; ++p) {
+            float4 v = planes[(uint64_t)p * n + i];
+            F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
+        }
+        const float px = F[0], py = F[1], pz = F[2];
+
+        // project_cov3d_to_screen                                            src/gaussians.rs:114-161
+        float pc[4];
+        mat4_vec(fc.view, px, py, pz, 1.0f, pc);
+        float limx = 1.3f * fc.htanx, limy = 1.3f * fc.htany;
+        float txtz = pc[0] / pc[2], tytz = pc[1] / pc[2];
+        float tx = fminf(limx, fmaxf(-limx, txtz)) * pc[2];
+        float ty = fminf(limy, fmaxf(-limy, tytz)) * pc[2];
+        float tz = pc[2];
+        Mat3 J;
+        M3(J, 0, 0) = fc.focal / tz; M3(J, 0, 1) = 0.0f;          M3(J, 0, 2) = -(fc.focal * tx) / (tz * tz);
+        M3(J, 1, 0) = 0.0f;          M3(J, 1, 1) = fc.focal / tz; M3(J, 1, 2) = -(fc.focal * ty) / (tz * tz);
+        M3(J, 2, 0) = 0.0f;          M3(J, 2, 1) = 0.0f;          M3(J, 2, 2) = 0.0f;
+        Mat3 Wm;   // viewmatrix.fixed_view::<3,3>(0,0).transpose()
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) M3(Wm, r, c) = fc.view[r * 4 + c];
+        Mat3 T = mat3_mul(Wm, J);
+        Mat3 Sg;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Sg.m[e] = F[4 + e];
+        Mat3 cov = mat3_mul(mat3_mul(mat3_t(T), mat3_t(Sg)), T);
+        float m11 = M3(cov, 0, 0) + fc.lowpass, m21 = M3(cov, 1, 0), m12 = M3(cov, 0, 1), m22 = M3(cov, 1, 1) + fc.lowpass;
+
+        // gaussian_vertex_shader                                             src/pipelines.rs:17-51
+        float det = m11 * m22 - m21 * m12;       // nalgebra 2x2 try_inverse
+        float q[4];
+        mat4_vec(fc.proj, pc[0], pc[1], pc[2], pc[3], q);
+        float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];
+        ca = m22 / det; cb = -m12 / det; cc = m11 / det;
+        hx = 3.0f * sqrtf(m11); hy = 3.0f * sqrtf(m22);
+        // euc: NDC -> target pixels
+        cx = (ndcx * 0.5f + 0.5f) * fc.w;
+        cy = fc.y_up ? (ndcy * -0.5f + 0.5f) * fc.h : (ndcy * 0.5f + 0.5f) * fc.h;
+
+
+        singular = (det == 0.0f);
+        bool vis = !singular && finitef(cx) && finitef(cy) && finitef(hx) && finitef(hy) && finitef(ca) && finitef(cb) &&
+                   finitef(cc) && finitef(ndcz);
+        if (vis && fc.zclip) vis = (fc.zmin <= ndcz) && (ndcz <= fc.zmax);
+        // exactly covered pixel ranges on the whole target; the slab then bounds the rows
+        int fx0 = 1, fx1 = 0, fy0 = 1, fy1 = 0;
+        const float off = fc.sample_half ? 0.5f : 0.0f;
+        bool on_target = vis && covered_interval(cx, hx, off, 0, fc.W - 1, &fx0, &fx1) &&
+                         covered_interval(cy, hy, off, 0, fc.H - 1, &fy0, &fy1);
+        if (on_target) {
+            int y0 = max(fy0, fc.row_px0), y1 = min(fy1, fc.row_px1 - 1);
+            in_slab = y0 <= y1;
+            tx0 = fx0 >> 4; tx1 = fx1 >> 4; ty0 = (y0 >> 4) - fc.tile_row0; ty1 = (y1 >> 4) - fc.tile_row0;
+        }
+        depth[i] = pc[2];
+        rect[i] = on_target ? make_ushort4((unsigned short)fx0, (unsigned short)fx1, (unsigned short)fy0, (unsigned short)fy1)
+                            : make_ushort4(1, 0, 1, 0);
+    }
+    if (in_slab) {
+#pragma unroll
+        for (int p = 4; p < LIVE_PLANES; ++p) {
             float4 v = planes[(uint64_t)p * n + i];
             F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
@@ -303,56 +371,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) col[ch] = col[ch] + 0.5f;   // HALF, no clamp
 
-        // project_cov3d_to_screen                                            src/gaussians.rs:114-161
-        float pc[4];
-        mat4_vec(fc.view, px, py, pz, 1.0f, pc);
-        float limx = 1.3f * fc.htanx, limy = 1.3f * fc.htany;
-        float txtz = pc[0] / pc[2], tytz = pc[1] / pc[2];
-        float tx = fminf(limx, fmaxf(-limx, txtz)) * pc[2];
-        float ty = fminf(limy, fmaxf(-limy, tytz)) * pc[2];
-        float tz = pc[2];
-        Mat3 J;
-        M3(J, 0, 0) = fc.focal / tz; M3(J, 0, 1) = 0.0f;          M3(J, 0, 2) = -(fc.focal * tx) / (tz * tz);
-        M3(J, 1, 0) = 0.0f;          M3(J, 1, 1) = fc.focal / tz; M3(J, 1, 2) = -(fc.focal * ty) / (tz * tz);
-        M3(J, 2, 0) = 0.0f;          M3(J, 2, 1) = 0.0f;          M3(J, 2, 2) = 0.0f;
-        Mat3 Wm;   // viewmatrix.fixed_view::<3,3>(0,0).transpose()
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) M3(Wm, r, c) = fc.view[r * 4 + c];
-        Mat3 T = mat3_mul(Wm, J);
-        Mat3 Sg;
-#pragma unroll
-        for (int e = 0; e < 9; ++e) Sg.m[e] = F[4 + e];
-        Mat3 cov = mat3_mul(mat3_mul(mat3_t(T), mat3_t(Sg)), T);
-        float m11 = M3(cov, 0, 0) + fc.lowpass, m21 = M3(cov, 1, 0), m12 = M3(cov, 0, 1), m22 = M3(cov, 1, 1) + fc.lowpass;
-
-        // gaussian_vertex_shader                                             src/pipelines.rs:17-51
-        float det = m11 * m22 - m21 * m12;       // nalgebra 2x2 try_inverse
-        float q[4];
-        mat4_vec(fc.proj, pc[0], pc[1], pc[2], pc[3], q);
-        float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];
-        float ca = m22 / det, cb = -m12 / det, cc = m11 / det;
-        float hx = 3.0f * sqrtf(m11), hy = 3.0f * sqrtf(m22);
-        // euc: NDC -> target pixels
-        float cx = (ndcx * 0.5f + 0.5f) * fc.w;
-        float cy = fc.y_up ? (ndcy * -0.5f + 0.5f) * fc.h : (ndcy * 0.5f + 0.5f) * fc.h;
-
-
-        singular = (det == 0.0f);
-        bool vis = !singular && finitef(cx) && finitef(cy) && finitef(hx) && finitef(hy) && finitef(ca) && finitef(cb) &&
-                   finitef(cc) && finitef(ndcz);
-        if (vis && fc.zclip) vis = (fc.zmin <= ndcz) && (ndcz <= fc.zmax);
-        // exactly covered pixel ranges on the whole target; the slab then bounds the rows
-        int fx0 = 1, fx1 = 0, fy0 = 1, fy1 = 0;
-        const float off = fc.sample_half ? 0.5f : 0.0f;
-        bool on_target = vis && covered_interval(cx, hx, off, 0, fc.W - 1, &fx0, &fx1) &&
-                         covered_interval(cy, hy, off, 0, fc.H - 1, &fy0, &fy1);
-        if (on_target) {
-            int y0 = max(fy0, fc.row_px0), y1 = min(fy1, fc.row_px1 - 1);
-            in_slab = y0 <= y1;
-            tx0 = fx0 >> 4; tx1 = fx1 >> 4; ty0 = (y0 >> 4) - fc.tile_row0; ty1 = (y1 >> 4) - fc.tile_row0;
-        }
         // fragments with power < pthr have alpha < 1/255 for certain (margin 1e-3 >> f32 error)
         float pthr = (opacity > 0.0f) ? (logf(1.0f / (255.0f * opacity)) - 1e-3f)
                                       : ((opacity <= 0.0f) ? 3.0e38f : -3.0e38f);
@@ -361,14 +379,24 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         r.b = make_float4(ca, fc.y_up ? cb : -cb, cc, opacity);   // cross term carries the y-axis sign (exact)
         r.c = make_float4(col[0], col[1], col[2], pthr);
         recs[orig[i]] = r;
-        depth[i] = pc[2];
-        rect[i] = on_target ? make_ushort4((unsigned short)fx0, (unsigned short)fx1, (unsigned short)fy0, (unsigned short)fy1)
-                            : make_ushort4(1, 0, 1, 0);
     }
-    const int nvis = __syncthreads_count(in_slab), nsing = __syncthreads_count(singular);
-    if (threadIdx.x == 0) {
-        if (nvis) atomicAdd(&status->n_visible, (unsigned long long)nvis);
-        if (nsing) atomicAdd(&status->n_singular, (unsigned long long)nsing);
+    // compact the slots that reach the slab into vislist (K2 runs over those only)
+    {
+        const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(in_slab);
+        if (lane == 0) swave[wave] = (unsigned int)__builtin_popcountll(m);
+        const int nsing = __syncthreads_count(singular);
+        const unsigned int nvis = swave[0] + swave[1] + swave[2] + swave[3];
+        if (threadIdx.x == 0) {
+            sbase = nvis ? (unsigned int)atomicAdd(&status->n_visible, (unsigned long long)nvis) : 0u;
+            if (nsing) atomicAdd(&status->n_singular, (unsigned long long)nsing);
+        }
+        __syncthreads();
+        if (in_slab) {
+            unsigned int r = sbase + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            for (unsigned int w = 0; w < wave; ++w) r += swave[w];
+            vislist[r] = (unsigned int)i;
+        }
     }
     bin_block<false>(sh, in_slab, tx0, tx1, ty0, ty1, fc.tiles_x, counts, nullptr, 0ull);
 }
@@ -438,26 +466,26 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
 
 // K2 -- one thread per Gaussian slot: claim a slot in every overlapped tile's bucket and write the
 // 64-bit key (depth_key << 32 | ORIGINAL index).  Bucket order is arbitrary; K3 fixes it.
-__global__ __launch_bounds__(256) void emit_kernel(uint64_t n, FrameConst fc, const float* __restrict__ depth,
+__global__ __launch_bounds__(256) void emit_kernel(FrameConst fc, const float* __restrict__ depth,
                                                    const ushort4* __restrict__ rect, const unsigned int* __restrict__ orig,
+                                                   const unsigned int* __restrict__ vislist,
                                                    unsigned int* __restrict__ cursor, unsigned long long* __restrict__ keys,
                                                    const FrameStatus* __restrict__ status) {
     __shared__ BinShared sh;
     if (status->overflow) return;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nvis = status->n_visible;        // K1 compacted the slab's slots into vislist
+    if ((unsigned long long)blockIdx.x * 256ull >= nvis) return;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool vis = false;
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
     unsigned long long key = 0;
-    if (i < n) {
+    if (j < nvis) {
+        const unsigned int i = vislist[j];
         ushort4 rc = rect[i];
-        if (rc.x <= rc.y) {
-            int y0 = max((int)rc.z, fc.row_px0), y1 = min((int)rc.w, fc.row_px1 - 1);
-            if (y0 <= y1) {
-                vis = true;
-                tx0 = rc.x >> 4; tx1 = rc.y >> 4; ty0 = (y0 >> 4) - fc.tile_row0; ty1 = (y1 >> 4) - fc.tile_row0;
-                key = ((unsigned long long)depth_key(depth[i]) << 32) | (unsigned long long)orig[i];
-            }
-        }
+        int y0 = max((int)rc.z, fc.row_px0), y1 = min((int)rc.w, fc.row_px1 - 1);
+        vis = true;
+        tx0 = rc.x >> 4; tx1 = rc.y >> 4; ty0 = (y0 >> 4) - fc.tile_row0; ty1 = (y1 >> 4) - fc.tile_row0;
+        key = ((unsigned long long)depth_key(depth[i]) << 32) | (unsigned long long)orig[i];
     }
     bin_block<true>(sh, vis, tx0, tx1, ty0, ty1, fc.tiles_x, cursor, keys, key);
 }
@@ -1017,19 +1045,19 @@ void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* 
     hipLaunchKernelGGL(cov3d_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, scales3, rot4, cov3d);
 }
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
-                       float* depth, ushort4* rect, unsigned int* counts, FrameStatus* status) {
+                       float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, FrameStatus* status) {
     if (!n) return;
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth, rect,
-                       counts, status);
+                       counts, vislist, status);
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, FrameStatus* status, unsigned long long capacity) {
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, status, capacity);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
-                 unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
+                 const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
     if (!n) return;
-    hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, fc, depth, rect, orig, cursor, keys, status);
+    hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, fc, depth, rect, orig, vislist, cursor, keys, status);
 }
 void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
                  unsigned long long* keys, unsigned long long* keys2, FrameStatus* status) {

@@ -293,3 +293,23 @@ def test_depth_ties_keep_index_order(R):
     for t in range(64):
         lst = order[off[t]:off[t + 1]].astype(np.int64)
         assert np.all(np.diff(lst) > 0), t             # equal depth everywhere => ascending index
+
+
+def test_anchor_fixture_on_gpu(R):
+    """the committed golden frames (tests/golden/anchor_64.npz) through the HIP path"""
+    import os
+    a = np.load(os.path.join(os.path.dirname(__file__), "golden", "anchor_64.npz"))
+    g = splat_amd.GaussianList(a["positions"], np.zeros((64, 3)), a["opacities"], np.zeros((64, 4)), a["sh"], a["cov3d"])
+    R.upload(g)
+    from splat_amd import _lib
+    for name, lp in (("img_lowpass_0p01", 0.01), ("img_lowpass_0p3", 0.3)):
+        c = _lib.CameraC()
+        c.view[:] = a["view"].tolist()
+        c.proj[:] = a["proj"].tolist()
+        c.w = c.h = 64.0
+        c.htanx, c.htany, c.focal = 1.0, 1.0, 32.0
+        c.cam_pos[:] = a["cam_pos"].tolist()
+        c.lowpass, c.sh_dim = lp, 15
+        img = np.zeros((64, 64), np.uint32)
+        R.render(c, img)
+        assert image_diff(img, a[name])[0] <= TOL_LSB, name

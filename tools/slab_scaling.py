@@ -42,3 +42,16 @@ for world in (1, 2, 4, 8):
               (world, name, [b - a for a, b in slabs], ["%.2f" % x for x in t], max(t), 1000.0 / max(t)))
         if world == 1:
             break
+
+# per-kernel breakdown of the heaviest 8-way slab
+slabs = sdist.slab_partition_balanced(loads, 8, row_overhead=2000.0)
+for s in (slabs[0], slabs[3]):
+    R.set_slab(*s)
+    for _ in range(3):
+        R.render_device(cam_c, img.data_ptr(), sync=True)
+    R.timing(reset=True)
+    for _ in range(10):
+        img.zero_()
+        R.render_device(cam_c, img.data_ptr())
+    ms, frames = R.timing(reset=True)
+    print("slab", s, {k: round(v / frames, 4) for k, v in ms.items()})
