@@ -16,7 +16,7 @@ _LIB = None
 
 class Conventions(C.Structure):
     _fields_ = [("y_up", C.c_int32), ("sample_half", C.c_int32), ("zclip", C.c_int32),
-                ("zmin", C.c_float), ("zmax", C.c_float)]
+                ("zmin", C.c_float), ("zmax", C.c_float), ("raster", C.c_int32)]
 
 
 class Camera(C.Structure):

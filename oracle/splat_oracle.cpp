@@ -247,7 +247,7 @@ double now_ms() {
 extern "C" {
 
 void orc_default_conventions(orc_conventions* c) {
-    c->y_up = 1; c->sample_half = 1; c->zclip = 1; c->zmin = 0.0f; c->zmax = 1.0f;
+    c->y_up = 1; c->sample_half = 1; c->zclip = 1; c->zmin = 0.0f; c->zmax = 1.0f; c->raster = 0;
 }
 
 // src/camera.rs:22-39 (new) + :41-68 (compute_matrices) + :84-89 (htanfovxy_focal)
@@ -389,6 +389,45 @@ int orc_render(uint64_t n, const float* pos4, const float* cov3d, const float* o
         }
     const float off = conv->sample_half ? 0.5f : 0.0f;
     std::vector<uint64_t> frags(nthreads, 0);
+    // raster == 1: generic two-triangle rasterisation of the quad (sensitivity variant, see header)
+    auto raster_triangles = [&](const orc_record& r, int a, int b, uint64_t& nf) {
+        // quad corners in NDC as gaussian_vertex_shader builds them, then euc's NDC -> pixel map
+        const float bndx = r.hx / cam->w * 2.0f, bndy = r.hy / cam->h * 2.0f;
+        const float corner[4][2] = {{-1, 1}, {-1, -1}, {1, -1}, {1, 1}};
+        float vx[4], vy[4], ux[4], uy[4];
+        for (int k = 0; k < 4; ++k) {
+            float nx = corner[k][0] * bndx + r.ndc[0], ny = corner[k][1] * bndy + r.ndc[1];
+            vx[k] = (nx * 0.5f + 0.5f) * cam->w;
+            vy[k] = conv->y_up ? (ny * -0.5f + 0.5f) * cam->h : (ny * 0.5f + 0.5f) * cam->h;
+            ux[k] = corner[k][0] * r.hx; uy[k] = corner[k][1] * r.hy;      // coordxy at the corner
+        }
+        const int tri[2][3] = {{0, 1, 2}, {0, 2, 3}};
+        for (int t = 0; t < 2; ++t) {
+            const int i0 = tri[t][0], i1 = tri[t][1], i2 = tri[t][2];
+            float area = (vx[i1] - vx[i0]) * (vy[i2] - vy[i0]) - (vy[i1] - vy[i0]) * (vx[i2] - vx[i0]);
+            if (area == 0.0f || !std::isfinite(area)) continue;
+            float xmin = std::min(vx[i0], std::min(vx[i1], vx[i2])), xmax = std::max(vx[i0], std::max(vx[i1], vx[i2]));
+            float ymin = std::min(vy[i0], std::min(vy[i1], vy[i2])), ymax = std::max(vy[i0], std::max(vy[i1], vy[i2]));
+            int x0 = (int)std::max(0.0f, std::floor(xmin) - 1.0f), x1 = (int)std::min((float)(W - 1), std::ceil(xmax) + 1.0f);
+            int y0 = (int)std::max((float)a, std::floor(ymin) - 1.0f), y1 = (int)std::min((float)(b - 1), std::ceil(ymax) + 1.0f);
+            for (int y = y0; y <= y1; ++y) {
+                uint32_t* row = argb + (size_t)y * W;
+                for (int x = x0; x <= x1; ++x) {
+                    float px = (float)x + off, py = (float)y + off;
+                    float w0 = ((vx[i1] - px) * (vy[i2] - py) - (vy[i1] - py) * (vx[i2] - px)) / area;
+                    float w1 = ((vx[i2] - px) * (vy[i0] - py) - (vy[i2] - py) * (vx[i0] - px)) / area;
+                    float w2 = 1.0f - w0 - w1;
+                    if (!(w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f)) continue;
+                    float cxy = w0 * ux[i0] + w1 * ux[i1] + w2 * ux[i2];
+                    float cyy = w0 * uy[i0] + w1 * uy[i1] + w2 * uy[i2];
+                    float alpha = fragment_alpha(r.conic[0], r.conic[1], r.conic[2], r.opacity, cxy, cyy);
+                    if (alpha == 0.0f) row[x] = blend_px(row[x], 0.0f, 0.0f, 0.0f, 0.0f);
+                    else row[x] = blend_px(row[x], r.rgb[0], r.rgb[1], r.rgb[2], alpha);
+                    ++nf;
+                }
+            }
+        }
+    };
     auto band = [&](int t) {
         int rows = row1 - row0;
         int a = row0 + (int)((int64_t)rows * t / nthreads), b = row0 + (int)((int64_t)rows * (t + 1) / nthreads);
@@ -396,6 +435,7 @@ int orc_render(uint64_t n, const float* pos4, const float* cov3d, const float* o
         for (uint64_t k = 0; k < n; ++k) {
             const orc_record& r = rec[order[k]];
             if (!r.visible) continue;
+            if (conv->raster == 1) { raster_triangles(r, a, b, nf); continue; }
             int y0 = std::max(r.py0, a), y1 = std::min(r.py1, b - 1);
             for (int y = y0; y <= y1; ++y) {
                 float sy = (float)y + off;

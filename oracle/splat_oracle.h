@@ -37,6 +37,13 @@ typedef struct {
     int32_t sample_half;   /* 1: sample at pixel centre (x+.5,y+.5) (default)   */
     int32_t zclip;         /* 1: cull quads whose ndc.z is outside [zmin,zmax]  */
     float zmin, zmax;      /* default 0..1 (euc CoordinateMode::VULKAN)         */
+    int32_t raster;        /* 0: analytic rectangle, coordxy = sample - centre (default).
+                              1: SENSITIVITY VARIANT -- the quad as two triangles (0-1-2, 0-2-3 of
+                                 src/pipelines.rs:7-14) rasterised separately with f32 barycentric
+                                 weights, inclusive edges (a sample on the shared diagonal is blended
+                                 by both), coordxy interpolated from the corner values.  It is what
+                                 a triangle rasteriser does in general, NOT a transcription of euc
+                                 (absent); it measures how far euc-internal rounding can move pixels. */
 } orc_conventions;
 
 /* Per-frame camera constants, i.e. what Camera's getters return
