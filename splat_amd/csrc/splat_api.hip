@@ -1,5 +1,11 @@
 // splat_api.hip -- C ABI (include/splat_hip.h) over the gfx950 kernels.  Host side only:
 // buffer ownership, per-frame constants, launch sequence, HIP-event timing, error reporting.
+//
+// Per-frame buffers live in two SLOTS used alternately.  With SPLAT_PIPELINE=1 binning + sorting of
+// frame N+1 run on an internal stream into the other slot while frame N is still compositing on
+// the caller's stream (fork/join = two events per frame; nothing is skipped or reused between
+// frames).  Measured gain on MI355X is ~1.5 %: the compositor already occupies every wave slot,
+// so the next frame's K1 only crawls alongside it -- hence off by default.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -15,39 +21,51 @@ using namespace splat;
 
 namespace {
 thread_local std::string g_create_error;
-constexpr int N_EV = 7;        // event boundaries: start, preprocess, scan, emit, sort, composite(+copy) ...
+constexpr int N_EV = 8;        // e0..e4 on the bin stream (start, K1, scan, K2, K3), e5..e7 on the caller's (K4 start, K4 end, status)
+constexpr int N_TIMES = 6;     // preprocess, scan, emit, sort, composite, status read-back
 constexpr int EV_RING = 32;
+constexpr int N_SLOTS = 2;
 
 struct EvSet {
     hipEvent_t e[N_EV];
+    bool used = false;
+};
+
+struct Slot {                  // everything one frame writes before the image
+    Rec* recs = nullptr;
+    float* depth = nullptr;
+    ushort4* rect = nullptr;
+    unsigned int* vislist = nullptr;
+    unsigned int* counts = nullptr;
+    unsigned int* offsets = nullptr;
+    unsigned int* cursor = nullptr;
+    unsigned int* order = nullptr;
+    unsigned long long* keys = nullptr;
+    unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
+    FrameStatus* d_status = nullptr;
+    hipEvent_t ev_ready = nullptr;         // bin stream -> caller's stream: lists are sorted
+    hipEvent_t ev_free = nullptr;          // caller's stream -> bin stream: compositor is done with the slot
     bool used = false;
 };
 }  // namespace
 
 struct splat_ctx {
     splat_config cfg{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // compositor + image: the caller-visible stream
     bool own_stream = false;
+    hipStream_t bin_stream = nullptr;      // K1..K3 of the next frame
     // scene
     uint64_t n = 0;
     float4* planes = nullptr;
-    Rec* recs = nullptr;
-    float* depth = nullptr;
-    ushort4* rect = nullptr;
-    unsigned int* orig = nullptr;      // slot -> original Gaussian index (Morton order of position)
-    unsigned int* vislist = nullptr;   // per frame: slots that reach this context's slab, compacted by K1
+    unsigned int* orig = nullptr;          // slot -> original Gaussian index (Morton order of position)
     std::vector<unsigned int> h_orig;
-    // binning
-    unsigned int* counts = nullptr;
-    unsigned int* offsets = nullptr;
-    unsigned int* cursor = nullptr;
-    unsigned int* order = nullptr;     // tile ids, longest list first
+    // per-frame buffers
+    Slot slots[N_SLOTS];
     unsigned int m_alloc = 0;
-    unsigned long long* keys = nullptr;
-    unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
     uint64_t cap = 0;
-    FrameStatus* d_status = nullptr;
-    FrameStatus* h_status = nullptr;   // pinned, one per ring slot
+    uint64_t frame_idx = 0;
+    int last_slot = -1;                    // buffer slot of the most recent frame (debug getters)
+    FrameStatus* h_status = nullptr;       // pinned, one per event-ring entry
     // host-image path
     uint32_t* d_img = nullptr;
     size_t img_cap = 0;
@@ -56,17 +74,18 @@ struct splat_ctx {
     // timing
     EvSet ring[EV_RING];
     int ring_next = 0;
-    double acc_ms[N_EV - 1] = {0, 0, 0, 0, 0, 0};
+    int last_ring = -1;
+    double acc_ms[N_TIMES] = {0, 0, 0, 0, 0, 0};
     uint64_t acc_frames = 0;
     // last frame
     FrameConst fc{};
     unsigned int n_tiles = 0;
-    int last_slot = -1;
-    uint64_t overflow_want = 0;        // a harvested frame overflowed the pair buffer: grow to this
+    uint64_t overflow_want = 0;            // a harvested frame overflowed the pair buffer: grow to this
     FrameStatus last{};
-    float early_eps = 1e-6f;           // SPLAT_EARLY_EPS overrides (0 disables the early-out)
-    int early_min = 256;               // SPLAT_EARLY_MIN
-    int prio_len = 0x3fffffff;         // SPLAT_PRIO_LEN
+    float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
+    int early_min = 256;                   // SPLAT_EARLY_MIN
+    int prio_len = 0x3fffffff;             // SPLAT_PRIO_LEN
+    bool pipeline = false;                 // SPLAT_PIPELINE=1: bin/sort of frame N+1 on an internal stream while frame N composites
     std::string err;
 };
 
@@ -125,29 +144,47 @@ void dfree(T*& p) {
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
-void harvest(splat_ctx* c, int slot) {
-    EvSet& s = c->ring[slot];
+const float* ev_times(const EvSet& s, float t[N_TIMES]) {
+    static const int pairs[N_TIMES][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {5, 6}, {6, 7}};
+    for (int k = 0; k < N_TIMES; ++k) {
+        t[k] = 0.f;
+        (void)hipEventElapsedTime(&t[k], s.e[pairs[k][0]], s.e[pairs[k][1]]);
+    }
+    return t;
+}
+
+void harvest(splat_ctx* c, int r) {
+    EvSet& s = c->ring[r];
     if (!s.used) return;
     (void)hipEventSynchronize(s.e[N_EV - 1]);
-    for (int k = 0; k + 1 < N_EV; ++k) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.e[k], s.e[k + 1]) == hipSuccess) c->acc_ms[k] += ms;
-    }
+    float t[N_TIMES];
+    ev_times(s, t);
+    for (int k = 0; k < N_TIMES; ++k) c->acc_ms[k] += t[k];
     c->acc_frames++;
-    const FrameStatus& st = c->h_status[slot];
+    const FrameStatus& st = c->h_status[r];
     if (st.overflow) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     s.used = false;
 }
 
+int sync_all(splat_ctx* c) {
+    if (c->bin_stream) HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPLAT_OK;
+}
+
 int ensure_bins(splat_ctx* c, unsigned int m) {
     if (m + 1 <= c->m_alloc) return SPLAT_OK;
-    dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->order);
+    int rc = sync_all(c);
+    if (rc != SPLAT_OK) return rc;
     c->m_alloc = 0;
-    HIP_TRY(c, hipMalloc(&c->counts, sizeof(unsigned int) * (size_t)(m + 1)));
-    HIP_TRY(c, hipMalloc(&c->offsets, sizeof(unsigned int) * (size_t)(m + 1)));
-    HIP_TRY(c, hipMalloc(&c->cursor, sizeof(unsigned int) * (size_t)(m + 1)));
-    HIP_TRY(c, hipMalloc(&c->order, sizeof(unsigned int) * (size_t)(m + 1)));
-    HIP_TRY(c, hipMemsetAsync(c->counts, 0, sizeof(unsigned int) * (size_t)(m + 1), c->stream));
+    for (Slot& s : c->slots) {
+        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order);
+        HIP_TRY(c, hipMalloc(&s.counts, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, hipMalloc(&s.offsets, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, hipMalloc(&s.cursor, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, hipMalloc(&s.order, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, hipMemset(s.counts, 0, sizeof(unsigned int) * (size_t)(m + 1)));
+    }
     c->m_alloc = m + 1;
     return SPLAT_OK;
 }
@@ -155,12 +192,15 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
 int ensure_keys(splat_ctx* c, uint64_t want) {
     if (want <= c->cap) return SPLAT_OK;
     if (want >= 0xFFFFFFF0ull) return fail(c, SPLAT_ERR_CAPACITY, "pair count exceeds 2^32");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dfree(c->keys); dfree(c->keys2);
+    int rc = sync_all(c);
+    if (rc != SPLAT_OK) return rc;
     c->cap = 0;
-    hipError_t e = hipMalloc(&c->keys, sizeof(unsigned long long) * want);
-    if (e == hipSuccess) e = hipMalloc(&c->keys2, sizeof(unsigned long long) * want);
-    if (e != hipSuccess) return fail(c, SPLAT_ERR_CAPACITY, std::string("cannot allocate pair buffer: ") + hipGetErrorString(e));
+    for (Slot& s : c->slots) {
+        dfree(s.keys); dfree(s.keys2);
+        hipError_t e = hipMalloc(&s.keys, sizeof(unsigned long long) * want);
+        if (e == hipSuccess) e = hipMalloc(&s.keys2, sizeof(unsigned long long) * want);
+        if (e != hipSuccess) return fail(c, SPLAT_ERR_CAPACITY, std::string("cannot allocate pair buffer: ") + hipGetErrorString(e));
+    }
     c->cap = want;
     return SPLAT_OK;
 }
@@ -190,44 +230,62 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     return SPLAT_OK;
 }
 
-// Enqueue one frame on the stream (never blocks unless the event ring wraps onto a frame
-// that is still running, 32 frames behind).
+// Enqueue one frame.  Never blocks the host unless the event ring wraps onto a frame that is
+// still running (32 frames behind).
 int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
-    const int slot = c->ring_next;
-    EvSet& ev = c->ring[slot];
+    const int r = c->ring_next;
+    EvSet& ev = c->ring[r];
     c->ring_next = (c->ring_next + 1) % EV_RING;
-    harvest(c, slot);
+    harvest(c, r);
+    const int si = (int)(c->frame_idx++ % N_SLOTS);
+    Slot& s = c->slots[si];
+    hipStream_t bs = c->pipeline ? c->bin_stream : c->stream;
     const unsigned int m = c->n_tiles;
-    HIP_TRY(c, hipEventRecord(ev.e[0], c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(FrameStatus), c->stream));
-    launch_preprocess(c->stream, c->n, c->planes, c->orig, c->fc, c->recs, c->depth, c->rect, c->counts, c->vislist, c->d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[1], c->stream));
-    launch_scan(c->stream, m, c->counts, c->offsets, c->cursor, c->order, c->d_status, c->cap);
-    HIP_TRY(c, hipEventRecord(ev.e[2], c->stream));
-    launch_emit(c->stream, c->n, c->fc, c->depth, c->rect, c->orig, c->vislist, c->cursor, c->keys, c->d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[3], c->stream));
-    launch_sort(c->stream, c->n_tiles, c->offsets, c->order, c->keys, c->keys2, c->d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[4], c->stream));
-    launch_composite(c->stream, c->n_tiles, c->fc, c->offsets, c->order, c->keys, c->recs, d_argb, c->d_status);
+    if (c->pipeline) {
+        // order this frame's binning after whatever the caller queued before the call (it may have
+        // written the scene-independent inputs we read? no -- but it keeps stream semantics intact
+        // for a caller that interleaves uploads), and after the compositor that last used the slot
+        if (s.used) HIP_TRY(c, hipStreamWaitEvent(bs, s.ev_free, 0));
+    }
+    HIP_TRY(c, hipEventRecord(ev.e[0], bs));
+    HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), bs));
+    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[1], bs));
+    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.d_status, c->cap);
+    HIP_TRY(c, hipEventRecord(ev.e[2], bs));
+    launch_emit(bs, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[3], bs));
+    launch_sort(bs, m, s.offsets, s.order, s.keys, s.keys2, s.d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[4], bs));
+    if (c->pipeline) {
+        HIP_TRY(c, hipEventRecord(s.ev_ready, bs));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_ready, 0));
+    }
     HIP_TRY(c, hipEventRecord(ev.e[5], c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&c->h_status[slot], c->d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
+    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.keys, s.recs, d_argb, s.d_status);
     HIP_TRY(c, hipEventRecord(ev.e[6], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
+    if (c->pipeline) HIP_TRY(c, hipEventRecord(s.ev_free, c->stream));
     HIP_TRY(c, hipGetLastError());
+    s.used = true;
     ev.used = true;
-    c->last_slot = slot;
+    c->last_ring = r;
+    c->last_slot = si;
     return SPLAT_OK;
 }
 
 // Wait for everything enqueued; returns SPLAT_ERR_CAPACITY (after growing the pair buffer) if a
 // frame overflowed it -- that frame's composite was skipped and it must be rendered again.
 int finish_frame(splat_ctx* c) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->last_slot >= 0) c->last = c->h_status[c->last_slot];
+    int rc = sync_all(c);
+    if (rc != SPLAT_OK) return rc;
+    if (c->last_ring >= 0) c->last = c->h_status[c->last_ring];
     for (int k = 0; k < EV_RING; ++k) harvest(c, k);
     if (c->overflow_want) {
         uint64_t want = (uint64_t)((double)c->overflow_want * 1.25) + 1024;
         c->overflow_want = 0;
-        int rc = ensure_keys(c, want);
+        rc = ensure_keys(c, want);
         if (rc != SPLAT_OK) return rc;
         return fail(c, SPLAT_ERR_CAPACITY, "pair buffer overflowed; capacity grown, frame must be re-rendered");
     }
@@ -247,15 +305,18 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->n_iter_blend = c->last.n_iter_blend;
     st->bytes_algorithmic = c->n * 148ull + c->last.n_visible * 48ull + c->last.n_pairs * 60ull +
                             (uint64_t)c->fc.W * (uint64_t)(c->fc.row_px1 - c->fc.row_px0) * 4ull;
-    float t[N_EV - 1] = {0};
-    float tot = 0.f;
-    if (c->last_slot >= 0) {
-        EvSet& ev = c->ring[c->last_slot];   // events stay valid after harvest
-        for (int k = 0; k + 1 < N_EV; ++k) (void)hipEventElapsedTime(&t[k], ev.e[k], ev.e[k + 1]);
-        (void)hipEventElapsedTime(&tot, ev.e[0], ev.e[5]);
-    }
+    float t[N_TIMES] = {0};
+    if (c->last_ring >= 0) ev_times(c->ring[c->last_ring], t);   // events stay valid after harvest
     st->ms_preprocess = t[0]; st->ms_scan = t[1]; st->ms_emit = t[2]; st->ms_sort = t[3]; st->ms_composite = t[4];
-    st->ms_total = tot;
+    st->ms_total = t[0] + t[1] + t[2] + t[3] + t[4];
+}
+
+void free_scene(splat_ctx* c) {
+    dfree(c->planes); dfree(c->orig);
+    for (Slot& s : c->slots) { dfree(s.recs); dfree(s.depth); dfree(s.rect); dfree(s.vislist); s.used = false; }
+    c->n = 0;
+    c->h_orig.clear();
+    c->last_slot = -1;
 }
 
 }  // namespace
@@ -291,6 +352,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e1 = std::getenv("SPLAT_EARLY_EPS")) c->early_eps = (float)std::atof(e1);
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
+    if (const char* e4 = std::getenv("SPLAT_PIPELINE")) c->pipeline = std::atoi(e4) != 0;
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         splat_destroy(c);
@@ -299,7 +361,17 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->own_stream = true;
-    if ((e = hipMalloc(&c->d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
+    {   // the binning stream gets the highest priority: a separate hardware queue from the caller's
+        // stream, and its short streaming kernels should not queue behind a frame-long compositor
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if ((e = hipStreamCreateWithPriority(&c->bin_stream, hipStreamNonBlocking, hi)) != hipSuccess) return bail("hipStreamCreate", e);
+    }
+    for (Slot& s : c->slots) {
+        if ((e = hipMalloc(&s.d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
+        if ((e = hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    }
     if ((e = hipHostMalloc(&c->h_status, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipHostMalloc(status)", e);
     std::memset(c->h_status, 0, sizeof(FrameStatus) * EV_RING);
     for (auto& s : c->ring)
@@ -312,14 +384,20 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
 void splat_destroy(splat_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    if (c->bin_stream) (void)hipStreamSynchronize(c->bin_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect);
-    dfree(c->counts); dfree(c->offsets); dfree(c->cursor); dfree(c->order); dfree(c->keys); dfree(c->keys2);
-    dfree(c->d_status); dfree(c->d_img); dfree(c->orig); dfree(c->vislist);
+    free_scene(c);
+    for (Slot& s : c->slots) {
+        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
+        if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
+        if (s.ev_free) (void)hipEventDestroy(s.ev_free);
+    }
+    dfree(c->d_img);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto& s : c->ring)
         for (auto& ev : s.e)
             if (ev) (void)hipEventDestroy(ev);
+    if (c->bin_stream) (void)hipStreamDestroy(c->bin_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -331,7 +409,7 @@ void* splat_stream(splat_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int splat_set_stream(splat_ctx* c, void* stream) {
     if (!c) return SPLAT_ERR_INVALID;
     int rc = finish_frame(c);
-    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
     return rc;
@@ -344,10 +422,9 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     if (n >= 0xFFFFFFFFull) return fail(c, SPLAT_ERR_INVALID, "too many Gaussians (index is 32-bit)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     (void)finish_frame(c);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dfree(c->planes); dfree(c->recs); dfree(c->depth); dfree(c->rect); dfree(c->orig); dfree(c->vislist);
-    c->n = 0;
-    c->h_orig.clear();
+    int rc = sync_all(c);
+    if (rc != SPLAT_OK) return rc;
+    free_scene(c);
     if (n == 0) return SPLAT_OK;
     morton_order(n, pos4, c->h_orig);
     float *d_pos = nullptr, *d_cov = nullptr, *d_op = nullptr, *d_sh = nullptr;
@@ -359,11 +436,13 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
         return fail(c, SPLAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e)); \
     }
     UP_TRY(hipMalloc(&c->planes, sizeof(float4) * SCENE_PLANES * n));
-    UP_TRY(hipMalloc(&c->recs, sizeof(Rec) * n));
-    UP_TRY(hipMalloc(&c->depth, sizeof(float) * n));
-    UP_TRY(hipMalloc(&c->rect, sizeof(ushort4) * n));
     UP_TRY(hipMalloc(&c->orig, sizeof(unsigned int) * n));
-    UP_TRY(hipMalloc(&c->vislist, sizeof(unsigned int) * n));
+    for (Slot& s : c->slots) {
+        UP_TRY(hipMalloc(&s.recs, sizeof(Rec) * n));
+        UP_TRY(hipMalloc(&s.depth, sizeof(float) * n));
+        UP_TRY(hipMalloc(&s.rect, sizeof(ushort4) * n));
+        UP_TRY(hipMalloc(&s.vislist, sizeof(unsigned int) * n));
+    }
     UP_TRY(hipMemcpyAsync(c->orig, c->h_orig.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, c->stream));
     UP_TRY(hipMalloc(&d_pos, sizeof(float) * 4 * n));
     UP_TRY(hipMalloc(&d_cov, sizeof(float) * 9 * n));
@@ -381,7 +460,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     c->n = n;
     if (c->cap == 0) {
         uint64_t want = c->cfg.pair_capacity ? c->cfg.pair_capacity : std::max<uint64_t>(1ull << 22, 16 * n);
-        int rc = ensure_keys(c, want);
+        rc = ensure_keys(c, want);
         if (rc != SPLAT_OK) return rc;
     }
     return SPLAT_OK;
@@ -435,12 +514,13 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     if (c->n == 0 || nt == 0) return SPLAT_OK;
     rc = ensure_bins(c, nt);
     if (rc != SPLAT_OK) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(FrameStatus), c->stream));
-    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, c->recs, c->depth, c->rect, c->counts, c->vislist, c->d_status);
-    launch_scan(c->stream, nt, c->counts, c->offsets, c->cursor, c->order, c->d_status, ~0ull);
+    Slot& s = c->slots[0];
+    HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
+    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.d_status);
+    launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.d_status, ~0ull);
     HIP_TRY(c, hipGetLastError());
     std::vector<unsigned int> off((size_t)nt + 1);
-    HIP_TRY(c, hipMemcpyAsync(off.data(), c->offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(off.data(), s.offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < n_rows; ++r)
         row_pairs[r] = (uint64_t)off[(size_t)(r + 1) * fc.tiles_x] - (uint64_t)off[(size_t)r * fc.tiles_x];
@@ -454,12 +534,12 @@ int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int
     int rc = SPLAT_OK;
     if (c->n == 0 && !c->planes) {
         // an empty scene renders nothing (the reference's loop body never runs)
-        if (stats) { c->last = FrameStatus{}; unsigned int nt; rc = build_frame_const(c, cam, &c->fc, &nt); if (rc) return rc; fill_stats(c, stats); }
+        if (stats) { c->last = FrameStatus{}; c->last_ring = -1; unsigned int nt; rc = build_frame_const(c, cam, &c->fc, &nt); if (rc) return rc; fill_stats(c, stats); }
         return SPLAT_OK;
     }
     rc = build_frame_const(c, cam, &c->fc, &c->n_tiles);
     if (rc != SPLAT_OK) return rc;
-    if (c->n_tiles == 0) { if (stats) { c->last = FrameStatus{}; fill_stats(c, stats); } return SPLAT_OK; }
+    if (c->n_tiles == 0) { if (stats) { c->last = FrameStatus{}; c->last_ring = -1; fill_stats(c, stats); } return SPLAT_OK; }
     rc = ensure_bins(c, c->n_tiles);
     if (rc != SPLAT_OK) return rc;
     for (int attempt = 0; attempt < 3; ++attempt) {
@@ -507,7 +587,7 @@ int splat_get_timing(splat_ctx* c, double ms_out[6], uint64_t* frames, int32_t r
     if (!c) return SPLAT_ERR_INVALID;
     int rc = splat_sync(c);
     if (rc != SPLAT_OK) return rc;
-    if (ms_out) for (int k = 0; k < N_EV - 1; ++k) ms_out[k] = c->acc_ms[k];
+    if (ms_out) for (int k = 0; k < N_TIMES; ++k) ms_out[k] = c->acc_ms[k];
     if (frames) *frames = c->acc_frames;
     if (reset) { for (auto& v : c->acc_ms) v = 0; c->acc_frames = 0; }
     return SPLAT_OK;
@@ -519,10 +599,12 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     if (n == 0) return SPLAT_OK;
     int rc = splat_sync(c);
     if (rc != SPLAT_OK) return rc;
+    if (c->last_slot < 0) return fail(c, SPLAT_ERR_INVALID, "no frame rendered yet");
+    const Slot& s = c->slots[c->last_slot];
     std::vector<Rec> r(n); std::vector<float> d(n); std::vector<ushort4> q(n);
-    HIP_TRY(c, hipMemcpy(r.data(), c->recs, sizeof(Rec) * n, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(d.data(), c->depth, sizeof(float) * n, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(q.data(), c->rect, sizeof(ushort4) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(r.data(), s.recs, sizeof(Rec) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(d.data(), s.depth, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(q.data(), s.rect, sizeof(ushort4) * n, hipMemcpyDeviceToHost));
     for (uint64_t j = 0; j < n; ++j) {          // depth/rect live in slot order, records in original order
         const uint64_t i = c->h_orig[j];
         splat_record& o = out[i];
@@ -538,12 +620,14 @@ int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offset
     if (!c) return SPLAT_ERR_INVALID;
     int rc = splat_sync(c);
     if (rc != SPLAT_OK) return rc;
+    if (c->last_slot < 0) return fail(c, SPLAT_ERR_INVALID, "no frame rendered yet");
+    const Slot& s = c->slots[c->last_slot];
     if (n_offsets != (uint64_t)c->n_tiles + 1 || n_order != c->last.n_pairs)
         return fail(c, SPLAT_ERR_INVALID, "tile list size mismatch");
-    HIP_TRY(c, hipMemcpy(tile_offsets, c->offsets, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(tile_offsets, s.offsets, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), hipMemcpyDeviceToHost));
     if (n_order) {
         std::vector<unsigned long long> k(n_order);
-        HIP_TRY(c, hipMemcpy(k.data(), c->keys, sizeof(unsigned long long) * n_order, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(k.data(), s.keys, sizeof(unsigned long long) * n_order, hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < n_order; ++i) order[i] = (uint32_t)k[i];
     }
     return SPLAT_OK;
