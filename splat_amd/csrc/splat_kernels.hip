@@ -543,7 +543,6 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
     const unsigned int C = (((n + NW - 1) / NW) + 63u) & ~63u;       // chunk per wave, multiple of 64
     const unsigned int w0 = wave * C, w1 = min(w0 + C, n);
     const unsigned int E = C >> 6;                                   // rounds per wave (<= EMAX)
-    const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned int* myhist = hist + wave * 256u;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 32 + 8 * pass;
@@ -551,21 +550,10 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
         for (int q = 0; q < 4; ++q) myhist[lane * 4u + q] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // count (digits straight from LDS: keeps the register-resident copy out of this loop)
+        // count: LDS atomics on this wave's histogram row (digits straight from LDS)
         for (unsigned int e = 0; e < E; ++e) {
             const unsigned int i = w0 + e * 64u + lane;
-            const bool valid = i < w1;
-            const unsigned int d = valid ? ((unsigned int)(s[i] >> shift) & 255u) : 0u;
-            unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                const bool bit = (d >> bb) & 1u;
-                const unsigned long long mb = __builtin_amdgcn_ballot_w64(bit);
-                same &= bit ? mb : ~mb;
-            }
-            if (valid && (same & lt) == 0ull) myhist[d] += (unsigned int)__builtin_popcountll(same);   // group leader
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (i < w1) atomicAdd(&myhist[(unsigned int)(s[i] >> shift) & 255u], 1u);
         }
         __syncthreads();
         // scan over waves (thread d handles digit d), then over digits (wave 0)
@@ -599,27 +587,18 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
             k[e] = ((unsigned int)e < E && i < w1) ? s[i] : ~0ull;
         }
         __syncthreads();
+        // Rank within the wave = value returned by an LDS atomic on the (already exclusive) histogram
+        // row.  Rounds are issued in order and the LDS serialises the lanes of one instruction in
+        // lane order on this hardware, which makes the pass stable; that is NOT an architectural
+        // guarantee, so the caller's 64-bit order check (+ exact fallback) stays the safety net.
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
             if ((unsigned int)e < E) {
                 const unsigned int i = w0 + (unsigned int)e * 64u + lane;
-                const bool valid = i < w1;
-                const unsigned int d = (unsigned int)(k[e] >> shift) & 255u;
-                unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
-#pragma unroll
-                for (int bb = 0; bb < 8; ++bb) {
-                    const bool bit = (d >> bb) & 1u;
-                    const unsigned long long mb = __builtin_amdgcn_ballot_w64(bit);
-                    same &= bit ? mb : ~mb;
-                }
-                unsigned int off = 0;
-                if (valid) off = myhist[d];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (valid) {
-                    const unsigned int rank = (unsigned int)__builtin_popcountll(same & lt);
-                    s[dbase[d] + off + rank] = k[e];
-                    if (rank == 0) myhist[d] = off + (unsigned int)__builtin_popcountll(same);
+                if (i < w1) {
+                    const unsigned int d = (unsigned int)(k[e] >> shift) & 255u;
+                    const unsigned int rank = atomicAdd(&myhist[d], 1u);
+                    s[dbase[d] + rank] = k[e];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -667,7 +646,6 @@ __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src,
     const unsigned int C = (((n + NW - 1) / NW) + 63u) & ~63u;
     const unsigned int w0 = wave * C, w1 = min(w0 + C, n);
     const unsigned int E = C >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned int* myhist = hist + wave * 256u;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 32 + 8 * pass;
@@ -678,25 +656,11 @@ __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src,
         for (int phase = 0; phase < 2; ++phase) {          // 0: count, 1: scatter
             for (unsigned int e = 0; e < E; ++e) {
                 const unsigned int i = w0 + e * 64u + lane;
-                const bool valid = i < w1;
-                const unsigned long long key = valid ? src[i] : 0ull;
-                const unsigned int d = (unsigned int)(key >> shift) & 255u;
-                unsigned long long same = __builtin_amdgcn_ballot_w64(valid);
-#pragma unroll
-                for (int bb = 0; bb < 8; ++bb) {
-                    const bool bit = (d >> bb) & 1u;
-                    const unsigned long long mb = __builtin_amdgcn_ballot_w64(bit);
-                    same &= bit ? mb : ~mb;
-                }
-                const unsigned int cnt = (unsigned int)__builtin_popcountll(same);
-                const unsigned int rank = (unsigned int)__builtin_popcountll(same & lt);
-                unsigned int off = 0;
-                if (valid) off = myhist[d];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (valid) {
-                    if (phase == 1) dst[dbase[d] + off + rank] = key;
-                    if (rank == 0) myhist[d] = off + cnt;
+                if (i < w1) {
+                    const unsigned long long key = src[i];
+                    const unsigned int d = (unsigned int)(key >> shift) & 255u;
+                    const unsigned int rank = atomicAdd(&myhist[d], 1u);     // see radix_sort_depth on stability
+                    if (phase == 1) dst[dbase[d] + rank] = key;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
