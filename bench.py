@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--orbit", action="store_true",
+                    help="step the camera yaw by 10 degrees every frame (the 36-pose orbit of src/main.rs:53-60) "
+                         "instead of the fixed pose")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -73,9 +76,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # SPLAT_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0 over gloo, to exercise the N>1 code
+    # path on a single-GPU box; the real run is one rank per GPU over RCCL
+    share = os.environ.get("SPLAT_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     n, W, H, seed = WORKLOADS[args.workload]
     R = splat_amd.Renderer(device=local)
@@ -85,6 +96,13 @@ def main():
     cam.update_camera_pose()
     pipe = splat_amd.GaussianSplatPipeline01(g, cam, renderer=R)   # what the default binary uses
     cam_c = pipe.camera_constants()
+    poses = [cam_c]
+    if args.orbit:
+        poses = []
+        for k in range(36):
+            poses.append(pipe.camera_constants())
+            cam.update_yaw_angle(10.0 * np.pi / 180.0)        # Key::Right, src/main.rs:57-60
+            cam.update_camera_pose()
     R.upload(g)
 
     if world > 1:
@@ -97,11 +115,17 @@ def main():
     R.set_stream(stream.cuda_stream)
     image = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 
+    frame_no = [0]
+
     def step():
+        pose = poses[frame_no[0] % len(poses)]
+        frame_no[0] += 1
         with torch.cuda.stream(stream):
             image.zero_()                                        # color = Buffer2d::fill([W,H], 0)
-            R.render_device(cam_c, image.data_ptr())             # enqueue only
+            R.render_device(pose, image.data_ptr())              # enqueue only
             if world > 1:
+                if share:
+                    stream.synchronize()     # gloo's CUDA receive is not ordered after this stream's work (NCCL's is)
                 sdist.gather_slabs(image, slabs, rank)
 
     def fence():
@@ -136,6 +160,16 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(comp, op=dist.ReduceOp.MAX)
 
+    slab_check = None
+    if world > 1 and rank == 0:
+        # the gathered frame must equal the frame this rank renders alone, byte for byte
+        R.set_slab(0, -1)
+        full = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        with torch.cuda.stream(stream):
+            R.render_device(poses[(frame_no[0] - 1) % len(poses)], full.data_ptr(), sync=True)
+        torch.cuda.synchronize()
+        slab_check = bool(torch.equal(full, image))
+        R.set_slab(*slabs[rank])
     if rank == 0:
         per = {k: v / max(frames, 1) for k, v in kern_ms.items()}
         t_gpu = sum(per[k] for k in ("preprocess", "scan", "emit", "sort", "composite"))
@@ -158,6 +192,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d Gaussians @%dx%d, synthetic seed %d, Camera(0,0,5), Pipeline01 "
                                    "(lowpass 0.01, sh_dim 15), exact mode" % (args.workload, n, W, H, seed),
+                       "camera": "36-pose yaw orbit, 10 degrees per frame" if args.orbit else "fixed pose",
                        "partition": ("load-balanced tile-row slabs %s + RCCL gather" % [b - a for a, b in slabs]) if world > 1 else "single GPU",
                        "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len), "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback), "wave_iters_scan": int(st.n_iter_scan), "wave_iters_blend": int(st.n_iter_blend)},
             "roofline": {"bound": "hbm", "kernel": "composite_exact_kernel", "achieved": achieved,
@@ -170,9 +205,11 @@ def main():
                                "frac": st.bytes_algorithmic / (t_gpu * 1e-3) / 1e9 / HBM_PEAK_GBS if t_gpu > 0 else 0.0},
             "kernel_ms": per,
         }
+        if slab_check is not None:
+            out["multi_gpu_frame_equals_single_gpu_frame"] = slab_check
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or (os.cpu_count() or 1)
-            ref, ost, cdt = cpu_baseline(g, cam_c, threads)
+            ref, ost, cdt = cpu_baseline(g, poses[(frame_no[0] - 1) % len(poses)], threads)
             gpu_img = image.cpu().numpy().view(np.uint32)
             d = np.abs(np.stack([((gpu_img >> s) & 255).astype(np.int32) - ((ref >> s) & 255).astype(np.int32)
                                  for s in (0, 8, 16, 24)]))
