@@ -896,12 +896,34 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
     auto fetch = [&](unsigned int base, unsigned int cnt, Rec& r) {
         if (lane < cnt) r = recs[(unsigned int)keys[base + lane]];
     };
-    auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base) -> unsigned int {
+    // Can ANY sample of the block be accepted?  Upper bound of alpha over the block: the minimum of
+    // the conic's quadratic form q = a dx^2 + 2 b dx dy + c dy^2 over the block's sample rectangle
+    // (convex: 0 if the centre is inside, else the best of the four edges) gives the largest
+    // power = -q/2; below the record's certain-reject threshold (c.w, margin 1e-3) every fragment
+    // of the record in this block is (0,0,0,0): RGB untouched.  A third of all (block, record)
+    // overlaps on C3.  Their only effect, the alpha byte, is resolved by the alpha pass below.
+    auto may_contribute = [&](const Rec& r) -> bool {
+        const float a = r.b.x, b = r.b.y, c = r.b.z;
+        if (!(a > 0.0f && c > 0.0f && a * c - b * b > 0.0f)) return true;      // not positive definite: keep
+        const float x0 = xlo - r.a.x, x1 = xhi - r.a.x, y0 = r.a.y - yhi, y1 = r.a.y - ylo;
+        float qmin = 0.0f;
+        if (!(x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f)) {
+            auto q = [&](float x, float y) { return a * x * x + 2.0f * b * x * y + c * y * y; };
+            auto cl = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+            qmin = fminf(fminf(q(x0, cl(-b * x0 / c, y0, y1)), q(x1, cl(-b * x1 / c, y0, y1))),
+                         fminf(q(cl(-b * y0 / a, x0, x1), y0), q(cl(-b * y1 / a, x0, x1), y1)));
+        }
+        const float pmax = -0.5f * qmin;
+        return !(pmax + 1e-3f * (1.0f + fabsf(pmax)) < r.c.w);
+    };
+    auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base, bool only_contributing) -> unsigned int {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier LDS reads of this wave are done
         __builtin_amdgcn_wave_barrier();
         bool ov = false;
-        if (lane < cnt)
+        if (lane < cnt) {
             ov = any_sample_covered(r.a.x, r.a.z, xlo, xhi, off) && any_sample_covered(r.a.y, r.a.w, ylo, yhi, off);
+            if (ov && only_contributing) ov = may_contribute(r);
+        }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(ov);
         if (ov) {
             const unsigned int slot = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
@@ -924,6 +946,33 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
     };
 
     unsigned int itA = 0, itB = 0;               // (wave, record) iterations per phase, for the stats
+    // ---------------- alpha pass: the alpha byte ----------------
+    // blend() stores the NEW fragment's alpha (src/pipelines.rs:162-167), rejected fragments store 0,
+    // so the byte is decided by each pixel's nearest covering record -- including the records that
+    // cannot contribute colour and are dropped from the walks below.  Nearest first, until every
+    // pixel of the block has met one.
+    float alast = -1.0f;                         // < 0: no record covers the pixel, the byte keeps its old value
+    {
+        bool found = !inside;
+        Rec r;
+        unsigned int cntN = min(64u, end - beg), bsN = end - cntN;
+        fetch(bsN, cntN, r);
+        while (true) {
+            const unsigned int bs = bsN, cnt = cntN;
+            const unsigned int k = stage(r, cnt, bs, false);
+            if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }
+            for (unsigned int j = k; j-- > 0;) {
+                const float4 a = L.a[j], b = L.b[j];
+                bool cov;
+                const float alpha = frag_alpha(a, b, exp_neg, cov);      // exact, 0 when rejected
+                const bool take = cov & !found;
+                alast = take ? alpha : alast;
+                found = found | cov;
+                if (__builtin_amdgcn_ballot_w64(!found) == 0ull) break;
+            }
+            if (__builtin_amdgcn_ballot_w64(!found) == 0ull || bs == beg) break;
+        }
+    }
     // ---------------- phase A: where must the exact walk start? ----------------
     unsigned int ws = beg;                       // this wave's start position (uniform)
     if (fc.early_eps > 0.0f && end - beg >= (unsigned int)fc.early_min) {
@@ -937,7 +986,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         fetch(bsN, cntN, r);
         while (true) {
             const unsigned int bs = bsN, cnt = cntN;
-            const unsigned int k = stage(r, cnt, bs);
+            const unsigned int k = stage(r, cnt, bs, true);
             if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }   // prefetch farther batch
             for (unsigned int j = k; j-- > 0;) {                  // nearest first
                 const float4 a = L.a[j], b = L.b[j], c = L.c[j];
@@ -961,7 +1010,6 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
     // ---------------- phase B: exact compositing from the start layer ----------------
     float R = (float)((old >> 16) & 0xffu), G = (float)((old >> 8) & 0xffu), B = (float)(old & 0xffu);
     float R2 = 255.0f, G2 = 255.0f, B2 = 255.0f;  // upper end of the bracket
-    float alast = -1.0f;                          // alpha of the last covering fragment (0 if rejected); < 0: none
     // blend(): src/pipelines.rs:147-167.  With alpha == 0 it is the identity on the 8-bit state
     // (k/255*255 truncates back to k for every byte), so it runs unconditionally.
     // BR = true: carry the state twice (lo from 0, hi from 255).  Compile-time flag.
@@ -979,7 +1027,6 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
             G2 = blend_channel(G2, ia, ag);
             B2 = blend_channel(B2, ia, ab);
         }
-        alast = cov ? alpha : alast;              // rejected fragments are still blended: A := 0
     };
     // Walk batches [start, end).  In bracket mode stop at the first batch boundary where every
     // pixel has lo == hi and return that position; otherwise return `end`.
@@ -990,7 +1037,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         if (cntN) fetch(bsN, cntN, r);
         while (cntN) {
             const unsigned int bs = bsN, cnt = cntN;
-            const unsigned int k = stage(r, cnt, bs);
+            const unsigned int k = stage(r, cnt, bs, true);
             bsN = bs + cnt; cntN = min(64u, end - bsN);
             if (cntN) fetch(bsN, cntN, r);                  // prefetch the next (nearer) batch
             for (unsigned int j = 0; j < k; ++j) shade(BRt, L.a[j], L.b[j], L.c[j]);
@@ -1003,12 +1050,11 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
     while (true) {
         if (start <= beg) {                           // nothing skipped: exact from the real pixel
             R = (float)((old >> 16) & 0xffu); G = (float)((old >> 8) & 0xffu); B = (float)(old & 0xffu);
-            alast = -1.0f;
             run(std::false_type{}, beg);
             break;
         }
         // skipped layers [beg, start): bracket them
-        R = G = B = 0.0f; R2 = G2 = B2 = 255.0f; alast = -1.0f;
+        R = G = B = 0.0f; R2 = G2 = B2 = 255.0f;
         const unsigned int pos = run(std::true_type{}, start);
         const bool open = __builtin_amdgcn_ballot_w64(inside & ((R != R2) | (G != G2) | (B != B2))) != 0ull;
         if (!open) {
