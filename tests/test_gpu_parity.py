@@ -313,3 +313,39 @@ def test_anchor_fixture_on_gpu(R):
         img = np.zeros((64, 64), np.uint32)
         R.render(c, img)
         assert image_diff(img, a[name])[0] <= TOL_LSB, name
+
+
+def test_early_out_is_exact_for_any_threshold():
+    """The compositor's early-out must not change a single byte whatever its transmittance threshold:
+    off (0), default, and a reckless 1e-2 that makes thousands of brackets fail and retry."""
+    import os
+    g = splat_amd.synthetic_scene(120000, 33)
+    g.positions[:, :3] *= 0.35                      # dense: hundreds of layers per pixel, long lists
+    cam = make_camera(192, 256)
+    imgs, fallbacks = [], []
+    old = os.environ.get("SPLAT_EARLY_EPS")
+    try:
+        for eps in ("0", "1e-6", "1e-2", "0.5"):
+            os.environ["SPLAT_EARLY_EPS"] = eps
+            r = splat_amd.Renderer()
+            try:
+                if not g.cov3d.any():
+                    g.compute_cov3d(r)
+                r.upload(g)
+                img = np.zeros((192, 256), np.uint32)
+                st = r.render(cam.to_c(0.01), img)
+                imgs.append(img)
+                fallbacks.append(st.n_fallback)
+            finally:
+                r.close()
+    finally:
+        if old is None:
+            os.environ.pop("SPLAT_EARLY_EPS", None)
+        else:
+            os.environ["SPLAT_EARLY_EPS"] = old
+    assert st.max_tile_len > 1000
+    assert fallbacks[0] == 0 and fallbacks[3] > fallbacks[1]        # the reckless thresholds do exercise the retry path
+    for k in (1, 2, 3):
+        assert np.array_equal(imgs[0], imgs[k]), k
+    ref, _ = O.render(scene_dict(g), oracle_camera(cam, 0.01), nthreads=8)
+    assert image_diff(imgs[0], ref)[0] <= TOL_LSB
