@@ -6,6 +6,6 @@ Host-side mirror of the reference's operator interface (`Camera`, `GaussianList`
 fallback: anything that computes needs the built library and a GPU, and says so loudly.
 """
 from .camera import Camera  # noqa: F401
-from .gaussians import GaussianList, naive_gaussians, load_from_ply, synthetic_scene, write_ply  # noqa: F401
+from .gaussians import GaussianList, naive_gaussians, load_from_ply, synthetic_scene, write_ply, trim_ply  # noqa: F401
 from .pipelines import GaussianSplatPipeline01, GaussianSplatPipeline02  # noqa: F401
 from .renderer import Renderer, SplatError  # noqa: F401

@@ -127,6 +127,41 @@ def write_ply(filename, raw, n):
         data.tofile(f)
 
 
+def trim_ply(src, dst, count=3):
+    """Fixture tooling, the counterpart of src/bin/00_ply_load.rs (`trim <in> <out>`: copy the first
+    three vertices into a new PLY with the same header): keeps the first `count` vertices of a
+    binary-little-endian or ascii PLY, any property list."""
+    with open(src, "rb") as f:
+        header = []
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError("%s: unterminated PLY header" % src)
+            header.append(line)
+            if line.strip() == b"end_header":
+                break
+        fmt, n, stride = None, None, 0
+        sizes = {"char": 1, "uchar": 1, "int8": 1, "uint8": 1, "short": 2, "ushort": 2, "int16": 2, "uint16": 2,
+                 "int": 4, "uint": 4, "int32": 4, "uint32": 4, "float": 4, "float32": 4, "double": 8, "float64": 8}
+        for k, line in enumerate(header):
+            t = line.decode("ascii", "replace").split()
+            if t[:1] == ["format"]:
+                fmt = t[1]
+            elif t[:1] == ["element"]:
+                if t[1] != "vertex":
+                    raise ValueError("Unexpected element!")
+                n = int(t[2])
+                count = min(count, n)
+                header[k] = ("element vertex %d\n" % count).encode()
+            elif t[:1] == ["property"]:
+                stride += sizes[t[1]]
+        body = b"".join(f.readline() for _ in range(count)) if fmt == "ascii" else f.read(stride * count)
+    with open(dst, "wb") as f:
+        f.write(b"".join(header))
+        f.write(body)
+    return count
+
+
 def synthetic_raw(n, seed):
     """Seeded stand-in for a trained scene, in PLY (pre-activation) units -- SURVEY.md section 8(d)."""
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -142,3 +142,14 @@ def test_div255_identity():
     got = (np.float64(k) * np.float64(hi) + np.float64(t)).astype(np.float32)   # fma: exact product, one rounding
     assert np.array_equal(got, want)
     assert np.array_equal((want * np.float32(255)).astype(np.int32), np.arange(256))    # /255*255 round trip
+
+
+def test_trim_ply_first_three(tmp_path):
+    """fixture tooling (src/bin/00_ply_load.rs): the first three splats, same header"""
+    p, raw = _write_fixture(tmp_path, n=50, seed=3)
+    out = str(tmp_path / "trim.ply")
+    assert splat_amd.trim_ply(p, out) == 3
+    a = O.load_ply(out)
+    assert a["pos4"].shape[0] == 3
+    assert np.array_equal(a["sh"], O.load_ply(p)["sh"][:3])          # payload copied verbatim
+    assert np.allclose(a["rot"][:, 3], raw["rot_0"][:3])
