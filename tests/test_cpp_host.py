@@ -123,3 +123,12 @@ def test_cli_main_loop(tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout.count("Rendering took") == 3
     assert os.path.getsize(out) == len("P6\n160 120\n255\n") + 160 * 120 * 3
+
+
+@pytest.mark.gpu
+def test_plain_c_client(tmp_path):
+    """examples/render_c.c: a C99 program against include/splat_hip.h only"""
+    out = str(tmp_path / "c.ppm")
+    r = subprocess.run([os.path.join(ROOT, "splat_amd", "render_c"), out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "4 visible" in r.stdout and os.path.getsize(out) == len("P6\n320 240\n255\n") + 320 * 240 * 3
