@@ -349,3 +349,25 @@ def test_early_out_is_exact_for_any_threshold():
         assert np.array_equal(imgs[0], imgs[k]), k
     ref, _ = O.render(scene_dict(g), oracle_camera(cam, 0.01), nthreads=8)
     assert image_diff(imgs[0], ref)[0] <= TOL_LSB
+
+
+def test_bench_multirank_path_on_shared_gpu():
+    """bench.py's N>1 path (balanced slabs, per-rank contexts, gather to rank 0) with two and three
+    processes sharing this GPU over gloo: the gathered frame must equal the single-context frame."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPLAT_BENCH_SHARE_GPU="1")
+    for n, port in ((2, 29631), (3, 29632)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                            "--gpus", str(n), "--steps", "3", "--warmup", "1", "--workload", "C2"],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == n and d["scaling"] == "strong"
+        assert d["multi_gpu_frame_equals_single_gpu_frame"] is True
+        assert d["config"]["n_pairs"] == 946132          # the slabs partition the frame's pairs exactly
