@@ -128,6 +128,11 @@ int splat_get_records(splat_ctx* ctx, splat_record* out, uint64_t n);
  * each tile's list in blend order (far -> near). Pass NULL to query sizes via stats. */
 int splat_get_tile_lists(splat_ctx* ctx, uint32_t* tile_offsets, uint64_t n_offsets, uint32_t* order,
                          uint64_t n_order);
+/* How the last frame was binned: the per-tile bucket size (keys) of one-pass binning, 0 for
+ * two-pass binning (count, scan, emit into exactly sized lists), < 0 without a frame.  One-pass
+ * is the default; SPLAT_BUCKETS=0, a caller-fixed pair_capacity, buckets that would not fit
+ * SPLAT_BUCKET_BYTES (default 8 GiB) or a tile list longer than 16384 select two-pass. */
+int64_t splat_binning_mode(splat_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("splat_get_records", C.c_int, [C.c_void_p, C.POINTER(Record), C.c_uint64]),
     ("splat_get_tile_lists", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32),
                                         C.c_uint64]),
+    ("splat_binning_mode", C.c_int64, [C.c_void_p]),
 ]
 
 _LIB = None

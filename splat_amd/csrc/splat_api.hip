@@ -40,6 +40,7 @@ struct Slot {                  // everything one frame writes before the image
     unsigned int* offsets = nullptr;
     unsigned int* cursor = nullptr;
     unsigned int* order = nullptr;
+    unsigned int* lens = nullptr;           // list length per tile (the list starts at offsets[tile])
     unsigned long long* keys = nullptr;
     unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
     FrameStatus* d_status = nullptr;
@@ -62,7 +63,14 @@ struct splat_ctx {
     // per-frame buffers
     Slot slots[N_SLOTS];
     unsigned int m_alloc = 0;
-    uint64_t cap = 0;
+    uint64_t cap = 0;                      // entries in each used slot's keys buffer
+    bool have_keys2 = false;               // keys2 (two-pass path only) is allocated at the same size
+    // one-pass binning (per-tile buckets): on unless SPLAT_BUCKETS=0, the caller fixed pair_capacity,
+    // the buckets would not fit bucket_bytes, or a tile outgrew the largest LDS-sortable bucket
+    bool use_buckets = true;
+    bool bucket_failed = false;            // sticky until the scene / target geometry changes
+    uint64_t bucket_bytes = 8ull << 30;    // SPLAT_BUCKET_BYTES
+    unsigned int bucket_m = 0;             // tile count bucket_failed refers to
     uint64_t frame_idx = 0;
     int last_slot = -1;                    // buffer slot of the most recent frame (debug getters)
     FrameStatus* h_status = nullptr;       // pinned, one per event-ring entry
@@ -81,6 +89,7 @@ struct splat_ctx {
     FrameConst fc{};
     unsigned int n_tiles = 0;
     uint64_t overflow_want = 0;            // a harvested frame overflowed the pair buffer: grow to this
+    bool bucket_overflow = false;          // a harvested frame overflowed a tile bucket: leave one-pass binning
     FrameStatus last{};
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
     int early_min = 256;                   // SPLAT_EARLY_MIN
@@ -162,7 +171,8 @@ void harvest(splat_ctx* c, int r) {
     for (int k = 0; k < N_TIMES; ++k) c->acc_ms[k] += t[k];
     c->acc_frames++;
     const FrameStatus& st = c->h_status[r];
-    if (st.overflow) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
+    if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
+    if (st.overflow == 2) c->bucket_overflow = true;
     s.used = false;
 }
 
@@ -178,7 +188,8 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     if (rc != SPLAT_OK) return rc;
     c->m_alloc = 0;
     for (Slot& s : c->slots) {
-        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order);
+        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens);
+        HIP_TRY(c, hipMalloc(&s.lens, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, hipMalloc(&s.counts, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, hipMalloc(&s.offsets, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, hipMalloc(&s.cursor, sizeof(unsigned int) * (size_t)(m + 1)));
@@ -189,20 +200,42 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     return SPLAT_OK;
 }
 
-int ensure_keys(splat_ctx* c, uint64_t want) {
-    if (want <= c->cap) return SPLAT_OK;
+int slots_in_use(const splat_ctx* c);
+
+// keys (and, for the two-pass path whose longest lists sort through global memory, keys2) of at
+// least `want` entries in every slot that frames rotate through
+int ensure_keys(splat_ctx* c, uint64_t want, bool need_keys2) {
+    if (want <= c->cap && (!need_keys2 || c->have_keys2)) return SPLAT_OK;
     if (want >= 0xFFFFFFF0ull) return fail(c, SPLAT_ERR_CAPACITY, "pair count exceeds 2^32");
     int rc = sync_all(c);
     if (rc != SPLAT_OK) return rc;
-    c->cap = 0;
-    for (Slot& s : c->slots) {
-        dfree(s.keys); dfree(s.keys2);
+    if (need_keys2 == c->have_keys2) want = std::max(want, c->cap);
+    c->cap = 0; c->have_keys2 = false;
+    for (Slot& s : c->slots) { dfree(s.keys); dfree(s.keys2); }
+    for (int k = 0; k < slots_in_use(c); ++k) {
+        Slot& s = c->slots[k];
         hipError_t e = hipMalloc(&s.keys, sizeof(unsigned long long) * want);
-        if (e == hipSuccess) e = hipMalloc(&s.keys2, sizeof(unsigned long long) * want);
+        if (e == hipSuccess && need_keys2) e = hipMalloc(&s.keys2, sizeof(unsigned long long) * want);
         if (e != hipSuccess) return fail(c, SPLAT_ERR_CAPACITY, std::string("cannot allocate pair buffer: ") + hipGetErrorString(e));
     }
-    c->cap = want;
+    c->cap = want; c->have_keys2 = need_keys2;
     return SPLAT_OK;
+}
+
+uint64_t default_pair_capacity(const splat_ctx* c) {
+    return c->cfg.pair_capacity ? c->cfg.pair_capacity : std::max<uint64_t>(1ull << 22, 16 * c->n);
+}
+
+// Bucket size for one-pass binning over m tiles, or 0 for the two-pass path.  A bucket never needs
+// more than n entries nor more than the LDS sort holds (16384); all buckets must fit the byte
+// budget and 32-bit list positions.
+unsigned int choose_bucket_cap(splat_ctx* c, unsigned int m) {
+    if (!c->use_buckets || c->cfg.pair_capacity || m == 0) return 0;
+    if (c->bucket_failed && c->bucket_m == m) return 0;
+    uint64_t cap = 1024;
+    while (cap < 16384 && cap < c->n) cap <<= 1;
+    if ((uint64_t)m * cap * 8ull > c->bucket_bytes || (uint64_t)m * cap >= 0xFFFFFFF0ull) return 0;
+    return (unsigned int)cap;
 }
 
 int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, unsigned int* n_tiles) {
@@ -219,6 +252,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->y_up = c->cfg.y_up; fc->sample_half = c->cfg.sample_half; fc->zclip = c->cfg.zclip;
     fc->zmin = c->cfg.zmin; fc->zmax = c->cfg.zmax;
     fc->early_eps = c->early_eps; fc->early_min = c->early_min; fc->prio_len = c->prio_len;
+    fc->bucket_cap = 0;
     fc->W = (int)cam->w; fc->H = (int)cam->h;
     fc->tiles_x = (fc->W + TILE - 1) / TILE;
     int tiles_y = (fc->H + TILE - 1) / TILE;
@@ -237,7 +271,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
     EvSet& ev = c->ring[r];
     c->ring_next = (c->ring_next + 1) % EV_RING;
     harvest(c, r);
-    const int si = (int)(c->frame_idx++ % N_SLOTS);
+    const int si = (int)(c->frame_idx++ % (uint64_t)slots_in_use(c));
     Slot& s = c->slots[si];
     hipStream_t bs = c->pipeline ? c->bin_stream : c->stream;
     const unsigned int m = c->n_tiles;
@@ -249,20 +283,21 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
     }
     HIP_TRY(c, hipEventRecord(ev.e[0], bs));
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), bs));
-    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.d_status);
+    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, s.d_status);
     HIP_TRY(c, hipEventRecord(ev.e[1], bs));
-    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.d_status, c->cap);
+    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, c->cap, c->fc.bucket_cap);
     HIP_TRY(c, hipEventRecord(ev.e[2], bs));
-    launch_emit(bs, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
+    if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
+        launch_emit(bs, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
     HIP_TRY(c, hipEventRecord(ev.e[3], bs));
-    launch_sort(bs, m, s.offsets, s.order, s.keys, s.keys2, s.d_status);
+    launch_sort(bs, m, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status);
     HIP_TRY(c, hipEventRecord(ev.e[4], bs));
     if (c->pipeline) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, bs));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_ready, 0));
     }
     HIP_TRY(c, hipEventRecord(ev.e[5], c->stream));
-    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.keys, s.recs, d_argb, s.d_status);
+    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status);
     HIP_TRY(c, hipEventRecord(ev.e[6], c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
@@ -282,14 +317,34 @@ int finish_frame(splat_ctx* c) {
     if (rc != SPLAT_OK) return rc;
     if (c->last_ring >= 0) c->last = c->h_status[c->last_ring];
     for (int k = 0; k < EV_RING; ++k) harvest(c, k);
+    if (c->bucket_overflow) {
+        c->bucket_overflow = false;
+        c->bucket_failed = true; c->bucket_m = c->n_tiles;
+        return fail(c, SPLAT_ERR_CAPACITY, "a tile outgrew its bucket; switched to two-pass binning, frame must be re-rendered");
+    }
     if (c->overflow_want) {
         uint64_t want = (uint64_t)((double)c->overflow_want * 1.25) + 1024;
         c->overflow_want = 0;
-        rc = ensure_keys(c, want);
+        rc = ensure_keys(c, want, true);
         if (rc != SPLAT_OK) return rc;
         return fail(c, SPLAT_ERR_CAPACITY, "pair buffer overflowed; capacity grown, frame must be re-rendered");
     }
     return SPLAT_OK;
+}
+
+int slots_in_use(const splat_ctx* c) { return c->pipeline ? N_SLOTS : 1; }
+
+// Pick the binning path for a frame over m tiles and make sure its key storage exists.
+int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
+    fc->bucket_cap = choose_bucket_cap(c, m);
+    if (fc->bucket_cap) {
+        int rc = ensure_keys(c, (uint64_t)m * fc->bucket_cap, false);
+        if (rc == SPLAT_OK) return rc;
+        if (rc != SPLAT_ERR_CAPACITY) return rc;
+        c->bucket_failed = true; c->bucket_m = m;      // no room for the buckets: exact lists instead
+        fc->bucket_cap = 0;
+    }
+    return ensure_keys(c, default_pair_capacity(c), true);
 }
 
 void fill_stats(splat_ctx* c, splat_stats* st) {
@@ -353,6 +408,8 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
     if (const char* e4 = std::getenv("SPLAT_PIPELINE")) c->pipeline = std::atoi(e4) != 0;
+    if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;
+    if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         splat_destroy(c);
@@ -388,7 +445,7 @@ void splat_destroy(splat_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     for (Slot& s : c->slots) {
-        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
+        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
         if (s.ev_free) (void)hipEventDestroy(s.ev_free);
     }
@@ -458,11 +515,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
 #undef UP_TRY
     cleanup();
     c->n = n;
-    if (c->cap == 0) {
-        uint64_t want = c->cfg.pair_capacity ? c->cfg.pair_capacity : std::max<uint64_t>(1ull << 22, 16 * n);
-        rc = ensure_keys(c, want);
-        if (rc != SPLAT_OK) return rc;
-    }
+    c->bucket_failed = false;              // key storage is sized at the first frame (prepare_binning)
     return SPLAT_OK;
 }
 
@@ -515,9 +568,10 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     rc = ensure_bins(c, nt);
     if (rc != SPLAT_OK) return rc;
     Slot& s = c->slots[0];
+    fc.bucket_cap = 0;          // count only
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
-    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.d_status);
-    launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.d_status, ~0ull);
+    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, s.d_status);
+    launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, ~0ull, 0u);
     HIP_TRY(c, hipGetLastError());
     std::vector<unsigned int> off((size_t)nt + 1);
     HIP_TRY(c, hipMemcpyAsync(off.data(), s.offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost, c->stream));
@@ -542,12 +596,15 @@ int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int
     if (c->n_tiles == 0) { if (stats) { c->last = FrameStatus{}; c->last_ring = -1; fill_stats(c, stats); } return SPLAT_OK; }
     rc = ensure_bins(c, c->n_tiles);
     if (rc != SPLAT_OK) return rc;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        rc = prepare_binning(c, c->n_tiles, &c->fc);
+        if (rc != SPLAT_OK) return rc;
         rc = enqueue_frame(c, (uint32_t*)d_argb);
         if (rc != SPLAT_OK) return rc;
         if (!sync && !stats) return SPLAT_OK;
         rc = finish_frame(c);
-        if (rc == SPLAT_ERR_CAPACITY && c->cap > c->last.n_pairs) continue;   // grown: the frame was skipped, redo
+        // the frame was skipped on the device; its storage has been grown / its path switched: redo
+        if (rc == SPLAT_ERR_CAPACITY && (c->fc.bucket_cap || c->cap > c->last.n_pairs)) continue;
         break;
     }
     if (rc != SPLAT_OK) return rc;
@@ -601,6 +658,16 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     if (rc != SPLAT_OK) return rc;
     if (c->last_slot < 0) return fail(c, SPLAT_ERR_INVALID, "no frame rendered yet");
     const Slot& s = c->slots[c->last_slot];
+    if (c->fc.bucket_cap) {
+        // one-pass binning keeps depth and rectangle in registers only: recompute them with the
+        // counting flavour of K1 (same code, same values), then clear its counts again
+        FrameConst fc = c->fc;
+        fc.bucket_cap = 0;
+        HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
+        launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, s.d_status);
+        HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     std::vector<Rec> r(n); std::vector<float> d(n); std::vector<ushort4> q(n);
     HIP_TRY(c, hipMemcpy(r.data(), s.recs, sizeof(Rec) * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(d.data(), s.depth, sizeof(float) * n, hipMemcpyDeviceToHost));
@@ -616,6 +683,11 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     return SPLAT_OK;
 }
 
+int64_t splat_binning_mode(splat_ctx* c) {
+    if (!c || c->last_slot < 0) return -1;
+    return (int64_t)c->fc.bucket_cap;
+}
+
 int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offsets, uint32_t* order, uint64_t n_order) {
     if (!c) return SPLAT_ERR_INVALID;
     int rc = splat_sync(c);
@@ -624,10 +696,24 @@ int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offset
     const Slot& s = c->slots[c->last_slot];
     if (n_offsets != (uint64_t)c->n_tiles + 1 || n_order != c->last.n_pairs)
         return fail(c, SPLAT_ERR_INVALID, "tile list size mismatch");
-    HIP_TRY(c, hipMemcpy(tile_offsets, s.offsets, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), hipMemcpyDeviceToHost));
+    const size_t m = c->n_tiles;
+    std::vector<unsigned int> beg(m + 1), len(m + 1);
+    HIP_TRY(c, hipMemcpy(beg.data(), s.offsets, sizeof(unsigned int) * (m + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(len.data(), s.lens, sizeof(unsigned int) * m, hipMemcpyDeviceToHost));
+    uint64_t run = 0;
+    for (size_t t = 0; t < m; ++t) { tile_offsets[t] = (uint32_t)run; run += len[t]; }
+    tile_offsets[m] = (uint32_t)run;
+    if (run != n_order) return fail(c, SPLAT_ERR_INVALID, "tile list size mismatch");
     if (n_order) {
         std::vector<unsigned long long> k(n_order);
-        HIP_TRY(c, hipMemcpy(k.data(), s.keys, sizeof(unsigned long long) * n_order, hipMemcpyDeviceToHost));
+        if (!c->fc.bucket_cap) {
+            HIP_TRY(c, hipMemcpy(k.data(), s.keys, sizeof(unsigned long long) * n_order, hipMemcpyDeviceToHost));
+        } else {                    // lists live in fixed-stride buckets: gather them
+            for (size_t t = 0; t < m; ++t)
+                if (len[t])
+                    HIP_TRY(c, hipMemcpy(k.data() + tile_offsets[t], s.keys + beg[t], sizeof(unsigned long long) * len[t],
+                                         hipMemcpyDeviceToHost));
+        }
         for (uint64_t i = 0; i < n_order; ++i) order[i] = (uint32_t)k[i];
     }
     return SPLAT_OK;

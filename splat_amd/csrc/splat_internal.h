@@ -31,6 +31,7 @@ struct FrameConst {
     float early_eps;       // compositor early-out: transmittance below which a pixel stops needing layers; 0 = off
     int early_min;         // shortest list the early-out is tried on
     int prio_len;          // lists >= prio_len / 2x / 4x run at wave priority 1 / 2 / 3
+    unsigned int bucket_cap; // one-pass binning: keys per tile bucket (0: two-pass binning with exact lists)
 };
 
 // Device-side frame status, read back once per frame.
@@ -39,7 +40,7 @@ struct FrameStatus {
     unsigned long long n_singular;
     unsigned long long n_pairs;
     unsigned int max_tile_len;
-    unsigned int overflow;   // 1: n_pairs > capacity, emit/sort/composite skipped
+    unsigned int overflow;   // 1: n_pairs > capacity; 2: a tile outgrew its bucket.  Emit/sort/composite skipped
     unsigned long long n_fallback;   // waves whose early-out bracket did not close (redone in full)
     unsigned long long n_sort_fallback; // tiles whose radix-by-depth order failed the 64-bit check (depth ties): bitonic redo
     unsigned long long n_iter_scan;  // compositor (wave, record) iterations: phase A (front-to-back scan)
@@ -57,16 +58,18 @@ void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float
                        const float* sh, const unsigned int* perm, float4* planes);
 void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d);
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
-                       float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, FrameStatus* status);
+                       float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
+                       FrameStatus* status);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
-                 unsigned int* order, FrameStatus* status, unsigned long long capacity);
+                 unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
+                 unsigned int bucket_cap);
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
-                 unsigned long long* keys, unsigned long long* keys2, FrameStatus* status);
+                 const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2, FrameStatus* status);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
-                      const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
-                      FrameStatus* status);
+                      const unsigned int* order, const unsigned int* lens, const unsigned long long* keys, const Rec* recs,
+                      uint32_t* argb, FrameStatus* status);
 
 }  // namespace splat
 #endif

@@ -168,8 +168,15 @@ template <bool EMIT, int G>
 __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], const int (&tx0)[G], const int (&tx1)[G],
                                           const int (&ty0)[G], const int (&ty1)[G], int tiles_x,
                                           unsigned int* __restrict__ gcount, unsigned long long* __restrict__ keys,
-                                          const unsigned long long (&key)[G]) {
+                                          const unsigned long long (&key)[G], unsigned int bcap = 0) {
     const unsigned int tid = threadIdx.x;
+    // where entry `slot` of `tile` lives: absolute (gcount = running cursors, two-pass path) or inside
+    // the tile's fixed-stride bucket (gcount = counts from zero, one-pass path; entries past the
+    // bucket's capacity are dropped and the frame is flagged by the scan)
+    auto put = [&](unsigned int tile, unsigned int slot, unsigned long long k) {
+        if (bcap == 0) keys[slot] = k;
+        else if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
+    };
     bool small[G], big[G];
     if (tid == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
     __syncthreads();
@@ -208,7 +215,7 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
             unsigned int c = sh.table[e];
             if (c) {
                 unsigned int tile = (unsigned int)((by0 + e / bw) * tiles_x + bx0 + e % bw);
-                unsigned int base = atomicAdd(&gcount[tile], c);
+                unsigned int base = atomicAdd(&gcount[tile], c);     // (issuing several before waiting: measured no gain)
                 if (EMIT) sh.table[e] = base;
             }
         }
@@ -220,7 +227,7 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
                     for (int ty = ty0[g]; ty <= ty1[g]; ++ty)
                         for (int tx = tx0[g]; tx <= tx1[g]; ++tx) {
                             unsigned int slot = atomicAdd(&sh.table[(ty - by0) * bw + (tx - bx0)], 1u);
-                            keys[slot] = key[g];
+                            put((unsigned int)(ty * tiles_x + tx), slot, key[g]);
                         }
         }
     } else {
@@ -229,8 +236,9 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
             if (small[g])   // bounding box larger than the table (incoherent block): direct
                 for (int ty = ty0[g]; ty <= ty1[g]; ++ty)
                     for (int tx = tx0[g]; tx <= tx1[g]; ++tx) {
-                        unsigned int slot = atomicAdd(&gcount[(unsigned int)(ty * tiles_x + tx)], 1u);
-                        if (EMIT) keys[slot] = key[g];
+                        const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
+                        unsigned int slot = atomicAdd(&gcount[tile], 1u);
+                        if (EMIT) put(tile, slot, key[g]);
                     }
     }
     // close-ups: every thread takes tiles of each big rectangle (in rounds of BIG_CAP)
@@ -251,8 +259,9 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
             const int w = X1 - X0 + 1, cnt = w * (Y1 - Y0 + 1);
             const unsigned long long kk = sh.bigkey[k];
             for (int e = (int)tid; e < cnt; e += 256) {
-                unsigned int slot = atomicAdd(&gcount[(unsigned int)((Y0 + e / w) * tiles_x + X0 + e % w)], 1u);
-                if (EMIT) keys[slot] = kk;
+                const unsigned int tile = (unsigned int)((Y0 + e / w) * tiles_x + X0 + e % w);
+                unsigned int slot = atomicAdd(&gcount[tile], 1u);
+                if (EMIT) put(tile, slot, kk);
             }
         }
         __syncthreads();
@@ -267,11 +276,18 @@ __device__ __forceinline__ unsigned int depth_key(float z) {
 
 // K1 -- one thread per Gaussian (slot j of the Morton-ordered scene, original index orig[j]): the
 // whole vertex stage, a 48-B record, the exactly covered pixel rectangle, and per-tile counts.
+// BUCKET = false (two-pass binning): counts only; depth/rect/vislist feed K2, which emits the keys
+//          into exactly sized lists after the scan.
+// BUCKET = true  (one-pass binning): every tile owns a fixed-stride bucket of fc.bucket_cap keys;
+//          the slot reservation that counts a (Gaussian, tile) pair also places its key, so there is
+//          no K2 and no second read of the per-Gaussian data.
+template <bool BUCKET>
 __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes,
                                                          const unsigned int* __restrict__ orig, FrameConst fc,
                                                          Rec* __restrict__ recs, float* __restrict__ depth,
                                                          ushort4* __restrict__ rect, unsigned int* __restrict__ counts,
                                                          unsigned int* __restrict__ vislist,
+                                                         unsigned long long* __restrict__ keys,
                                                          FrameStatus* __restrict__ status) {
     __shared__ BinShared sh;
     __shared__ unsigned int swave[4];
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     bool singular = false, in_slab = false;
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
     float F[64];
-    float cx = 0, cy = 0, hx = 0, hy = 0, ca = 0, cb = 0, cc = 0;
+    float cx = 0, cy = 0, hx = 0, hy = 0, ca = 0, cb = 0, cc = 0, zview = 0;
     if (i < n) {
         // geometry first: position, opacity, cov3d live in planes 0-3 (64 B); the SH planes are
         // only fetched for Gaussians that reach this context's slab
@@ -341,9 +357,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
             in_slab = y0 <= y1;
             tx0 = fx0 >> 4; tx1 = fx1 >> 4; ty0 = (y0 >> 4) - fc.tile_row0; ty1 = (y1 >> 4) - fc.tile_row0;
         }
-        depth[i] = pc[2];
-        rect[i] = on_target ? make_ushort4((unsigned short)fx0, (unsigned short)fx1, (unsigned short)fy0, (unsigned short)fy1)
-                            : make_ushort4(1, 0, 1, 0);
+        zview = pc[2];
+        if (!BUCKET) {
+            depth[i] = pc[2];
+            rect[i] = on_target ? make_ushort4((unsigned short)fx0, (unsigned short)fx1, (unsigned short)fy0, (unsigned short)fy1)
+                                : make_ushort4(1, 0, 1, 0);
+        }
     }
     if (in_slab) {
 #pragma unroll
@@ -405,6 +424,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         r.c = make_float4(col[0], col[1], col[2], pthr);
         recs[orig[i]] = r;
     }
+    if (BUCKET) {
+        const int nvis = __syncthreads_count(in_slab), nsing = __syncthreads_count(singular);
+        if (threadIdx.x == 0) {
+            if (nvis) atomicAdd(&status->n_visible, (unsigned long long)nvis);
+            if (nsing) atomicAdd(&status->n_singular, (unsigned long long)nsing);
+        }
+        const bool v1[1] = {in_slab};
+        const int a1[1] = {tx0}, b1[1] = {tx1}, c1[1] = {ty0}, d1[1] = {ty1};
+        const unsigned long long k1[1] = {in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)orig[i]) : 0ull};
+        bin_block<true, 1>(sh, v1, a1, b1, c1, d1, fc.tiles_x, counts, keys, k1, fc.bucket_cap);
+        return;
+    }
     // compact the slots that reach the slab into vislist (K2 runs over those only)
     {
         const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -437,8 +468,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
 // class, so the sort and composite grids start their longest tiles first (no long tail).
 __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int* __restrict__ counts,
                                                     unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor,
-                                                    unsigned int* __restrict__ order, FrameStatus* __restrict__ status,
-                                                    unsigned long long capacity) {
+                                                    unsigned int* __restrict__ order, unsigned int* __restrict__ lens,
+                                                    FrameStatus* __restrict__ status,
+                                                    unsigned long long capacity, unsigned int bucket_cap) {
     constexpr int NCLS = 64;
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int hist[NCLS];
@@ -470,7 +502,14 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
 #pragma unroll
         for (unsigned int w = 0; w < 16; ++w) { unsigned int x = wsum[w]; total += x; if (w < wave) woff += x; }
         const unsigned int excl = carry + woff + v - c;
-        if (k < m) { offsets[k] = excl; cursor[k] = excl; atomicAdd(&hist[cls_of(c)], 1u); }
+        if (k < m) {
+            // one-pass binning: list k starts at its bucket and is at most bucket_cap long
+            offsets[k] = bucket_cap ? k * bucket_cap : excl;
+            cursor[k] = excl;
+            const unsigned int len = bucket_cap ? min(c, bucket_cap) : c;
+            lens[k] = len;
+            atomicAdd(&hist[cls_of(len)], 1u);
+        }
         carry += total;
         __syncthreads();
     }
@@ -482,16 +521,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         for (int w = 0; w < 16; ++w) mx = max(mx, wsum[w]);
         offsets[m] = carry;
         status->n_pairs = carry;
-        status->overflow = ((unsigned long long)carry > capacity) ? 1u : 0u;
+        status->overflow = bucket_cap ? ((mx > bucket_cap) ? 2u : 0u) : (((unsigned long long)carry > capacity) ? 1u : 0u);
         status->max_tile_len = mx;
         unsigned int run = 0;
         for (int cidx = NCLS - 1; cidx >= 0; --cidx) { start[cidx] = run; run += hist[cidx]; }
     }
-    __syncthreads();   // offsets[] written above by this workgroup are visible to it
-    for (unsigned int k = tid; k < m; k += 1024) {
-        unsigned int b = offsets[k], e = (k + 1 == m) ? carry : offsets[k + 1];
-        order[atomicAdd(&start[cls_of(e - b)], 1u)] = k;
-    }
+    __syncthreads();   // lens[] written above by this workgroup are visible to it
+    for (unsigned int k = tid; k < m; k += 1024) order[atomicAdd(&start[cls_of(lens[k])], 1u)] = k;
 }
 
 // K2 -- one thread per Gaussian slot: claim a slot in every overlapped tile's bucket and write the
@@ -562,7 +598,44 @@ __device__ __forceinline__ void bitonic_sort(T* s, unsigned int n, unsigned int 
 }
 
 
-// In-LDS LSD radix sort of the keys by their DEPTH half (upper 32 bits): four 8-bit passes.
+// Digit plan of a list whose depth keys span [dmin, dmax]: the keys are sorted on (depth - dmin),
+// which has V = bits(dmax - dmin) significant bits, in P = ceil(V/8) passes of w = ceil(V/P) bits
+// each.  Subtracting the minimum matters beyond saving passes: the raw top byte (sign + exponent)
+// takes two or three values per tile, and a pass whose 64 lanes all hit the same two histogram
+// words serialises in the LDS atomic unit -- the degenerate top passes, not the evenly spread low
+// ones, made a 10 000-key list take 60 us.
+struct DigitPlan { unsigned int dmin; int P; int w; };
+__device__ __forceinline__ DigitPlan plan_digits(unsigned int dmin, unsigned int dmax, bool even_passes) {
+    const unsigned int range = dmax - dmin;
+    const int V = range ? 32 - __clz((int)range) : 0;
+    int P = (V + 7) / 8;
+    if (even_passes && (P & 1)) ++P;                       // ping-pong buffers: finish where we started
+    DigitPlan pl;
+    pl.dmin = dmin; pl.P = P; pl.w = P ? (V + P - 1) / P : 0;
+    return pl;
+}
+__device__ __forceinline__ unsigned int digit_of(unsigned long long key, const DigitPlan& pl, int pass) {
+    return (((unsigned int)(key >> 32) - pl.dmin) >> (pl.w * pass)) & ((1u << pl.w) - 1u);
+}
+// Block-wide min / max of the depth halves; every thread passes the min / max of the keys it has seen.
+// `scratch` = two LDS words.  Ends with a barrier.
+__device__ __forceinline__ DigitPlan block_digit_plan(unsigned int mn, unsigned int mx, unsigned int* scratch,
+                                                      unsigned int tid, bool even_passes) {
+    if (tid == 0) { scratch[0] = 0xffffffffu; scratch[1] = 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (unsigned int)__shfl_xor((int)mn, o));
+        mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+    }
+    if ((tid & 63u) == 0) { atomicMin(&scratch[0], mn); atomicMax(&scratch[1], mx); }
+    __syncthreads();
+    const DigitPlan pl = plan_digits(scratch[0], scratch[1], even_passes);
+    __syncthreads();                                       // scratch is reused by the passes
+    return pl;
+}
+
+// In-LDS LSD radix sort of the keys by their DEPTH half (upper 32 bits): pl.P passes of pl.w bits.
 // Wave w owns the contiguous chunk [w*C, (w+1)*C) of the array, striped over its lanes, so the
 // (wave, round, lane) processing order is the memory order and the sort is stable:
 //   count    per-wave digit histogram; lanes with the same digit find each other with 8 ballots
@@ -573,23 +646,37 @@ __device__ __forceinline__ void bitonic_sort(T* s, unsigned int n, unsigned int 
 template <int NT, int EMAX>
 __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned int* hist /*[NT/64][256]*/,
                                                  unsigned int* tot /*[256]*/, unsigned int* dbase /*[256]*/,
-                                                 unsigned int n, unsigned int tid) {
+                                                 unsigned int n, unsigned int tid, const DigitPlan pl) {
     constexpr unsigned int NW = NT / 64;
     const unsigned int wave = tid >> 6, lane = tid & 63u;
     const unsigned int C = (((n + NW - 1) / NW) + 63u) & ~63u;       // chunk per wave, multiple of 64
     const unsigned int w0 = wave * C, w1 = min(w0 + C, n);
     const unsigned int E = C >> 6;                                   // rounds per wave (<= EMAX)
     unsigned int* myhist = hist + wave * 256u;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 32 + 8 * pass;
+    for (int pass = 0; pass < pl.P; ++pass) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) myhist[lane * 4u + q] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // count: LDS atomics on this wave's histogram row (digits straight from LDS)
-        for (unsigned int e = 0; e < E; ++e) {
-            const unsigned int i = w0 + e * 64u + lane;
-            if (i < w1) atomicAdd(&myhist[(unsigned int)(s[i] >> shift) & 255u], 1u);
+        // every wave pulls its keys into registers ...
+        unsigned long long k[EMAX];
+        unsigned int rank[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const unsigned int i = w0 + (unsigned int)e * 64u + lane;
+            k[e] = ((unsigned int)e < E && i < w1) ? s[i] : ~0ull;
+        }
+        // ... and counts them with ONE returning LDS atomic per key on its histogram row: the value
+        // returned is the key's rank among the wave's keys of the same digit.  The rounds are issued
+        // in order and the LDS serialises the lanes of one instruction in lane order on this
+        // hardware, so ranks follow the memory order and the pass is stable; that is NOT an
+        // architectural guarantee, so the caller's 64-bit order check (+ exact fallback) stays the
+        // safety net.
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const unsigned int i = w0 + (unsigned int)e * 64u + lane;
+            rank[e] = 0;
+            if ((unsigned int)e < E && i < w1) rank[e] = atomicAdd(&myhist[digit_of(k[e], pl, pass)], 1u);
         }
         __syncthreads();
         // scan over waves (thread d handles digit d), then over digits (wave 0)
@@ -615,29 +702,14 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
             const unsigned int ex = v - (t0 + t1 + t2 + t3);
             dbase[4 * tid] = ex; dbase[4 * tid + 1] = ex + t0; dbase[4 * tid + 2] = ex + t0 + t1; dbase[4 * tid + 3] = ex + t0 + t1 + t2;
         }
-        // every wave pulls its keys into registers, then (barrier) scatters them in place
-        unsigned long long k[EMAX];
+        __syncthreads();
+        // scatter in place: digit base + this wave's offset within the digit + rank within the wave
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
             const unsigned int i = w0 + (unsigned int)e * 64u + lane;
-            k[e] = ((unsigned int)e < E && i < w1) ? s[i] : ~0ull;
-        }
-        __syncthreads();
-        // Rank within the wave = value returned by an LDS atomic on the (already exclusive) histogram
-        // row.  Rounds are issued in order and the LDS serialises the lanes of one instruction in
-        // lane order on this hardware, which makes the pass stable; that is NOT an architectural
-        // guarantee, so the caller's 64-bit order check (+ exact fallback) stays the safety net.
-#pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            if ((unsigned int)e < E) {
-                const unsigned int i = w0 + (unsigned int)e * 64u + lane;
-                if (i < w1) {
-                    const unsigned int d = (unsigned int)(k[e] >> shift) & 255u;
-                    const unsigned int rank = atomicAdd(&myhist[d], 1u);
-                    s[dbase[d] + rank] = k[e];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+            if ((unsigned int)e < E && i < w1) {
+                const unsigned int d = digit_of(k[e], pl, pass);
+                s[dbase[d] + myhist[d] + rank[e]] = k[e];
             }
         }
         __syncthreads();
@@ -652,8 +724,8 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
 template <int NT, int EMAX>
 __device__ __forceinline__ void sort_keys_lds(unsigned long long* s, unsigned int* hist, unsigned int* tot,
                                               unsigned int* dbase, unsigned int n, unsigned int tid,
-                                              FrameStatus* status) {
-    radix_sort_depth<NT, EMAX>(s, hist, tot, dbase, n, tid);
+                                              FrameStatus* status, const DigitPlan pl) {
+    radix_sort_depth<NT, EMAX>(s, hist, tot, dbase, n, tid, pl);
     for (int it = 0; it < 6; ++it) {
         bool swapped = false;
 #pragma unroll
@@ -676,15 +748,14 @@ __device__ __forceinline__ void sort_keys_lds(unsigned long long* s, unsigned in
 template <int NT>
 __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src, unsigned long long* dst,
                                                         unsigned int* hist, unsigned int* tot, unsigned int* dbase,
-                                                        unsigned int n, unsigned int tid) {
+                                                        unsigned int n, unsigned int tid, const DigitPlan pl) {
     constexpr unsigned int NW = NT / 64;
     const unsigned int wave = tid >> 6, lane = tid & 63u;
     const unsigned int C = (((n + NW - 1) / NW) + 63u) & ~63u;
     const unsigned int w0 = wave * C, w1 = min(w0 + C, n);
     const unsigned int E = C >> 6;
     unsigned int* myhist = hist + wave * 256u;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 32 + 8 * pass;
+    for (int pass = 0; pass < pl.P; ++pass) {              // pl.P is even: the result ends in `src`
 #pragma unroll
         for (int q = 0; q < 4; ++q) myhist[lane * 4u + q] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -694,7 +765,7 @@ __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src,
                 const unsigned int i = w0 + e * 64u + lane;
                 if (i < w1) {
                     const unsigned long long key = src[i];
-                    const unsigned int d = (unsigned int)(key >> shift) & 255u;
+                    const unsigned int d = digit_of(key, pl, pass);
                     const unsigned int rank = atomicAdd(&myhist[d], 1u);     // see radix_sort_depth on stability
                     if (phase == 1) dst[dbase[d] + rank] = key;
                 }
@@ -738,6 +809,7 @@ __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src,
 template <int NT, int CAP>
 __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __restrict__ offsets,
                                                          const unsigned int* __restrict__ order,
+                                                         const unsigned int* __restrict__ lens,
                                                          unsigned long long* __restrict__ keys,
                                                          unsigned long long* __restrict__ keys2,
                                                          FrameStatus* __restrict__ status, unsigned int lo,
@@ -749,19 +821,34 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
     unsigned int* dbase = tot + 256;
     if (status->overflow) return;
     const unsigned int tile = order[blockIdx.x];
-    const unsigned int b = offsets[tile], e = offsets[tile + 1];
-    const unsigned int n = e - b;
+    const unsigned int b = offsets[tile];
+    const unsigned int n = lens[tile];
     if (n < 2 || n <= lo) return;
     if (n <= (unsigned int)CAP) {
-        for (unsigned int t = threadIdx.x; t < n; t += NT) s[t] = keys[b + t];
-        __syncthreads();
-        if (n <= radix_min) bitonic_sort(s, n, threadIdx.x, NT);   // few steps: cheaper than four radix passes
-        else sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status);
+        unsigned int mn = 0xffffffffu, mx = 0u;
+        for (unsigned int t = threadIdx.x; t < n; t += NT) {
+            const unsigned long long k = keys[b + t];
+            s[t] = k;
+            mn = min(mn, (unsigned int)(k >> 32)); mx = max(mx, (unsigned int)(k >> 32));
+        }
+        if (n <= radix_min) {
+            __syncthreads();
+            bitonic_sort(s, n, threadIdx.x, NT);   // few steps: cheaper than the radix passes
+        } else {
+            const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, false);   // (its barriers publish s[])
+            sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl);
+        }
         for (unsigned int t = threadIdx.x; t < n; t += NT) keys[b + t] = s[t];
     } else if (last) {
         // longer than LDS: radix passes over the L2-resident bucket, then the same tie fix-up
         unsigned long long* g = keys + b;
-        radix_sort_depth_global<NT>(g, keys2 + b, hist, tot, dbase, n, threadIdx.x);
+        unsigned int mn = 0xffffffffu, mx = 0u;
+        for (unsigned int t = threadIdx.x; t < n; t += NT) {
+            const unsigned int d = (unsigned int)(g[t] >> 32);
+            mn = min(mn, d); mx = max(mx, d);
+        }
+        const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, true);
+        radix_sort_depth_global<NT>(g, keys2 + b, hist, tot, dbase, n, threadIdx.x, pl);
         bool sorted = false;
         for (int it = 0; it < 6 && !sorted; ++it) {
             bool swapped = false;
@@ -818,15 +905,15 @@ __device__ __forceinline__ float div255(float k) {
     const float RH = 0x1.010102p-8f, RL = -0x1.fdfdfep-33f;
     return fmaf(k, RH, k * RL);
 }
-__device__ __forceinline__ float quant_u8(float v) {
-    // Rust `(v) as u8` kept as a float: NaN/negative -> 0, >= 255 -> 255, else truncate
-    return truncf(fminf(fmaxf(v, 0.0f), 255.0f));
-}
 // One channel of blend(): src/pipelines.rs:157-161.  Monotone non-decreasing in the state k for
 // fixed alpha/colour (every step -- /255, *ia, +const, *255, clamp, trunc -- is monotone under
 // round-to-nearest), which is what makes the [lo,hi] bracket of the early-out exact.
+// The u8 cast saturates (NaN/negative -> 0, >= 255 -> 255).  Clamping the blended value to [0,1]
+// BEFORE the *255 gives the same byte for every input (x in [0,1] is untouched; x > 1 -> 255; x < 0 or
+// NaN -> 0) and folds into the add as its clamp modifier: one VALU less per channel than med3.
 __device__ __forceinline__ float blend_channel(float k, float ia, float ac) {
-    return quant_u8((ia * div255(k) + ac) * 255.0f);
+    const float x = __builtin_amdgcn_fmed3f(ia * div255(k) + ac, 0.0f, 1.0f);
+    return truncf(x * 255.0f);
 }
 
 struct WaveLds { float4 a[64]; float4 b[64]; float4 c[64]; };   // one batch of 64 records, private to a wave
@@ -849,6 +936,7 @@ struct WaveLds { float4 a[64]; float4 b[64]; float4 c[64]; };   // one batch of 
 #endif
 __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
+                                                              const unsigned int* __restrict__ lens,
                                                               const unsigned long long* __restrict__ keys,
                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                               FrameStatus* __restrict__ status) {
@@ -857,7 +945,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
     const unsigned int tile = order[blockIdx.x];
     const unsigned int tid = threadIdx.x;
     const unsigned int beg = __builtin_amdgcn_readfirstlane(offsets[tile]);
-    const unsigned int end = __builtin_amdgcn_readfirstlane(offsets[tile + 1]);
+    const unsigned int end = beg + __builtin_amdgcn_readfirstlane(lens[tile]);
     if (beg == end) return;
     const unsigned int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     // The longest lists are the critical path of the launch: let their waves win VALU arbitration
@@ -1095,14 +1183,21 @@ void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* 
     hipLaunchKernelGGL(cov3d_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, scales3, rot4, cov3d);
 }
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
-                       float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, FrameStatus* status) {
+                       float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
+                       FrameStatus* status) {
     if (!n) return;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth, rect,
-                       counts, vislist, status);
+    if (fc.bucket_cap)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth,
+                           rect, counts, vislist, keys, status);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth,
+                           rect, counts, vislist, keys, status);
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
-                 unsigned int* order, FrameStatus* status, unsigned long long capacity) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, status, capacity);
+                 unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
+                 unsigned int bucket_cap) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
+                       bucket_cap);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
@@ -1110,7 +1205,7 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
     hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256 * EMIT_G)), dim3(256), 0, s, fc, depth, rect, orig, vislist, cursor, keys, status);
 }
 void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
-                 unsigned long long* keys, unsigned long long* keys2, FrameStatus* status) {
+                 const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2, FrameStatus* status) {
     if (!n_tiles) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1124,19 +1219,19 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offset
     static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
     // longest class first (the tiles are ordered longest-first too)
     hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(n_tiles), dim3(1024), (sort_lds_bytes<1024, 16384>()), s, offsets, order,
-                       keys, keys2, status, 8192u, radix_min, 1);
+                       lens, keys, keys2, status, 8192u, radix_min, 1);
     hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(n_tiles), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
-                       keys, keys2, status, 2048u, radix_min, 0);
+                       lens, keys, keys2, status, 2048u, radix_min, 0);
     hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
-                       keys, keys2, status, 0u, radix_min, 0);
+                       lens, keys, keys2, status, 0u, radix_min, 0);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
-                      const unsigned int* order, const unsigned long long* keys, const Rec* recs, uint32_t* argb,
-                      FrameStatus* status) {
+                      const unsigned int* order, const unsigned int* lens, const unsigned long long* keys, const Rec* recs,
+                      uint32_t* argb, FrameStatus* status) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
-    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), 0, s, fc, offsets, order, keys, recs, argb, status);
+    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status);
 }
 
 }  // namespace splat

@@ -122,6 +122,10 @@ class Renderer:
         self._check(self._L.splat_get_records(self._h, out.ctypes.data_as(C.POINTER(_lib.Record)), self.n))
         return out
 
+    def binning_mode(self):
+        """bucket size (keys per tile) of the last frame's one-pass binning, 0 = two-pass, < 0 = no frame"""
+        return int(self._L.splat_binning_mode(self._h))
+
     def tile_lists(self, n_tiles, n_pairs):
         off = np.zeros(n_tiles + 1, np.uint32)
         order = np.zeros(n_pairs, np.uint32)

@@ -235,6 +235,70 @@ def test_long_tile_lists_all_sort_paths():
         r.close()
 
 
+def test_binning_paths_agree():
+    """One-pass binning (per-tile buckets filled by K1) and two-pass binning (count, scan, emit) must
+    give the same lists and the same frame; a tile that outgrows its bucket, or buckets that do not
+    fit the byte budget, fall back to two-pass on their own."""
+    import os
+    g = splat_amd.synthetic_scene(60000, 41)
+    g.positions[:, :3] *= 0.6
+    cam = make_camera(200, 328)
+    saved = {k: os.environ.get(k) for k in ("SPLAT_BUCKETS", "SPLAT_BUCKET_BYTES")}
+    out = {}
+    try:
+        for name, env in (("one", {}), ("two", {"SPLAT_BUCKETS": "0"}), ("nofit", {"SPLAT_BUCKET_BYTES": "100000"})):
+            for k in saved:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            r = splat_amd.Renderer()
+            try:
+                if not g.cov3d.any():
+                    g.compute_cov3d(r)
+                r.upload(g)
+                img = np.zeros((200, 328), np.uint32)
+                st = r.render(cam.to_c(0.01), img)
+                n_tiles = ((328 + 15) // 16) * ((200 + 15) // 16)
+                off, order = r.tile_lists(n_tiles, st.n_pairs)
+                recs = r.records()
+                out[name] = (img, off, order, recs, r.binning_mode(), st.n_pairs, st.max_tile_len)
+            finally:
+                r.close()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert out["one"][4] > 0 and out["two"][4] == 0 and out["nofit"][4] == 0, [o[4] for o in out.values()]
+    for name in ("two", "nofit"):
+        assert np.array_equal(out["one"][0], out[name][0]), name
+        assert np.array_equal(out["one"][1], out[name][1]) and np.array_equal(out["one"][2], out[name][2]), name
+        assert out["one"][3].tobytes() == out[name][3].tobytes(), name
+        assert out["one"][5:] == out[name][5:]
+    ref, ost = O.render(scene_dict(g), oracle_camera(cam, 0.01), nthreads=8)
+    assert out["one"][5] == ost.n_tile_pairs
+    assert image_diff(out["one"][0], ref)[0] <= TOL_LSB
+
+
+def test_bucket_overflow_falls_back_to_two_pass():
+    """a tile list longer than the largest bucket (16384): the frame is redone with two-pass binning"""
+    r = splat_amd.Renderer()
+    try:
+        g = splat_amd.synthetic_scene(40000, 17)
+        g.positions[:, :3] *= 0.02
+        g.compute_cov3d(r)
+        cam = make_camera(96, 96)
+        img, st, ref, ost = render_both(r, g, cam, 0.01)
+        assert st.max_tile_len > 16384 and r.binning_mode() == 0
+        assert st.n_pairs == ost.n_tile_pairs
+        assert image_diff(img, ref)[0] <= TOL_LSB
+        # a scene that fits afterwards goes back to one-pass
+        g2 = gpu_scene(r, 20000, 5)
+        img, st, ref, ost = render_both(r, g2, make_camera(96, 96), 0.01)
+        assert r.binning_mode() > 0 and image_diff(img, ref)[0] <= TOL_LSB
+    finally:
+        r.close()
+
+
 def test_slabs_equal_full_frame(R):
     """multi-GPU decomposition: tile-row slabs rendered separately == the full frame, byte for byte"""
     g = gpu_scene(R, 30000, 19)
