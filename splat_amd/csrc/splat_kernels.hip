@@ -599,19 +599,20 @@ __device__ __forceinline__ void bitonic_sort(T* s, unsigned int n, unsigned int 
 
 
 // Digit plan of a list whose depth keys span [dmin, dmax]: the keys are sorted on (depth - dmin),
-// which has V = bits(dmax - dmin) significant bits, in P = ceil(V/8) passes of w = ceil(V/P) bits
-// each.  Subtracting the minimum matters beyond saving passes: the raw top byte (sign + exponent)
+// which has V = bits(dmax - dmin) significant bits, in P = ceil(V/wmax) passes of w = ceil(V/P) bits
+// each (wmax = 9 when the list leaves room in LDS for 512-bin histograms -- float depths over a few
+// octaves have V = 24..27, three passes instead of four -- else 8).  Subtracting the minimum matters beyond saving passes: the raw top byte (sign + exponent)
 // takes two or three values per tile, and a pass whose 64 lanes all hit the same two histogram
 // words serialises in the LDS atomic unit -- the degenerate top passes, not the evenly spread low
 // ones, made a 10 000-key list take 60 us.
-struct DigitPlan { unsigned int dmin; int P; int w; };
-__device__ __forceinline__ DigitPlan plan_digits(unsigned int dmin, unsigned int dmax, bool even_passes) {
+struct DigitPlan { unsigned int dmin; int P; int w; int lb; };   // lb: log2 of the histogram size (>= w)
+__device__ __forceinline__ DigitPlan plan_digits(unsigned int dmin, unsigned int dmax, bool even_passes, int wmax) {
     const unsigned int range = dmax - dmin;
     const int V = range ? 32 - __clz((int)range) : 0;
-    int P = (V + 7) / 8;
+    int P = (V + wmax - 1) / wmax;
     if (even_passes && (P & 1)) ++P;                       // ping-pong buffers: finish where we started
     DigitPlan pl;
-    pl.dmin = dmin; pl.P = P; pl.w = P ? (V + P - 1) / P : 0;
+    pl.dmin = dmin; pl.P = P; pl.w = P ? (V + P - 1) / P : 0; pl.lb = wmax;
     return pl;
 }
 __device__ __forceinline__ unsigned int digit_of(unsigned long long key, const DigitPlan& pl, int pass) {
@@ -620,7 +621,7 @@ __device__ __forceinline__ unsigned int digit_of(unsigned long long key, const D
 // Block-wide min / max of the depth halves; every thread passes the min / max of the keys it has seen.
 // `scratch` = two LDS words.  Ends with a barrier.
 __device__ __forceinline__ DigitPlan block_digit_plan(unsigned int mn, unsigned int mx, unsigned int* scratch,
-                                                      unsigned int tid, bool even_passes) {
+                                                      unsigned int tid, bool even_passes, int wmax) {
     if (tid == 0) { scratch[0] = 0xffffffffu; scratch[1] = 0u; }
     __syncthreads();
 #pragma unroll
@@ -630,7 +631,7 @@ __device__ __forceinline__ DigitPlan block_digit_plan(unsigned int mn, unsigned 
     }
     if ((tid & 63u) == 0) { atomicMin(&scratch[0], mn); atomicMax(&scratch[1], mx); }
     __syncthreads();
-    const DigitPlan pl = plan_digits(scratch[0], scratch[1], even_passes);
+    const DigitPlan pl = plan_digits(scratch[0], scratch[1], even_passes, wmax);
     __syncthreads();                                       // scratch is reused by the passes
     return pl;
 }
@@ -644,18 +645,18 @@ __device__ __forceinline__ DigitPlan block_digit_plan(unsigned int mn, unsigned 
 // Depth ties are left in bucket order, which is arbitrary; the caller checks the full 64-bit
 // order afterwards and falls back to the exact bitonic network if anything is out of place.
 template <int NT, int EMAX>
-__device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned int* hist /*[NT/64][256]*/,
-                                                 unsigned int* tot /*[256]*/, unsigned int* dbase /*[256]*/,
+__device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned int* hist /*[NT/64][nb]*/,
+                                                 unsigned int* tot /*[nb]*/, unsigned int* dbase /*[nb]*/,
                                                  unsigned int n, unsigned int tid, const DigitPlan pl) {
     constexpr unsigned int NW = NT / 64;
     const unsigned int wave = tid >> 6, lane = tid & 63u;
     const unsigned int C = (((n + NW - 1) / NW) + 63u) & ~63u;       // chunk per wave, multiple of 64
     const unsigned int w0 = wave * C, w1 = min(w0 + C, n);
     const unsigned int E = C >> 6;                                   // rounds per wave (<= EMAX)
-    unsigned int* myhist = hist + wave * 256u;
+    const unsigned int nb = 1u << pl.lb;                              // 256 or 512 bins
+    unsigned int* myhist = hist + wave * nb;
     for (int pass = 0; pass < pl.P; ++pass) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) myhist[lane * 4u + q] = 0;
+        for (unsigned int q = lane; q < nb; q += 64u) myhist[q] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // every wave pulls its keys into registers ...
@@ -679,28 +680,33 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
             if ((unsigned int)e < E && i < w1) rank[e] = atomicAdd(&myhist[digit_of(k[e], pl, pass)], 1u);
         }
         __syncthreads();
-        // scan over waves (thread d handles digit d), then over digits (wave 0)
-        if (tid < 256) {
+        // scan over waves (one thread per digit), then over digits (wave 0, nb/64 digits per lane)
+        for (unsigned int d = tid; d < nb; d += NT) {
             unsigned int acc = 0;
 #pragma unroll
             for (unsigned int w = 0; w < NW; ++w) {
-                const unsigned int t = hist[w * 256u + tid];
-                hist[w * 256u + tid] = acc;
+                const unsigned int t = hist[w * nb + d];
+                hist[w * nb + d] = acc;
                 acc += t;
             }
-            tot[tid] = acc;
+            tot[d] = acc;
         }
         __syncthreads();
         if (tid < 64) {
-            const unsigned int t0 = tot[4 * tid], t1 = tot[4 * tid + 1], t2 = tot[4 * tid + 2], t3 = tot[4 * tid + 3];
-            unsigned int v = t0 + t1 + t2 + t3;
+            const unsigned int per = nb >> 6;                        // 4 or 8
+            unsigned int t[8], sum = 0;
+#pragma unroll
+            for (unsigned int j = 0; j < 8; ++j) { t[j] = (j < per) ? tot[per * tid + j] : 0u; sum += t[j]; }
+            unsigned int v = sum;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
-                const unsigned int t = (unsigned int)__shfl_up((int)v, o);
-                if ((int)tid >= o) v += t;
+                const unsigned int u = (unsigned int)__shfl_up((int)v, o);
+                if ((int)tid >= o) v += u;
             }
-            const unsigned int ex = v - (t0 + t1 + t2 + t3);
-            dbase[4 * tid] = ex; dbase[4 * tid + 1] = ex + t0; dbase[4 * tid + 2] = ex + t0 + t1; dbase[4 * tid + 3] = ex + t0 + t1 + t2;
+            unsigned int ex = v - sum;
+#pragma unroll
+            for (unsigned int j = 0; j < 8; ++j)
+                if (j < per) { dbase[per * tid + j] = ex; ex += t[j]; }
         }
         __syncthreads();
         // scatter in place: digit base + this wave's offset within the digit + rank within the wave
@@ -804,6 +810,9 @@ __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src,
     }
 }
 
+template <int NT, int CAP>
+constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 512) * 4; }
+
 // One workgroup per tile; a launch handles the lists with lo < n <= CAP (three size classes, so
 // that mid-sized lists get two workgroups per CU instead of one LDS-filling one).
 template <int NT, int CAP>
@@ -816,26 +825,35 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
                                                          unsigned int radix_min, int last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
-    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)CAP * 8);
-    unsigned int* tot = hist + (NT / 64) * 256;
-    unsigned int* dbase = tot + 256;
     if (status->overflow) return;
     const unsigned int tile = order[blockIdx.x];
     const unsigned int b = offsets[tile];
     const unsigned int n = lens[tile];
+    // histograms live right behind the keys in use: a list that leaves room gets 512 bins
+    constexpr unsigned int NW = NT / 64;
+    const unsigned int keys_bytes = ((min(n, (unsigned int)CAP) * 8u) + 15u) & ~15u;
+    const int lb = (keys_bytes + (NW + 2u) * 512u * 4u <= sort_lds_bytes<NT, CAP>()) ? 9 : 8;
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + keys_bytes);
+    unsigned int* tot = hist + (NW << lb);
+    unsigned int* dbase = tot + (1u << lb);
     if (n < 2 || n <= lo) return;
     if (n <= (unsigned int)CAP) {
         unsigned int mn = 0xffffffffu, mx = 0u;
-        for (unsigned int t = threadIdx.x; t < n; t += NT) {
-            const unsigned long long k = keys[b + t];
-            s[t] = k;
-            mn = min(mn, (unsigned int)(k >> 32)); mx = max(mx, (unsigned int)(k >> 32));
+        for (unsigned int t0 = threadIdx.x; t0 < n; t0 += 8u * NT) {     // eight loads in flight per thread
+            unsigned long long k[8];
+#pragma unroll
+            for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; k[u] = (t < n) ? keys[b + t] : 0ull; }
+#pragma unroll
+            for (unsigned int u = 0; u < 8; ++u) {
+                const unsigned int t = t0 + u * NT;
+                if (t < n) { s[t] = k[u]; mn = min(mn, (unsigned int)(k[u] >> 32)); mx = max(mx, (unsigned int)(k[u] >> 32)); }
+            }
         }
         if (n <= radix_min) {
             __syncthreads();
             bitonic_sort(s, n, threadIdx.x, NT);   // few steps: cheaper than the radix passes
         } else {
-            const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, false);   // (its barriers publish s[])
+            const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, false, lb);   // (its barriers publish s[])
             sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl);
         }
         for (unsigned int t = threadIdx.x; t < n; t += NT) keys[b + t] = s[t];
@@ -847,7 +865,7 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
             const unsigned int d = (unsigned int)(g[t] >> 32);
             mn = min(mn, d); mx = max(mx, d);
         }
-        const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, true);
+        const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, true, 8);
         radix_sort_depth_global<NT>(g, keys2 + b, hist, tot, dbase, n, threadIdx.x, pl);
         bool sorted = false;
         for (int it = 0; it < 6 && !sorted; ++it) {
@@ -868,8 +886,6 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
         }
     }
 }
-template <int NT, int CAP>
-constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 512) * 4; }
 
 // Does ANY sample s = lo + k (k = 0..count-1, all exactly representable) satisfy |s - c| <= h ?
 // |s - c| grows monotonically (also after f32 rounding) away from c, so testing the one or two
