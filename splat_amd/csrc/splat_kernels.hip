@@ -164,7 +164,13 @@ struct BinShared {
 
 // G Gaussians per thread per call: the fixed costs (bbox reduce, table zero/flush, ~6 barriers)
 // are paid once per 256*G Gaussians.
-template <bool EMIT, int G>
+// PREINIT: the caller has already zeroed the whole table, reset box/nbig and passed a barrier
+// (K1 does it before its long vertex stage, which saves two barriers here).
+__device__ __forceinline__ void bin_preinit(BinShared& sh) {
+    for (int e = (int)threadIdx.x; e < AGG_CAP; e += 256) sh.table[e] = 0;
+    if (threadIdx.x == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
+}
+template <bool EMIT, int G, bool PREINIT = false>
 __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], const int (&tx0)[G], const int (&tx1)[G],
                                           const int (&ty0)[G], const int (&ty1)[G], int tiles_x,
                                           unsigned int* __restrict__ gcount, unsigned long long* __restrict__ keys,
@@ -178,8 +184,10 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
         else if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
     };
     bool small[G], big[G];
-    if (tid == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
-    __syncthreads();
+    if (!PREINIT) {
+        if (tid == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
+        __syncthreads();
+    }
     {   // block bounding box of the aggregated rectangles: wave reduce, then one LDS atomic per wave
         int a = 0x7fffffff, b = 0x7fffffff, c = -1, d = -1;
 #pragma unroll
@@ -203,8 +211,10 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
     const int area = (sh.box[2] >= 0) ? bw * bh : 0;
     const bool agg = area > 0 && area <= AGG_CAP;
     if (agg) {
-        for (int e = (int)tid; e < area; e += 256) sh.table[e] = 0;
-        __syncthreads();
+        if (!PREINIT) {
+            for (int e = (int)tid; e < area; e += 256) sh.table[e] = 0;
+            __syncthreads();
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (small[g])
@@ -225,9 +235,14 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
             for (int g = 0; g < G; ++g)
                 if (small[g])
                     for (int ty = ty0[g]; ty <= ty1[g]; ++ty)
-                        for (int tx = tx0[g]; tx <= tx1[g]; ++tx) {
-                            unsigned int slot = atomicAdd(&sh.table[(ty - by0) * bw + (tx - bx0)], 1u);
-                            put((unsigned int)(ty * tiles_x + tx), slot, key[g]);
+                        for (int tx = tx0[g]; tx <= tx1[g]; tx += 4) {      // four ranks in flight, then four stores
+                            unsigned int slot[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                slot[u] = (tx + u <= tx1[g]) ? atomicAdd(&sh.table[(ty - by0) * bw + (tx + u - bx0)], 1u) : 0u;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (tx + u <= tx1[g]) put((unsigned int)(ty * tiles_x + tx + u), slot[u], key[g]);
                         }
         }
     } else {
@@ -297,6 +312,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
     float F[64];
     float cx = 0, cy = 0, hx = 0, hy = 0, ca = 0, cb = 0, cc = 0, zview = 0;
+    if (BUCKET) bin_preinit(sh);            // published by the barriers of the counts below
     if (i < n) {
         // geometry first: position, opacity, cov3d live in planes 0-3 (64 B); the SH planes are
         // only fetched for Gaussians that reach this context's slab
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         const bool v1[1] = {in_slab};
         const int a1[1] = {tx0}, b1[1] = {tx1}, c1[1] = {ty0}, d1[1] = {ty1};
         const unsigned long long k1[1] = {in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)orig[i]) : 0ull};
-        bin_block<true, 1>(sh, v1, a1, b1, c1, d1, fc.tiles_x, counts, keys, k1, fc.bucket_cap);
+        bin_block<true, 1, true>(sh, v1, a1, b1, c1, d1, fc.tiles_x, counts, keys, k1, fc.bucket_cap);
         return;
     }
     // compact the slots that reach the slab into vislist (K2 runs over those only)
