@@ -194,7 +194,7 @@ def main():
                                    "(lowpass 0.01, sh_dim 15), exact mode" % (args.workload, n, W, H, seed),
                        "camera": "36-pose yaw orbit, 10 degrees per frame" if args.orbit else "fixed pose",
                        "partition": ("load-balanced tile-row slabs %s + RCCL gather" % [b - a for a, b in slabs]) if world > 1 else "single GPU",
-                       "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len), "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback), "wave_iters_scan": int(st.n_iter_scan), "wave_iters_blend": int(st.n_iter_blend)},
+                       "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len), "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback), "wave_iters_scan": int(st.n_iter_scan), "wave_iters_blend": int(st.n_iter_blend), "k1_blocks_culled": int(st.n_blocks_culled)},
             "roofline": {"bound": "hbm", "kernel": "composite_exact_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": per["composite"], "bytes_per_launch": comp_bytes,

@@ -72,6 +72,7 @@ typedef struct {
     uint64_t n_sort_fallback; /* tiles re-sorted by the exact bitonic network because depth ties were out of index order */
     uint64_t n_iter_scan;  /* compositor (wave, record) iterations spent in the front-to-back scan           */
     uint64_t n_iter_blend; /* ... and in exact blending                                                      */
+    uint64_t n_blocks_culled; /* 256-Gaussian blocks K1 skipped: bounds cannot reach the slab / target      */
 } splat_stats;
 
 /* Projected per-Gaussian record as the kernels keep it (debug / stage parity). */

@@ -26,7 +26,8 @@ class Stats(C.Structure):
                 ("n_pairs", C.c_uint64), ("max_tile_len", C.c_uint64), ("bytes_algorithmic", C.c_uint64),
                 ("ms_preprocess", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float),
                 ("ms_sort", C.c_float), ("ms_composite", C.c_float), ("ms_total", C.c_float),
-                ("n_fallback", C.c_uint64), ("n_sort_fallback", C.c_uint64), ("n_iter_scan", C.c_uint64), ("n_iter_blend", C.c_uint64)]
+                ("n_fallback", C.c_uint64), ("n_sort_fallback", C.c_uint64), ("n_iter_scan", C.c_uint64), ("n_iter_blend", C.c_uint64),
+                ("n_blocks_culled", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -59,6 +59,9 @@ struct splat_ctx {
     uint64_t n = 0;
     float4* planes = nullptr;
     unsigned int* orig = nullptr;          // slot -> original Gaussian index (Morton order of position)
+    BlockBounds* bounds = nullptr;         // per K1 block of 256 slots (block culling)
+    unsigned char* culled = nullptr;       // per block: 1 if the last K1 skipped it
+    bool cull_blocks = true;               // SPLAT_CULL=0 disables
     std::vector<unsigned int> h_orig;
     // per-frame buffers
     Slot slots[N_SLOTS];
@@ -146,6 +149,33 @@ void morton_order(uint64_t n, const float* pos4, std::vector<unsigned int>& orde
     std::sort(keyed.begin(), keyed.end());
     order.resize(n);
     for (uint64_t j = 0; j < n; ++j) order[j] = (unsigned int)keyed[j];
+}
+
+// Bounds of every K1 block (256 consecutive slots): AABB of the finite centres, largest ||cov3d||_F.
+void block_bounds(uint64_t n, const float* pos4, const float* cov3d, const std::vector<unsigned int>& order,
+                  std::vector<BlockBounds>& out) {
+    const uint64_t nb = (n + 255) / 256;
+    out.resize(nb);
+    for (uint64_t b = 0; b < nb; ++b) {
+        BlockBounds bb;
+        for (int a = 0; a < 3; ++a) { bb.lo[a] = INFINITY; bb.hi[a] = -INFINITY; }
+        bb.fmax = 0.0f; bb.pad = 0.0f;
+        const uint64_t j1 = std::min<uint64_t>(n, (b + 1) * 256);
+        for (uint64_t j = b * 256; j < j1; ++j) {
+            const uint64_t i = order[j];
+            const float* p = pos4 + 4 * i;
+            if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;   // never visible
+            for (int a = 0; a < 3; ++a) { bb.lo[a] = std::min(bb.lo[a], p[a]); bb.hi[a] = std::max(bb.hi[a], p[a]); }
+            double f2 = 0.0;
+            for (int e = 0; e < 9; ++e) f2 += (double)cov3d[9 * i + e] * (double)cov3d[9 * i + e];
+            float f = (float)std::sqrt(f2) * 1.0001f;
+            if (!(f >= 0.0f)) f = INFINITY;                    // NaN: unbounded extent
+            bb.fmax = std::max(bb.fmax, f);
+        }
+        if (!(bb.lo[0] <= bb.hi[0]))                            // no finite centre at all: NaN bounds answer "maybe"
+            for (int a = 0; a < 3; ++a) { bb.lo[a] = NAN; bb.hi[a] = NAN; }
+        out[b] = bb;
+    }
 }
 
 template <typename T>
@@ -253,6 +283,9 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->zmin = c->cfg.zmin; fc->zmax = c->cfg.zmax;
     fc->early_eps = c->early_eps; fc->early_min = c->early_min; fc->prio_len = c->prio_len;
     fc->bucket_cap = 0;
+    // (a singular cov2d needs lowpass == 0 or a non-PSD cov3d; with lowpass == 0 every Gaussian is
+    // looked at so that n_singular stays what the reference would have panicked on)
+    fc->cull_blocks = (c->cull_blocks && c->bounds && cam->lowpass > 0.0f) ? 1 : 0;
     fc->W = (int)cam->w; fc->H = (int)cam->h;
     fc->tiles_x = (fc->W + TILE - 1) / TILE;
     int tiles_y = (fc->H + TILE - 1) / TILE;
@@ -283,7 +316,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
     }
     HIP_TRY(c, hipEventRecord(ev.e[0], bs));
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), bs));
-    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, s.d_status);
+    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, s.d_status);
     HIP_TRY(c, hipEventRecord(ev.e[1], bs));
     launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, c->cap, c->fc.bucket_cap);
     HIP_TRY(c, hipEventRecord(ev.e[2], bs));
@@ -358,6 +391,12 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->n_sort_fallback = c->last.n_sort_fallback;
     st->n_iter_scan = c->last.n_iter_scan;
     st->n_iter_blend = c->last.n_iter_blend;
+    st->n_blocks_culled = 0;
+    if (c->fc.cull_blocks && c->culled && c->last_ring >= 0) {      // the frame has finished: count its block flags
+        std::vector<unsigned char> f((c->n + 255) / 256);
+        if (hipMemcpy(f.data(), c->culled, f.size(), hipMemcpyDeviceToHost) == hipSuccess)
+            for (unsigned char v : f) st->n_blocks_culled += v;
+    }
     st->bytes_algorithmic = c->n * 148ull + c->last.n_visible * 48ull + c->last.n_pairs * 60ull +
                             (uint64_t)c->fc.W * (uint64_t)(c->fc.row_px1 - c->fc.row_px0) * 4ull;
     float t[N_TIMES] = {0};
@@ -367,7 +406,7 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
 }
 
 void free_scene(splat_ctx* c) {
-    dfree(c->planes); dfree(c->orig);
+    dfree(c->planes); dfree(c->orig); dfree(c->bounds); dfree(c->culled);
     for (Slot& s : c->slots) { dfree(s.recs); dfree(s.depth); dfree(s.rect); dfree(s.vislist); s.used = false; }
     c->n = 0;
     c->h_orig.clear();
@@ -409,6 +448,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
     if (const char* e4 = std::getenv("SPLAT_PIPELINE")) c->pipeline = std::atoi(e4) != 0;
     if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;
+    if (const char* e7 = std::getenv("SPLAT_CULL")) c->cull_blocks = std::atoi(e7) != 0;
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
@@ -501,6 +541,12 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
         UP_TRY(hipMalloc(&s.vislist, sizeof(unsigned int) * n));
     }
     UP_TRY(hipMemcpyAsync(c->orig, c->h_orig.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, c->stream));
+    std::vector<BlockBounds> hb;
+    block_bounds(n, pos4, cov3d, c->h_orig, hb);
+    UP_TRY(hipMalloc(&c->bounds, sizeof(BlockBounds) * hb.size()));
+    UP_TRY(hipMemcpyAsync(c->bounds, hb.data(), sizeof(BlockBounds) * hb.size(), hipMemcpyHostToDevice, c->stream));
+    UP_TRY(hipMalloc(&c->culled, hb.size()));
+    UP_TRY(hipMemsetAsync(c->culled, 0, hb.size(), c->stream));
     UP_TRY(hipMalloc(&d_pos, sizeof(float) * 4 * n));
     UP_TRY(hipMalloc(&d_cov, sizeof(float) * 9 * n));
     UP_TRY(hipMalloc(&d_op, sizeof(float) * n));
@@ -570,7 +616,7 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     Slot& s = c->slots[0];
     fc.bucket_cap = 0;          // count only
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
-    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, s.d_status);
+    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, c->bounds, c->culled, s.d_status);
     launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, ~0ull, 0u);
     HIP_TRY(c, hipGetLastError());
     std::vector<unsigned int> off((size_t)nt + 1);
@@ -658,13 +704,14 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     if (rc != SPLAT_OK) return rc;
     if (c->last_slot < 0) return fail(c, SPLAT_ERR_INVALID, "no frame rendered yet");
     const Slot& s = c->slots[c->last_slot];
-    if (c->fc.bucket_cap) {
-        // one-pass binning keeps depth and rectangle in registers only: recompute them with the
-        // counting flavour of K1 (same code, same values), then clear its counts again
+    {
+        // one-pass binning keeps depth and rectangle in registers only, and block culling skips
+        // whole blocks: recompute every Gaussian with the counting flavour of K1, culling off (same
+        // code, same values), then clear its counts again
         FrameConst fc = c->fc;
-        fc.bucket_cap = 0;
+        fc.bucket_cap = 0; fc.cull_blocks = 0;
         HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
-        launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, s.d_status);
+        launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, nullptr, nullptr, s.d_status);
         HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }

@@ -32,7 +32,12 @@ struct FrameConst {
     int early_min;         // shortest list the early-out is tried on
     int prio_len;          // lists >= prio_len / 2x / 4x run at wave priority 1 / 2 / 3
     unsigned int bucket_cap; // one-pass binning: keys per tile bucket (0: two-pass binning with exact lists)
+    int cull_blocks;       // K1 skips 256-Gaussian blocks whose bounds cannot reach the slab (needs lowpass > 0)
 };
+
+// Upload-time bounds of one K1 block (256 consecutive slots of the Morton-ordered scene): the AABB
+// of the finite positions and the largest Frobenius norm of a cov3d (>= its spectral norm).
+struct BlockBounds { float lo[3], hi[3], fmax, pad; };
 
 // Device-side frame status, read back once per frame.
 struct FrameStatus {
@@ -45,6 +50,7 @@ struct FrameStatus {
     unsigned long long n_sort_fallback; // tiles whose radix-by-depth order failed the 64-bit check (depth ties): bitonic redo
     unsigned long long n_iter_scan;  // compositor (wave, record) iterations: phase A (front-to-back scan)
     unsigned long long n_iter_blend; //                                       phase B (exact blend)
+    unsigned long long n_blocks_culled; // K1 blocks skipped by the bounds test (filled on the host from the block flags)
 };
 
 // 48-byte projected record (3 x float4), gathered by the compositor.
@@ -59,6 +65,7 @@ void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float
 void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d);
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
                        float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
+                       const BlockBounds* bounds, unsigned char* culled /* one flag per block, written when culling */,
                        FrameStatus* status);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,

@@ -184,6 +184,31 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
         else if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
     };
     bool small[G], big[G];
+    // f(tx, ty, key) for every tile of the thread's aggregated rectangle.  A rectangle of up to LANE_T
+    // tiles is walked by its own lane; larger ones (<= AGG_MAX_TILES = one wave) are spread over the
+    // lanes of the wave, one tile each -- otherwise the lane that owns a 60-tile splat keeps its
+    // wave in the loop sixty rounds (measured: the scatter phase of such a block 42 k cycles vs 3 k).
+    constexpr int LANE_T = 9;
+    auto each_tile = [&](int g, auto f) {
+        const unsigned int lane = tid & 63u;
+        const int w = tx1[g] - tx0[g] + 1, nt = small[g] ? w * (ty1[g] - ty0[g] + 1) : 0;
+        if (nt > 0 && nt <= LANE_T)
+            for (int ty = ty0[g]; ty <= ty1[g]; ++ty)
+                for (int tx = tx0[g]; tx <= tx1[g]; ++tx) f(tx, ty, key[g]);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(nt > LANE_T);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const int X0 = __builtin_amdgcn_readlane(tx0[g], src), Y0 = __builtin_amdgcn_readlane(ty0[g], src);
+            const int W = __builtin_amdgcn_readlane(w, src), N = __builtin_amdgcn_readlane(nt, src);
+            const unsigned int klo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)key[g], src);
+            const unsigned int khi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(key[g] >> 32), src);
+            if ((int)lane < N) {
+                const int dy = (int)lane / W, dx = (int)lane - dy * W;
+                f(X0 + dx, Y0 + dy, ((unsigned long long)khi << 32) | klo);
+            }
+        }
+    };
     if (!PREINIT) {
         if (tid == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
         __syncthreads();
@@ -217,9 +242,7 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
         }
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (small[g])
-                for (int ty = ty0[g]; ty <= ty1[g]; ++ty)
-                    for (int tx = tx0[g]; tx <= tx1[g]; ++tx) atomicAdd(&sh.table[(ty - by0) * bw + (tx - bx0)], 1u);
+            each_tile(g, [&](int tx, int ty, unsigned long long) { atomicAdd(&sh.table[(ty - by0) * bw + (tx - bx0)], 1u); });
         __syncthreads();
         for (int e = (int)tid; e < area; e += 256) {
             unsigned int c = sh.table[e];
@@ -233,28 +256,19 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
             __syncthreads();
 #pragma unroll
             for (int g = 0; g < G; ++g)
-                if (small[g])
-                    for (int ty = ty0[g]; ty <= ty1[g]; ++ty)
-                        for (int tx = tx0[g]; tx <= tx1[g]; tx += 4) {      // four ranks in flight, then four stores
-                            unsigned int slot[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                slot[u] = (tx + u <= tx1[g]) ? atomicAdd(&sh.table[(ty - by0) * bw + (tx + u - bx0)], 1u) : 0u;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (tx + u <= tx1[g]) put((unsigned int)(ty * tiles_x + tx + u), slot[u], key[g]);
-                        }
+                each_tile(g, [&](int tx, int ty, unsigned long long k) {
+                    const unsigned int slot = atomicAdd(&sh.table[(ty - by0) * bw + (tx - bx0)], 1u);
+                    put((unsigned int)(ty * tiles_x + tx), slot, k);
+                });
         }
     } else {
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (small[g])   // bounding box larger than the table (incoherent block): direct
-                for (int ty = ty0[g]; ty <= ty1[g]; ++ty)
-                    for (int tx = tx0[g]; tx <= tx1[g]; ++tx) {
-                        const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
-                        unsigned int slot = atomicAdd(&gcount[tile], 1u);
-                        if (EMIT) put(tile, slot, key[g]);
-                    }
+        for (int g = 0; g < G; ++g)     // bounding box larger than the table (incoherent block): direct
+            each_tile(g, [&](int tx, int ty, unsigned long long k) {
+                const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
+                unsigned int slot = atomicAdd(&gcount[tile], 1u);
+                if (EMIT) put(tile, slot, k);
+            });
     }
     // close-ups: every thread takes tiles of each big rectangle (in rounds of BIG_CAP)
 #pragma unroll
@@ -289,6 +303,50 @@ __device__ __forceinline__ unsigned int depth_key(float z) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Can ANY Gaussian of a block land on this context's slab?  Conservative test on the block's
+// upload-time bounds: every Gaussian centre lies in the AABB, so its clip coordinates lie in the
+// convex hull of the eight projected corners (while w keeps its sign), and its 3-sigma half
+// extents obey h <= 3 sqrt((focal/z)^2 |v|^2 ||cov3d||_F + lowpass), v the view-matrix row.
+// Anything that cannot be bounded (w or view z changing sign inside the box, non-finite bounds)
+// answers "maybe".  Margins: 1 px + 0.1 % on screen, 1e-4 on NDC z.  Lanes 0-7 of each wave take one
+// corner each; the result is wave-uniform and identical in the block's four waves.
+__device__ __forceinline__ bool block_may_reach_slab(const BlockBounds& bb, const FrameConst& fc) {
+    const unsigned int lane = threadIdx.x & 63u;
+    const float px = (lane & 1u) ? bb.hi[0] : bb.lo[0], py = (lane & 2u) ? bb.hi[1] : bb.lo[1], pz = (lane & 4u) ? bb.hi[2] : bb.lo[2];
+    float pc[4], q[4];
+    mat4_vec(fc.view, px, py, pz, 1.0f, pc);
+    mat4_vec(fc.proj, pc[0], pc[1], pc[2], pc[3], q);
+    const float sx = (q[0] / q[3] * 0.5f + 0.5f) * fc.w;
+    const float sy = fc.y_up ? (q[1] / q[3] * -0.5f + 0.5f) * fc.h : (q[1] / q[3] * 0.5f + 0.5f) * fc.h;
+    const float sz = q[2] / q[3];
+    float lo[5] = {sx, sy, sz, q[3], pc[2]}, hi[5] = {sx, sy, sz, q[3], pc[2]};
+    bool finite = finitef(sx) && finitef(sy) && finitef(sz) && finitef(q[3]) && finitef(pc[2]);
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], o));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o));
+        }
+        finite = finite & (__shfl_xor((int)finite, o) != 0);
+    }
+    if (!finite) return true;
+    if (!(lo[3] > 0.0f || hi[3] < 0.0f) || !(lo[4] > 0.0f || hi[4] < 0.0f)) return true;   // w or view z crosses zero
+    const float wabs = fminf(fabsf(lo[3]), fabsf(hi[3])), wmax = fmaxf(fabsf(lo[3]), fabsf(hi[3]));
+    if (!(wabs > 1e-3f * wmax)) return true;                                               // projection too steep to trust
+    const float zabs = fminf(fabsf(lo[4]), fabsf(hi[4]));
+    const float nx = fc.view[0] * fc.view[0] + fc.view[4] * fc.view[4] + fc.view[8] * fc.view[8];
+    const float ny = fc.view[1] * fc.view[1] + fc.view[5] * fc.view[5] + fc.view[9] * fc.view[9];
+    const float fz = fc.focal / zabs, s = fz * fz * bb.fmax;
+    const float hx = 3.0f * sqrtf(s * nx + fc.lowpass) * 1.001f + 1.0f, hy = 3.0f * sqrtf(s * ny + fc.lowpass) * 1.001f + 1.0f;
+    auto pad = [](float v) { return 1e-3f * fabsf(v); };
+    // written so that a NaN anywhere falls through to "maybe"
+    if (hi[0] + hx + pad(hi[0]) < 0.0f || lo[0] - hx - pad(lo[0]) > fc.w) return false;
+    if (hi[1] + hy + pad(hi[1]) < (float)fc.row_px0 || lo[1] - hy - pad(lo[1]) > (float)fc.row_px1) return false;
+    if (fc.zclip && (hi[2] + 1e-4f + pad(hi[2]) * 0.1f < fc.zmin || lo[2] - 1e-4f - pad(lo[2]) * 0.1f > fc.zmax)) return false;
+    return true;
+}
+
 // K1 -- one thread per Gaussian (slot j of the Morton-ordered scene, original index orig[j]): the
 // whole vertex stage, a 48-B record, the exactly covered pixel rectangle, and per-tile counts.
 // BUCKET = false (two-pass binning): counts only; depth/rect/vislist feed K2, which emits the keys
@@ -303,10 +361,20 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                                          ushort4* __restrict__ rect, unsigned int* __restrict__ counts,
                                                          unsigned int* __restrict__ vislist,
                                                          unsigned long long* __restrict__ keys,
+                                                         const BlockBounds* __restrict__ bounds,
+                                                         unsigned char* __restrict__ culled,
                                                          FrameStatus* __restrict__ status) {
     __shared__ BinShared sh;
     __shared__ unsigned int swave[4];
     __shared__ unsigned int sbase;
+    // whole block off this context's slab / target: nothing to read, count or emit
+    // (the flag is a plain store: thousands of culled blocks retire within microseconds, and that
+    // many atomics on one counter took longer than the blocks they counted)
+    if (fc.cull_blocks) {
+        const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
+        if (threadIdx.x == 0) culled[blockIdx.x] = reach ? 0 : 1;
+        if (!reach) return;
+    }
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool singular = false, in_slab = false;
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
@@ -1036,7 +1104,10 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         const float pmax = -0.5f * qmin;
         return !(pmax + 1e-3f * (1.0f + fabsf(pmax)) < r.c.w);
     };
-    auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base, bool only_contributing) -> unsigned int {
+    // scan_layout: the phase-A walk only estimates transmittance, so its records are staged in a
+    // form that makes the estimate cheap -- the conic pre-multiplied by -log2(e)/2 and log2(opacity),
+    // so that alpha ~ exp2(a' dx^2 + b' dx dy + c' dy^2 + l2o) is six VALU and one v_exp.
+    auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base, bool only_contributing, bool scan_layout = false) -> unsigned int {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier LDS reads of this wave are done
         __builtin_amdgcn_wave_barrier();
         bool ov = false;
@@ -1047,8 +1118,14 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         const unsigned long long m = __builtin_amdgcn_ballot_w64(ov);
         if (ov) {
             const unsigned int slot = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            L.a[slot] = r.a; L.b[slot] = r.b;
-            L.c[slot] = make_float4(r.c.x, r.c.y, r.c.z, __uint_as_float(base + lane));   // .w: list position
+            if (scan_layout) {
+                const float L2E = 1.4426950408889634f;
+                L.a[slot] = make_float4(r.a.x, r.a.y, __uint_as_float(base + lane), 0.0f);
+                L.b[slot] = make_float4(-0.5f * L2E * r.b.x, -L2E * r.b.y, -0.5f * L2E * r.b.z, __log2f(r.b.w));
+            } else {
+                L.a[slot] = r.a; L.b[slot] = r.b;
+                L.c[slot] = make_float4(r.c.x, r.c.y, r.c.z, __uint_as_float(base + lane));   // .w: list position
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1106,15 +1183,19 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         fetch(bsN, cntN, r);
         while (true) {
             const unsigned int bs = bsN, cnt = cntN;
-            const unsigned int k = stage(r, cnt, bs, true);
+            const unsigned int k = stage(r, cnt, bs, true, true);
             if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }   // prefetch farther batch
             for (unsigned int j = k; j-- > 0;) {                  // nearest first
-                const float4 a = L.a[j], b = L.b[j], c = L.c[j];
-                bool cov;
-                const float alpha = frag_alpha(a, b, [](float x) { return __expf(x); }, cov);   // approximate is enough
-                T *= (1.0f - alpha);
+                const float4 a = L.a[j], b = L.b[j];
+                // an estimate is enough here (too shallow a start costs a retry, never exactness):
+                // no 3-sigma rectangle, no power > 0 case, v_exp instead of expf
+                const float dx = sxm - a.x, dy = a.y - sym;
+                const float p2 = fmaf(dx, fmaf(b.x, dx, b.y * dy), (b.z * dy) * dy) + b.w;
+                float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(p2));
+                alpha = (p2 < -7.994353f) ? 0.0f : alpha;          // log2(1/255)
+                T = fmaf(-alpha, T, T);
                 const bool now = !done & (T < fc.early_eps);
-                sp = now ? __float_as_uint(c.w) : sp;
+                sp = now ? __float_as_uint(a.z) : sp;
                 done = done | now;
             }
             itA += k;
@@ -1216,14 +1297,15 @@ void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* 
 }
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
                        float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
-                       FrameStatus* status) {
+                       const BlockBounds* bounds, unsigned char* culled, FrameStatus* status) {
     if (!n) return;
+    if (!bounds || !culled) fc.cull_blocks = 0;
     if (fc.bucket_cap)
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth,
-                           rect, counts, vislist, keys, status);
+                           rect, counts, vislist, keys, bounds, culled, status);
     else
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth,
-                           rect, counts, vislist, keys, status);
+                           rect, counts, vislist, keys, bounds, culled, status);
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,

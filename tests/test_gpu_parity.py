@@ -299,6 +299,47 @@ def test_bucket_overflow_falls_back_to_two_pass():
         r.close()
 
 
+def test_block_culling_never_changes_a_frame():
+    """K1 skips 256-Gaussian blocks whose upload-time bounds cannot reach the slab / target.  The test is
+    conservative by construction; check it: culling on == culling off (frame, visible count, pair
+    count) for cameras outside, inside and looking away from the cloud, full frame and thin slabs."""
+    import os
+    g = splat_amd.synthetic_scene(50000, 77)
+    g.positions[:25000, :3] *= 0.3                  # a dense core plus a wide halo
+    poses = [((0, 0, 5), 0.0, 0.0), ((0, 0, 0.5), 0.3, 0.1), ((2.0, 1.0, 0.2), 2.5, -0.4), ((0, 0, 5), 3.14159, 0.0),
+             ((6.0, 0.0, 0.0), 1.2, 0.9)]
+    saved = os.environ.get("SPLAT_CULL")
+    res = {}
+    try:
+        for cull in ("1", "0"):
+            os.environ["SPLAT_CULL"] = cull
+            r = splat_amd.Renderer()
+            try:
+                if not g.cov3d.any():
+                    g.compute_cov3d(r)
+                r.upload(g)
+                out = []
+                for pos, yaw, pitch in poses:
+                    cam = make_camera(208, 304, pos=pos, yaw=yaw, pitch=pitch)
+                    for slab in ((0, -1), (0, 2), (5, 7), (12, 13)):
+                        r.set_slab(*slab)
+                        img = np.zeros((208, 304), np.uint32)
+                        st = r.render(cam.to_c(0.3), img)
+                        out.append((img, st.n_visible, st.n_pairs, st.max_tile_len, st.n_blocks_culled))
+                res[cull] = out
+            finally:
+                r.close()
+    finally:
+        os.environ.pop("SPLAT_CULL", None)
+        if saved is not None:
+            os.environ["SPLAT_CULL"] = saved
+    assert len(res["1"]) == len(res["0"])
+    for k, (a, b) in enumerate(zip(res["1"], res["0"])):
+        assert a[1:4] == b[1:4], (k, a[1:], b[1:])
+        assert np.array_equal(a[0], b[0]), k
+    assert all(o[4] == 0 for o in res["0"]) and sum(o[4] > 0 for o in res["1"]) > len(res["1"]) // 2, [o[4] for o in res["1"]]
+
+
 def test_slabs_equal_full_frame(R):
     """multi-GPU decomposition: tile-row slabs rendered separately == the full frame, byte for byte"""
     g = gpu_scene(R, 30000, 19)

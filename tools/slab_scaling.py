@@ -54,4 +54,6 @@ for s in (slabs[0], slabs[3]):
         img.zero_()
         R.render_device(cam_c, img.data_ptr())
     ms, frames = R.timing(reset=True)
-    print("slab", s, {k: round(v / frames, 4) for k, v in ms.items()})
+    st = R.render_device(cam_c, img.data_ptr(), sync=True, want_stats=True)
+    print("slab", s, {k: round(v / frames, 4) for k, v in ms.items()},
+          "K1 blocks culled %d of %d, visible %d, pairs %d" % (st.n_blocks_culled, (n + 255) // 256, st.n_visible, st.n_pairs))
