@@ -158,6 +158,7 @@ struct BinShared {
     unsigned int table[AGG_CAP];
     int box[4];                        // min tx, min ty, max tx, max ty of the aggregated Gaussians
     unsigned int nbig;
+    unsigned int nvis, nsing;          // block totals for the frame statistics (bin_bucket)
     int big[BIG_CAP][4];               // tile rects of the block's big Gaussians
     unsigned long long bigkey[BIG_CAP];
 };
@@ -168,7 +169,7 @@ struct BinShared {
 // (K1 does it before its long vertex stage, which saves two barriers here).
 __device__ __forceinline__ void bin_preinit(BinShared& sh) {
     for (int e = (int)threadIdx.x; e < AGG_CAP; e += 256) sh.table[e] = 0;
-    if (threadIdx.x == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
+    if (threadIdx.x == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; sh.nvis = 0; sh.nsing = 0; }
 }
 template <bool EMIT, int G, bool PREINIT = false>
 __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], const int (&tx0)[G], const int (&tx1)[G],
@@ -297,6 +298,110 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
     }
 }
 
+// One-pass binning for K1<BUCKET>: the same aggregation as bin_block<EMIT>, reorganised to need
+// three barriers instead of six (a K1 block is latency bound: every barrier also waits for the
+// slowest of its four waves).  The LDS table is addressed by a hash of the tile coordinates,
+//     slot(tx, ty) = (ty & 63) * 64 + ((tx + 17 ty) & 63),
+// which is collision-free whenever the block's tile bounding box is at most 64 x 64 -- so counting can
+// start before the bounding box is known; the box (LDS atomics, no barrier of its own) is only
+// needed afterwards, to validate the hash and to turn slots back into tiles.  A block that fails the
+// validation (incoherent: its Gaussians are spread over more than 64 tiles in x or y) places its
+// pairs with one global atomic each.  Block statistics ride on the same barriers.
+// The caller has run bin_preinit() and a barrier.
+__device__ __forceinline__ void bin_bucket(BinShared& sh, bool vis, bool singular, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                           unsigned int* __restrict__ gcount, unsigned long long* __restrict__ keys,
+                                           unsigned long long key, unsigned int bcap, FrameStatus* __restrict__ status) {
+    const unsigned int tid = threadIdx.x, lane = tid & 63u;
+    auto put = [&](unsigned int tile, unsigned int slot, unsigned long long k) {
+        if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
+    };
+    auto hslot = [](int tx, int ty) -> unsigned int { return (unsigned int)(((ty & 63) << 6) | ((tx + 17 * ty) & 63)); };
+    const int w = tx1 - tx0 + 1, ntiles = vis ? w * (ty1 - ty0 + 1) : 0;
+    const bool small = vis && ntiles <= AGG_MAX_TILES, big = vis && !small;
+    constexpr int LANE_T = 9;
+    auto each_tile = [&](auto f) {          // see bin_block
+        if (small && ntiles <= LANE_T)
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) f(tx, ty, key);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(small && ntiles > LANE_T);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const int X0 = __builtin_amdgcn_readlane(tx0, src), Y0 = __builtin_amdgcn_readlane(ty0, src);
+            const int W = __builtin_amdgcn_readlane(w, src), N = __builtin_amdgcn_readlane(ntiles, src);
+            const unsigned int klo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)key, src);
+            const unsigned int khi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(key >> 32), src);
+            if ((int)lane < N) {
+                const int dy = (int)lane / W, dx = (int)lane - dy * W;
+                f(X0 + dx, Y0 + dy, ((unsigned long long)khi << 32) | klo);
+            }
+        }
+    };
+    {   // block statistics and bounding box of the aggregated rectangles: wave reduce, LDS atomics by lane 0
+        const unsigned int nv = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vis));
+        const unsigned int ns = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(singular));
+        int a = small ? tx0 : 0x7fffffff, b = small ? ty0 : 0x7fffffff, c = small ? tx1 : -1, d = small ? ty1 : -1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a = min(a, __shfl_xor(a, o)); b = min(b, __shfl_xor(b, o));
+            c = max(c, __shfl_xor(c, o)); d = max(d, __shfl_xor(d, o));
+        }
+        if (lane == 0) {
+            if (nv) atomicAdd(&sh.nvis, nv);
+            if (ns) atomicAdd(&sh.nsing, ns);
+            if (c >= 0) { atomicMin(&sh.box[0], a); atomicMin(&sh.box[1], b); atomicMax(&sh.box[2], c); atomicMax(&sh.box[3], d); }
+        }
+    }
+    each_tile([&](int tx, int ty, unsigned long long) { atomicAdd(&sh.table[hslot(tx, ty)], 1u); });
+    __syncthreads();
+    const int bx0 = sh.box[0], by0 = sh.box[1];
+    const bool any = sh.box[2] >= 0;
+    const bool hashed = any && (sh.box[2] - bx0) < 64 && (sh.box[3] - by0) < 64;
+    if (tid == 0) {
+        if (sh.nvis) atomicAdd(&status->n_visible, (unsigned long long)sh.nvis);
+        if (sh.nsing) atomicAdd(&status->n_singular, (unsigned long long)sh.nsing);
+    }
+    if (hashed) {
+        // reserve every touched tile's run in its bucket: one returning global atomic per (block, tile)
+        for (int e = (int)tid; e < AGG_CAP; e += 256) {
+            const unsigned int c = sh.table[e];
+            if (c) {
+                const int ty = by0 + (((e >> 6) - by0) & 63);
+                const int tx = bx0 + (((e & 63) - 17 * ty - bx0) & 63);
+                sh.table[e] = atomicAdd(&gcount[(unsigned int)(ty * tiles_x + tx)], c);
+            }
+        }
+        __syncthreads();
+        each_tile([&](int tx, int ty, unsigned long long k) {
+            const unsigned int slot = atomicAdd(&sh.table[hslot(tx, ty)], 1u);
+            put((unsigned int)(ty * tiles_x + tx), slot, k);
+        });
+    } else if (any) {
+        each_tile([&](int tx, int ty, unsigned long long k) {
+            const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
+            put(tile, atomicAdd(&gcount[tile], 1u), k);
+        });
+    }
+    // close-ups (more than AGG_MAX_TILES tiles): the whole block takes the tiles of each, one per thread
+    if (__syncthreads_or(big ? 1 : 0) == 0) return;
+    if (big) {
+        unsigned int k = atomicAdd(&sh.nbig, 1u);
+        sh.big[k][0] = tx0; sh.big[k][1] = tx1; sh.big[k][2] = ty0; sh.big[k][3] = ty1;
+        sh.bigkey[k] = key;
+    }
+    __syncthreads();
+    const unsigned int nbig = sh.nbig;
+    for (unsigned int k = 0; k < nbig; ++k) {
+        const int X0 = sh.big[k][0], X1 = sh.big[k][1], Y0 = sh.big[k][2], Y1 = sh.big[k][3];
+        const int bw = X1 - X0 + 1, cnt = bw * (Y1 - Y0 + 1);
+        const unsigned long long kk = sh.bigkey[k];
+        for (int e = (int)tid; e < cnt; e += 256) {
+            const unsigned int tile = (unsigned int)((Y0 + e / bw) * tiles_x + X0 + e % bw);
+            put(tile, atomicAdd(&gcount[tile], 1u), kk);
+        }
+    }
+}
+
 // order-preserving u32 of an f32 (ascending z == far first in a right-handed view)
 __device__ __forceinline__ unsigned int depth_key(float z) {
     unsigned int u = __float_as_uint(z);
@@ -380,7 +485,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
     float F[64];
     float cx = 0, cy = 0, hx = 0, hy = 0, ca = 0, cb = 0, cc = 0, zview = 0;
-    if (BUCKET) bin_preinit(sh);            // published by the barriers of the counts below
+    if (BUCKET) { bin_preinit(sh); __syncthreads(); }   // (all four waves are here at once: a cheap barrier)
     if (i < n) {
         // geometry first: position, opacity, cov3d live in planes 0-3 (64 B); the SH planes are
         // only fetched for Gaussians that reach this context's slab
@@ -509,15 +614,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         recs[orig[i]] = r;
     }
     if (BUCKET) {
-        const int nvis = __syncthreads_count(in_slab), nsing = __syncthreads_count(singular);
-        if (threadIdx.x == 0) {
-            if (nvis) atomicAdd(&status->n_visible, (unsigned long long)nvis);
-            if (nsing) atomicAdd(&status->n_singular, (unsigned long long)nsing);
-        }
-        const bool v1[1] = {in_slab};
-        const int a1[1] = {tx0}, b1[1] = {tx1}, c1[1] = {ty0}, d1[1] = {ty1};
-        const unsigned long long k1[1] = {in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)orig[i]) : 0ull};
-        bin_block<true, 1, true>(sh, v1, a1, b1, c1, d1, fc.tiles_x, counts, keys, k1, fc.bucket_cap);
+        const unsigned long long key = in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)orig[i]) : 0ull;
+        bin_bucket(sh, in_slab, singular, tx0, tx1, ty0, ty1, fc.tiles_x, counts, keys, key, fc.bucket_cap, status);
         return;
     }
     // compact the slots that reach the slab into vislist (K2 runs over those only)
