@@ -178,11 +178,14 @@ def main():
         slab_px = (sdist.slab_pixel_rows(slabs[0], H)[1] - sdist.slab_pixel_rows(slabs[0], H)[0]) * W
         comp_bytes = st.n_pairs * 48 + slab_px * 4
         achieved = comp_bytes / (per["composite"] * 1e-3) / 1e9 if per["composite"] > 0 else 0.0
-        traffic = None
+        traffic, valu_util, prof_src = None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(args.workload, {}).get("composite_exact_kernel")
+                tj = json.load(open(tp))
+                traffic = tj.get(args.workload, {}).get("composite_exact_kernel")
+                valu_util = tj.get(args.workload, {}).get("composite_exact_kernel:detail", {}).get("valu_issue_util")
+                prof_src = tj.get(args.workload + ":source")
             except Exception:
                 traffic = None
         out = {
@@ -198,7 +201,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "composite_exact_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": per["composite"], "bytes_per_launch": comp_bytes,
-                         "note": "compositor is VALU/exp bound, not HBM bound (DESIGN.md)"},
+                         "valu_issue_util": valu_util, "counters_from": ("profiles/%s_pmc_*.csv" % prof_src) if prof_src else None,
+                         "note": "the compositor is bound by VALU issue, not by HBM: valu_issue_util = wave64 VALU "
+                                 "instructions x 2 cycles / (1024 SIMDs x launch cycles), from the committed SQ counter pass"},
             "roofline_frame": {"bytes_algorithmic": int(st.bytes_algorithmic), "t_gpu_ms": t_gpu,
                                "achieved": st.bytes_algorithmic / (t_gpu * 1e-3) / 1e9 if t_gpu > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the profiles a round commits under profiles/: kernel-trace stats, three separate PMC passes
+# (never combined with trace domains), the bench line.  Run on the GPU box from the repo root:
+#   bash tools/profile_round.sh r02a
+# Everything is wrapped in `timeout`: a rocprofv3 that hangs at exit must not eat the box.
+tag=${1:-rXX}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+B="python bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+P="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B > $out/trace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-include-regex splat --output-format csv -d $out/pmc_$c -- $P > $out/pmc_$c.log 2>&1
+done
+timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES \
+  --kernel-include-regex splat --output-format csv -d $out/pmc_SQ -- $P > $out/pmc_SQ.log 2>&1
+timeout 300 python bench.py > $out/bench.json 2> $out/bench.err
+find $out -name "*.csv" | head -40
+tail -c 600 $out/bench.json
