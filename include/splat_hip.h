@@ -34,6 +34,10 @@ extern "C" {
 
 /* composite modes */
 #define SPLAT_MODE_EXACT 0       /* back-to-front, 8-bit truncation per splat: bit-faithful to blend() */
+#define SPLAT_MODE_CORRECTED_PROJECTION 1 /* same compositing, but cov2d = J W S W^T J^T with the perspective-shear
+                                    terms of J (3DGS paper) that the reference drops (its Matrix3::new is
+                                    row-major, src/gaussians.rs:141-151).  NOT parity with the reference:
+                                    SURVEY section 8(f) rank 2, off by default.                                  */
 
 typedef struct splat_ctx splat_ctx;
 

@@ -16,7 +16,7 @@ _LIB = None
 
 class Conventions(C.Structure):
     _fields_ = [("y_up", C.c_int32), ("sample_half", C.c_int32), ("zclip", C.c_int32),
-                ("zmin", C.c_float), ("zmax", C.c_float), ("raster", C.c_int32)]
+                ("zmin", C.c_float), ("zmax", C.c_float), ("raster", C.c_int32), ("corrected_projection", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -64,6 +64,7 @@ def lib():
         L.orc_compute_cov3d.argtypes = [C.c_uint64, fp, fp, fp]
         L.orc_eval_sh.argtypes = [fp, C.c_int32, fp, fp]
         L.orc_project_cov2d.argtypes = [fp, fp, C.POINTER(Camera), fp]
+        L.orc_project_cov2d_corrected.argtypes = [fp, fp, C.POINTER(Camera), fp]
         L.orc_sort.argtypes = [C.c_uint64, fp, fp, C.POINTER(C.c_uint32)]
         L.orc_preprocess.argtypes = [C.c_uint64, fp, fp, fp, fp, C.POINTER(Camera), C.POINTER(Conventions),
                                      C.c_void_p]
@@ -117,11 +118,11 @@ def eval_sh(sh48, sh_dim, d):
     return out
 
 
-def project_cov2d(pos, cov3d, cam):
+def project_cov2d(pos, cov3d, cam, corrected=False):
     pos = np.ascontiguousarray(pos, np.float32)
     cov3d = np.ascontiguousarray(cov3d, np.float32)
     out = np.zeros(4, np.float32)
-    lib().orc_project_cov2d(_fp(pos), _fp(cov3d), C.byref(cam), _fp(out))
+    (lib().orc_project_cov2d_corrected if corrected else lib().orc_project_cov2d)(_fp(pos), _fp(cov3d), C.byref(cam), _fp(out))
     return out.reshape(2, 2).T  # column-major -> [r][c]
 
 

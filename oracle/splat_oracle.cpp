@@ -137,7 +137,11 @@ void cov3d_one(const float* s, const float* q, float* out9) {
 }
 
 // src/gaussians.rs:114-161 (lowpass .01) / :473-522 (lowpass .3)
-void project_cov2d(const float* pos, const float* cov3d9, const orc_camera* cam, float out[4], float* depth_out) {
+// corrected != 0: NOT the reference -- the EWA Jacobian the way the 3DGS paper has it (J enters
+// transposed, so the perspective-shear terms -f*tx/tz^2, -f*ty/tz^2 reach the 2x2 block instead of
+// the discarded third column: quirk Q9 / SURVEY section 8(f) rank 2).  Same products, same order.
+void project_cov2d(const float* pos, const float* cov3d9, const orc_camera* cam, float out[4], float* depth_out,
+                   int corrected = 0) {
     float pw[4] = {pos[0], pos[1], pos[2], 1.0f}, pc[4];
     mul4(cam->view, pw, pc);
     if (depth_out) *depth_out = pc[2];
@@ -154,7 +158,7 @@ void project_cov2d(const float* pos, const float* cov3d9, const orc_camera* cam,
     M3 V3x3;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) V3x3.at(r, c) = cam->view[c * 4 + r];
     M3 W = transpose(V3x3);
-    M3 T = mul(W, J);
+    M3 T = corrected ? mul(W, transpose(J)) : mul(W, J);
     M3 S; std::memcpy(S.m, cov3d9, sizeof S.m);
     M3 cov = mul(mul(transpose(T), transpose(S)), T);
     out[0] = cov.at(0, 0) + cam->lowpass;       // column-major 2x2: (0,0),(1,0),(0,1),(1,1)
@@ -186,7 +190,7 @@ void preprocess_one(const float* pos4, const float* cov3d9, float opacity, const
     V3 col = eval_sh(sh48, cam->sh_dim, dir);                   // :100
     r->rgb[0] = col.x; r->rgb[1] = col.y; r->rgb[2] = col.z;
     r->opacity = opacity;
-    project_cov2d(pos4, cov3d9, cam, r->cov2d, &r->depth);      // :102
+    project_cov2d(pos4, cov3d9, cam, r->cov2d, &r->depth, conv->corrected_projection);      // :102
     // try_inverse of a 2x2 (nalgebra linalg/inverse.rs): det = m11*m22 - m21*m12
     float m11 = r->cov2d[0], m21 = r->cov2d[1], m12 = r->cov2d[2], m22 = r->cov2d[3];
     float det = m11 * m22 - m21 * m12;
@@ -248,6 +252,7 @@ extern "C" {
 
 void orc_default_conventions(orc_conventions* c) {
     c->y_up = 1; c->sample_half = 1; c->zclip = 1; c->zmin = 0.0f; c->zmax = 1.0f; c->raster = 0;
+    c->corrected_projection = 0;
 }
 
 // src/camera.rs:22-39 (new) + :41-68 (compute_matrices) + :84-89 (htanfovxy_focal)
@@ -322,6 +327,9 @@ void orc_eval_sh(const float* sh48, int32_t sh_dim, const float dir[3], float ou
 
 void orc_project_cov2d(const float pos[3], const float cov3d[9], const orc_camera* cam, float out[4]) {
     project_cov2d(pos, cov3d, cam, out, nullptr);
+}
+void orc_project_cov2d_corrected(const float pos[3], const float cov3d[9], const orc_camera* cam, float out[4]) {
+    project_cov2d(pos, cov3d, cam, out, nullptr, 1);
 }
 
 // src/gaussians.rs:297-306: z = (view * positions)[2]; indices.sort_by(partial_cmp, NaN => Equal) -- stable

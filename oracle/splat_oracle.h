@@ -44,6 +44,9 @@ typedef struct {
                                  by both), coordxy interpolated from the corner values.  It is what
                                  a triangle rasteriser does in general, NOT a transcription of euc
                                  (absent); it measures how far euc-internal rounding can move pixels. */
+    int32_t corrected_projection; /* 0 (default): the reference's cov2d (no perspective-shear term, quirk Q9).
+                              1: NOT the reference -- J enters transposed, as in the 3DGS paper; the
+                                 counterpart of splat_config.mode = SPLAT_MODE_CORRECTED_PROJECTION. */
 } orc_conventions;
 
 /* Per-frame camera constants, i.e. what Camera's getters return
@@ -96,6 +99,7 @@ void orc_compute_cov3d(uint64_t n, const float* scales3, const float* rot4, floa
 void orc_eval_sh(const float* sh48, int32_t sh_dim, const float dir[3], float out[3]);
 /* project_cov3d_to_screen :114-161 / :473-522; out = 2x2 column-major. */
 void orc_project_cov2d(const float pos[3], const float cov3d[9], const orc_camera* cam, float out[4]);
+void orc_project_cov2d_corrected(const float pos[3], const float cov3d[9], const orc_camera* cam, float out[4]);
 /* stable ascending view-z argsort :297-306 / :464-471. */
 void orc_sort(uint64_t n, const float* pos4, const float view[16], uint32_t* order_out);
 /* full vertex stage for every Gaussian. */

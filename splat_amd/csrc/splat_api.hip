@@ -283,6 +283,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->zmin = c->cfg.zmin; fc->zmax = c->cfg.zmax;
     fc->early_eps = c->early_eps; fc->early_min = c->early_min; fc->prio_len = c->prio_len;
     fc->bucket_cap = 0;
+    fc->corrected = (c->cfg.mode == SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
     // (a singular cov2d needs lowpass == 0 or a non-PSD cov3d; with lowpass == 0 every Gaussian is
     // looked at so that n_singular stays what the reference would have panicked on)
     fc->cull_blocks = (c->cull_blocks && c->bounds && cam->lowpass > 0.0f) ? 1 : 0;
@@ -434,7 +435,8 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     splat_config def;
     splat_default_config(&def);
     if (!cfg) cfg = &def;
-    if (cfg->mode != SPLAT_MODE_EXACT) return fail(nullptr, SPLAT_ERR_INVALID, "unknown mode");
+    if (cfg->mode != SPLAT_MODE_EXACT && cfg->mode != SPLAT_MODE_CORRECTED_PROJECTION)
+        return fail(nullptr, SPLAT_ERR_INVALID, "unknown mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

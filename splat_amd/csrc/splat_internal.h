@@ -32,6 +32,7 @@ struct FrameConst {
     int early_min;         // shortest list the early-out is tried on
     int prio_len;          // lists >= prio_len / 2x / 4x run at wave priority 1 / 2 / 3
     unsigned int bucket_cap; // one-pass binning: keys per tile bucket (0: two-pass binning with exact lists)
+    int corrected;         // SPLAT_MODE_CORRECTED_PROJECTION: J enters transposed (perspective-shear terms kept)
     int cull_blocks;       // K1 skips 256-Gaussian blocks whose bounds cannot reach the slab (needs lowpass > 0)
 };
 

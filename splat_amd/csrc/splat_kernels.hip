@@ -440,8 +440,14 @@ __device__ __forceinline__ bool block_may_reach_slab(const BlockBounds& bb, cons
     const float wabs = fminf(fabsf(lo[3]), fabsf(hi[3])), wmax = fmaxf(fabsf(lo[3]), fabsf(hi[3]));
     if (!(wabs > 1e-3f * wmax)) return true;                                               // projection too steep to trust
     const float zabs = fminf(fabsf(lo[4]), fabsf(hi[4]));
-    const float nx = fc.view[0] * fc.view[0] + fc.view[4] * fc.view[4] + fc.view[8] * fc.view[8];
-    const float ny = fc.view[1] * fc.view[1] + fc.view[5] * fc.view[5] + fc.view[9] * fc.view[9];
+    float nx = fc.view[0] * fc.view[0] + fc.view[4] * fc.view[4] + fc.view[8] * fc.view[8];
+    float ny = fc.view[1] * fc.view[1] + fc.view[5] * fc.view[5] + fc.view[9] * fc.view[9];
+    if (fc.corrected) {
+        // the Jacobian row is (f/z)(1, 0, -tx/z) with |tx/z| <= 1.3 htan: |row V|^2 <= |row|^2 ||V||_F^2
+        const float nz = fc.view[2] * fc.view[2] + fc.view[6] * fc.view[6] + fc.view[10] * fc.view[10];
+        const float ht = fmaxf(fc.htanx, fc.htany);
+        nx = ny = (nx + ny + nz) * (1.0f + 1.69f * ht * ht);
+    }
     const float fz = fc.focal / zabs, s = fz * fz * bb.fmax;
     const float hx = 3.0f * sqrtf(s * nx + fc.lowpass) * 1.001f + 1.0f, hy = 3.0f * sqrtf(s * ny + fc.lowpass) * 1.001f + 1.0f;
     auto pad = [](float v) { return 1e-3f * fabsf(v); };
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) M3(Wm, r, c) = fc.view[r * 4 + c];
-        Mat3 T = mat3_mul(Wm, J);
+        Mat3 T = fc.corrected ? mat3_mul(Wm, mat3_t(J)) : mat3_mul(Wm, J);   // corrected: the shear column reaches the 2x2 block
         Mat3 Sg;
 #pragma unroll
         for (int e = 0; e < 9; ++e) Sg.m[e] = F[4 + e];

@@ -172,6 +172,33 @@ def test_convention_switches(conv):
         r.close()
 
 
+def test_corrected_projection_mode_matches_the_oracle_flag():
+    """SPLAT_MODE_CORRECTED_PROJECTION (section 8(f) rank 2, off by default): K1 and the oracle apply the same
+    products in the same order, so records stay bit-identical and the frame within 1 LSB; and the mode
+    does change the picture (it is not the reference)."""
+    g = splat_amd.synthetic_scene(30000, 23)
+    cam = make_camera(208, 304, pos=(0.4, -0.3, 4.0), yaw=0.5, pitch=-0.2)
+    imgs = {}
+    for mode in (splat_amd.MODE_EXACT, splat_amd.MODE_CORRECTED_PROJECTION):
+        r = splat_amd.Renderer(mode=mode)
+        try:
+            if not g.cov3d.any():
+                g.compute_cov3d(r)
+            conv = dict(corrected_projection=1) if mode else None
+            img, st, ref, ost = render_both(r, g, cam, 0.3, conv_kw=conv)
+            rec = r.records()
+            want = O.preprocess(scene_dict(g), oracle_camera(cam, 0.3), O.default_conventions(**(conv or {})))
+            vis = want["visible"] == 1
+            for f in ("cx", "cy", "hx", "hy", "conic", "opacity", "rgb"):
+                assert np.array_equal(rec[f][vis], want[f][vis]), (mode, f)
+            assert st.n_pairs == ost.n_tile_pairs
+            assert image_diff(img, ref)[0] <= TOL_LSB
+            imgs[mode] = img
+        finally:
+            r.close()
+    assert not np.array_equal(imgs[0], imgs[1])
+
+
 def test_sh_degrees(R):
     g = gpu_scene(R, 5000, 15)
     cam = make_camera(128, 128)
