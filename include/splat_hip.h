@@ -111,6 +111,19 @@ int splat_set_slab(splat_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
  * preprocess + scan kernels.  n_rows must be ceil(h / SPLAT_TILE). */
 int splat_tile_row_loads(splat_ctx* ctx, const splat_camera* cam, uint64_t* row_pairs, int32_t n_rows);
 
+/* Viewer-loop variant (src/main.rs:69-78: clear, render, present): the frame is rendered onto a
+ * CLEARED device image -- what the loop's `color.clear(0)` + `render_to_buffer` amount to -- and
+ * copied to `argb_out` (host, w*h u32) asynchronously; the call returns once the work is queued.
+ * Frames alternate between two device images, so frame N+1 renders while frame N crosses PCIe.
+ * `argb_out` is complete after splat_stream_wait(ctx, argb_out) (or splat_sync); give each frame
+ * in flight its own buffer, ideally pinned (splat_host_alloc) -- a pageable one works but the
+ * copy then blocks the calling thread.  SPLAT_ERR_CAPACITY from the wait means the frame was
+ * skipped on the device (storage has been grown): render it again. */
+int splat_render_stream(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb_out);
+int splat_stream_wait(splat_ctx* ctx, const uint32_t* argb_out);
+void* splat_host_alloc(uint64_t bytes);      /* page-locked host memory (hipHostMalloc); NULL on failure */
+void splat_host_free(void* p);
+
 /* render_to_buffer: blends the scene onto `argb` (in/out, host, w*h u32).  stats may be NULL. */
 int splat_render(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb, splat_stats* stats);
 

@@ -86,9 +86,17 @@ public:
     PipelineBase(const PipelineBase&) = delete;
     PipelineBase& operator=(const PipelineBase&) = delete;
     splat_stats last_stats{};
+    // Viewer loop (src/main.rs:69-78) without the stall: stream_frame() == clear + render_to_buffer,
+    // queued; the pixels are in `color` after wait_frame(color).  Keep two buffers in flight
+    // (pinned ones from alloc_frame make the copy truly asynchronous).
+    void wait_frame(const uint32_t* color);
+    static uint32_t* alloc_frame(size_t pixels);
+    static void free_frame(uint32_t* p);
 protected:
     PipelineBase() = default;
     void render(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color);
+    void stream(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color);
+    void ensure(const GaussianList& g);
     splat_ctx* ctx_ = nullptr;
     const void* uploaded_ = nullptr;
 };
@@ -99,6 +107,7 @@ public:
     GaussianSplatPipeline01(std::vector<Gaussian> gaussians, Camera camera);
     // Blends onto `color` (w*h u32, 0xAARRGGBB) exactly as src/pipelines.rs:66-86 does.
     void render_to_buffer(uint32_t* color);
+    void stream_frame(uint32_t* color);        // cleared frame, asynchronous (see PipelineBase)
     std::vector<Gaussian> gaussians;   // pub
     Camera camera;                     // pub
 private:
@@ -109,6 +118,7 @@ class GaussianSplatPipeline02 : public detail::PipelineBase {
 public:
     GaussianSplatPipeline02(GaussianList gaussians, Camera camera);
     void render_to_buffer(uint32_t* color);    // src/pipelines.rs:260-280
+    void stream_frame(uint32_t* color);
     GaussianList gaussians;            // pub
     Camera camera;                     // pub
 };

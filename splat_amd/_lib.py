@@ -61,6 +61,10 @@ SYMBOLS = [
     ("splat_get_tile_lists", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32),
                                         C.c_uint64]),
     ("splat_binning_mode", C.c_int64, [C.c_void_p]),
+    ("splat_render_stream", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p]),
+    ("splat_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("splat_host_alloc", C.c_void_p, [C.c_uint64]),
+    ("splat_host_free", None, [C.c_void_p]),
 ]
 
 _LIB = None

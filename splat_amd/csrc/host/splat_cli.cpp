@@ -12,12 +12,14 @@
 int main(int argc, char** argv) {
     const char* ply = nullptr; const char* out = nullptr;
     int W = 800, H = 600, frames = 36;
+    bool streaming = false;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--ply") && i + 1 < argc) ply = argv[++i];
         else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
         else if (!std::strcmp(argv[i], "--size") && i + 2 < argc) { W = std::atoi(argv[++i]); H = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
-        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--out frame.ppm]\n"); return 2; }
+        else if (!std::strcmp(argv[i], "--stream")) streaming = true;
+        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--stream] [--out frame.ppm]\n"); return 2; }
     }
     try {
         std::printf("Loading gaussians from %s\n", ply ? ply : "naive_gaussians()");
@@ -27,6 +29,25 @@ int main(int argc, char** argv) {
         splat::Vec3 pos{0.0f, 0.0f, 5.0f};                    // CAMERA_POSITION, src/main.rs:13
         splat::GaussianSplatPipeline01 pipeline(g, splat::Camera((float)H, (float)W, &pos));
         std::vector<uint32_t> color((size_t)W * H, 0u);
+        if (streaming) {
+            // the same loop with the present step decoupled: two pinned frames in flight, frame f is
+            // "presented" (waited for) while frame f+1 renders and frame f crosses PCIe
+            uint32_t* buf[2] = {splat::GaussianSplatPipeline01::alloc_frame((size_t)W * H),
+                                splat::GaussianSplatPipeline01::alloc_frame((size_t)W * H)};
+            auto t0 = std::chrono::steady_clock::now();
+            for (int f = 0; f < frames; ++f) {
+                pipeline.camera.update_camera_pose();
+                pipeline.stream_frame(buf[f & 1]);
+                if (f > 0) pipeline.wait_frame(buf[(f - 1) & 1]);
+                pipeline.camera.update_yaw_angle(10.0f * 3.14159265f / 180.0f);
+            }
+            pipeline.wait_frame(buf[(frames - 1) & 1]);
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("Streamed %d frames in %.3f ms: %.3f ms per frame, host-visible\n", frames, ms, ms / frames);
+            std::memcpy(color.data(), buf[(frames - 1) & 1], color.size() * 4);
+            for (auto* b : buf) splat::GaussianSplatPipeline01::free_frame(b);
+            frames = 0;
+        }
         for (int f = 0; f < frames; ++f) {
             auto t0 = std::chrono::steady_clock::now();
             pipeline.camera.update_camera_pose();

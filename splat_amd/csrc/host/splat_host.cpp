@@ -284,7 +284,7 @@ void GaussianList::compute_cov3d(splat_ctx* gpu) {
 // ---------------------------------------------------------------- pipelines (src/pipelines.rs)
 namespace detail {
 PipelineBase::~PipelineBase() { if (ctx_) splat_destroy(ctx_); }
-void PipelineBase::render(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color) {
+void PipelineBase::ensure(const GaussianList& g) {
     if (!ctx_) {
         if (splat_create(nullptr, &ctx_) != SPLAT_OK) throw std::runtime_error(std::string("splat_create: ") + splat_last_error(nullptr));
     }
@@ -293,9 +293,27 @@ void PipelineBase::render(const GaussianList& g, const Camera& cam, float lowpas
               ctx_, "splat_upload_scene");
         uploaded_ = &g;
     }
+}
+void PipelineBase::render(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color) {
+    ensure(g);
     splat_camera c = cam.constants(lowpass, 15);   // the literal at src/pipelines.rs:100,189
     check(splat_render(ctx_, &c, color, &last_stats), ctx_, "splat_render");
 }
+void PipelineBase::stream(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color) {
+    ensure(g);
+    splat_camera c = cam.constants(lowpass, 15);
+    check(splat_render_stream(ctx_, &c, color), ctx_, "splat_render_stream");
+}
+void PipelineBase::wait_frame(const uint32_t* color) {
+    if (!ctx_) throw std::runtime_error("wait_frame: nothing was streamed");
+    check(splat_stream_wait(ctx_, color), ctx_, "splat_stream_wait");
+}
+uint32_t* PipelineBase::alloc_frame(size_t pixels) {
+    void* p = splat_host_alloc((uint64_t)pixels * 4);
+    if (!p) throw std::bad_alloc();
+    return static_cast<uint32_t*>(p);
+}
+void PipelineBase::free_frame(uint32_t* p) { splat_host_free(p); }
 }  // namespace detail
 
 GaussianSplatPipeline01::GaussianSplatPipeline01(std::vector<Gaussian> g, Camera cam)
@@ -305,6 +323,11 @@ void GaussianSplatPipeline01::render_to_buffer(uint32_t* color) {
     if (soa_.num_gaussians != gaussians.size() || uploaded_ == nullptr) soa_ = GaussianList::from_vec(gaussians, false);
     render(soa_, camera, 0.01f, color);
 }
+void GaussianSplatPipeline01::stream_frame(uint32_t* color) {
+    if (soa_.num_gaussians != gaussians.size() || uploaded_ == nullptr) soa_ = GaussianList::from_vec(gaussians, false);
+    stream(soa_, camera, 0.01f, color);
+}
+void GaussianSplatPipeline02::stream_frame(uint32_t* color) { stream(gaussians, camera, 0.3f, color); }
 GaussianSplatPipeline02::GaussianSplatPipeline02(GaussianList g, Camera cam) : gaussians(std::move(g)), camera(std::move(cam)) {}
 void GaussianSplatPipeline02::render_to_buffer(uint32_t* color) { render(gaussians, camera, 0.3f, color); }
 

@@ -80,6 +80,14 @@ struct splat_ctx {
     // host-image path
     uint32_t* d_img = nullptr;
     size_t img_cap = 0;
+    // streaming path (splat_render_stream): two device images, a copy stream, per-image events
+    uint32_t* s_img[2] = {nullptr, nullptr};
+    size_t s_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t s_rendered[2] = {nullptr, nullptr}, s_copied[2] = {nullptr, nullptr};
+    const uint32_t* s_dst[2] = {nullptr, nullptr};
+    bool s_used[2] = {false, false};
+    uint64_t s_idx = 0;
     // slab
     int slab0 = 0, slab1 = -1;
     // timing
@@ -209,6 +217,7 @@ void harvest(splat_ctx* c, int r) {
 int sync_all(splat_ctx* c) {
     if (c->bin_stream) HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     return SPLAT_OK;
 }
 
@@ -492,6 +501,12 @@ void splat_destroy(splat_ctx* c) {
         if (s.ev_free) (void)hipEventDestroy(s.ev_free);
     }
     dfree(c->d_img);
+    for (int k = 0; k < 2; ++k) {
+        dfree(c->s_img[k]);
+        if (c->s_rendered[k]) (void)hipEventDestroy(c->s_rendered[k]);
+        if (c->s_copied[k]) (void)hipEventDestroy(c->s_copied[k]);
+    }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto& s : c->ring)
         for (auto& ev : s.e)
@@ -681,6 +696,68 @@ int splat_render(splat_ctx* c, const splat_camera* cam, uint32_t* argb, splat_st
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPLAT_OK;
 }
+
+int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_out) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (!argb_out || !cam) return fail(c, SPLAT_ERR_INVALID, "NULL argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    FrameConst fc; unsigned int nt;
+    int rc = build_frame_const(c, cam, &fc, &nt);
+    if (rc != SPLAT_OK) return rc;
+    const size_t bytes = (size_t)fc.W * fc.H * 4;
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->s_rendered[k], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->s_copied[k], hipEventDisableTiming));
+        }
+    }
+    if (bytes > c->s_cap) {
+        rc = sync_all(c);
+        if (rc != SPLAT_OK) return rc;
+        for (int k = 0; k < 2; ++k) {
+            dfree(c->s_img[k]); c->s_used[k] = false;
+            HIP_TRY(c, hipMalloc(&c->s_img[k], bytes));
+        }
+        c->s_cap = bytes;
+    }
+    const int k = (int)(c->s_idx++ & 1u);
+    // the image must not be cleared while its previous frame is still crossing PCIe
+    if (c->s_used[k]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->s_copied[k], 0));
+    HIP_TRY(c, hipMemsetAsync(c->s_img[k], 0, bytes, c->stream));
+    rc = splat_render_device(c, cam, c->s_img[k], 0, nullptr);
+    if (rc != SPLAT_OK) return rc;
+    HIP_TRY(c, hipEventRecord(c->s_rendered[k], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->s_rendered[k], 0));
+    HIP_TRY(c, hipMemcpyAsync(argb_out, c->s_img[k], bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(c->s_copied[k], c->copy_stream));
+    c->s_dst[k] = argb_out; c->s_used[k] = true;
+    return SPLAT_OK;
+}
+
+int splat_stream_wait(splat_ctx* c, const uint32_t* argb_out) {
+    if (!c) return SPLAT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    // the most recent frame that went to this buffer (the other image may hold an older one)
+    const int newest = (int)((c->s_idx + 1) & 1u);
+    for (int j = 0; j < 2; ++j) {
+        const int k = j == 0 ? newest : newest ^ 1;
+        if (c->s_used[k] && c->s_dst[k] == argb_out) {
+            HIP_TRY(c, hipEventSynchronize(c->s_copied[k]));
+            for (int r = 0; r < EV_RING; ++r)          // statuses of finished frames: did one overflow?
+                if (c->ring[r].used && hipEventQuery(c->ring[r].e[N_EV - 1]) == hipSuccess) harvest(c, r);
+            if (c->overflow_want || c->bucket_overflow) return finish_frame(c);
+            return SPLAT_OK;
+        }
+    }
+    return fail(c, SPLAT_ERR_INVALID, "no streamed frame is bound to this buffer");
+}
+
+void* splat_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, (size_t)bytes) == hipSuccess ? p : nullptr;
+}
+void splat_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int splat_sync(splat_ctx* c) {
     if (!c) return SPLAT_ERR_INVALID;

@@ -45,6 +45,9 @@ class Renderer:
         if getattr(self, "_h", None):
             self._L.splat_destroy(self._h)
             self._h = None
+            for p in getattr(self, "_pinned", []):
+                self._L.splat_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -104,6 +107,24 @@ class Renderer:
 
     def sync(self):
         self._check(self._L.splat_sync(self._h))
+
+    # ---- viewer-loop streaming (src/main.rs:69-78): cleared frame -> async copy into a host buffer
+    def host_image(self, h, w):
+        """a pinned (page-locked) h x w uint32 image; keep the Renderer alive while it is in use"""
+        p = self._L.splat_host_alloc(int(h) * int(w) * 4)
+        if not p:
+            raise MemoryError("splat_host_alloc")
+        arr = np.ctypeslib.as_array((C.c_uint32 * (int(h) * int(w))).from_address(p)).reshape(int(h), int(w))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return arr
+
+    def render_stream(self, cam_c, out):
+        assert out.dtype == np.uint32 and out.flags.c_contiguous
+        self._check(self._L.splat_render_stream(self._h, C.byref(cam_c), C.c_void_p(out.ctypes.data)))
+
+    def stream_wait(self, out):
+        self._check(self._L.splat_stream_wait(self._h, C.c_void_p(out.ctypes.data)))
 
     def timing(self, reset=True):
         ms = (C.c_double * 6)()

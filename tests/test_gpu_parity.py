@@ -367,6 +367,37 @@ def test_block_culling_never_changes_a_frame():
     assert all(o[4] == 0 for o in res["0"]) and sum(o[4] > 0 for o in res["1"]) > len(res["1"]) // 2, [o[4] for o in res["1"]]
 
 
+def test_streamed_frames_equal_synchronous_frames(R):
+    """splat_render_stream (viewer loop: cleared frame, asynchronous copy-out, two frames in flight)
+    delivers exactly the frames splat_render produces on a cleared buffer -- pinned and pageable
+    destination buffers, an orbit of poses."""
+    g = gpu_scene(R, 25000, 29)
+    R.upload(g)
+    H, W = 176, 240
+    poses = [make_camera(H, W, yaw=0.35 * k) for k in range(7)]
+    want = []
+    for cam in poses:
+        img = np.zeros((H, W), np.uint32)
+        R.render(cam.to_c(0.01), img)
+        want.append(img)
+    for pinned in (True, False):
+        bufs = [R.host_image(H, W) if pinned else np.empty((H, W), np.uint32) for _ in range(2)]
+        for b in bufs:
+            b[:] = 0xDEADBEEF                       # the stream path must not blend onto this
+        got = []
+        for k, cam in enumerate(poses):
+            R.render_stream(cam.to_c(0.01), bufs[k & 1])
+            if k > 0:
+                R.stream_wait(bufs[(k - 1) & 1])
+                got.append(bufs[(k - 1) & 1].copy())
+        R.stream_wait(bufs[(len(poses) - 1) & 1])
+        got.append(bufs[(len(poses) - 1) & 1].copy())
+        for k in range(len(poses)):
+            assert np.array_equal(got[k], want[k]), (pinned, k)
+    with pytest.raises(splat_amd.SplatError):
+        R.stream_wait(np.zeros((H, W), np.uint32))      # a buffer no frame was streamed to
+
+
 def test_slabs_equal_full_frame(R):
     """multi-GPU decomposition: tile-row slabs rendered separately == the full frame, byte for byte"""
     g = gpu_scene(R, 30000, 19)
