@@ -1,11 +1,14 @@
 // splat_api.hip -- C ABI (include/splat_hip.h) over the gfx950 kernels.  Host side only:
 // buffer ownership, per-frame constants, launch sequence, HIP-event timing, error reporting.
 //
-// Per-frame buffers live in two SLOTS used alternately.  With SPLAT_PIPELINE=1 binning + sorting of
-// frame N+1 run on an internal stream into the other slot while frame N is still compositing on
-// the caller's stream (fork/join = two events per frame; nothing is skipped or reused between
-// frames).  Measured gain on MI355X is ~1.5 %: the compositor already occupies every wave slot,
-// so the next frame's K1 only crawls alongside it -- hence off by default.
+// Frames overlap on the device (SPLAT_PIPELINE = frames in flight, default 2): per-frame buffers live
+// in SLOTS used in rotation; preprocess + scan + sort of frame N+1 run on an internal high-priority
+// stream into the next slot while frame N composites on the caller's stream (fork/join = two events
+// per frame; nothing is skipped or reused between frames).  K1 and the sort are latency chains
+// (36 % / < 21 % VALU), the compositor is VALU bound (78 %): side by side they take 0.57 ms per frame
+// instead of 0.63 (C3; +10 %, C2 +35 %, C1 +47 %).  SPLAT_PIPELINE=3 also moves the sort to its own
+// stream (K1 of N+2 | sort of N+1 | compositor of N): the 147-KB-LDS sort workgroups then starve
+// beside the other two (+3 % only) -- kept as an option.  SPLAT_PIPELINE=1: one stream, no overlap.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -21,10 +24,10 @@ using namespace splat;
 
 namespace {
 thread_local std::string g_create_error;
-constexpr int N_EV = 8;        // e0..e4 on the bin stream (start, K1, scan, K2, K3), e5..e7 on the caller's (K4 start, K4 end, status)
+constexpr int N_EV = 9;        // e0..e2 on the bin stream (start, K1, scan), e8, e3, e4 on the sort stream (start, K2, K3), e5..e7 on the caller's (K4 start, K4 end, status)
 constexpr int N_TIMES = 6;     // preprocess, scan, emit, sort, composite, status read-back
 constexpr int EV_RING = 32;
-constexpr int N_SLOTS = 2;
+constexpr int N_SLOTS = 3;
 
 struct EvSet {
     hipEvent_t e[N_EV];
@@ -44,7 +47,8 @@ struct Slot {                  // everything one frame writes before the image
     unsigned long long* keys = nullptr;
     unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
     FrameStatus* d_status = nullptr;
-    hipEvent_t ev_ready = nullptr;         // bin stream -> caller's stream: lists are sorted
+    hipEvent_t ev_binned = nullptr;        // bin stream -> sort stream: buckets and lengths are final
+    hipEvent_t ev_ready = nullptr;         // sort stream -> caller's stream: lists are sorted
     hipEvent_t ev_free = nullptr;          // caller's stream -> bin stream: compositor is done with the slot
     bool used = false;
 };
@@ -54,7 +58,8 @@ struct splat_ctx {
     splat_config cfg{};
     hipStream_t stream = nullptr;          // compositor + image: the caller-visible stream
     bool own_stream = false;
-    hipStream_t bin_stream = nullptr;      // K1..K3 of the next frame
+    hipStream_t bin_stream = nullptr;      // K1 + scan of a later frame
+    hipStream_t sort_stream = nullptr;     // K2 + K3 (depth 2: the bin stream itself)
     // scene
     uint64_t n = 0;
     float4* planes = nullptr;
@@ -101,11 +106,16 @@ struct splat_ctx {
     unsigned int n_tiles = 0;
     uint64_t overflow_want = 0;            // a harvested frame overflowed the pair buffer: grow to this
     bool bucket_overflow = false;          // a harvested frame overflowed a tile bucket: leave one-pass binning
+    // sort launch sizes: the long-list sort launches cover a prefix of the longest-first tile order,
+    // sized from the most recent harvested frame (+25 % + slack); the device validates, a miss redoes the frame
+    bool sort_hint = false, sort_grid_miss = false;
+    unsigned int hint_ge8192 = 0, hint_ge2048 = 0;
+    unsigned int grid_big = 0, grid_mid = 0;      // what the frame being enqueued uses
     FrameStatus last{};
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
     int early_min = 256;                   // SPLAT_EARLY_MIN
     int prio_len = 0x3fffffff;             // SPLAT_PRIO_LEN
-    bool pipeline = false;                 // SPLAT_PIPELINE=1: bin/sort of frame N+1 on an internal stream while frame N composites
+    int pipeline = 2;                      // frames in flight on the device (SPLAT_PIPELINE = 1 | 2 | 3, see enqueue_frame)
     std::string err;
 };
 
@@ -192,7 +202,7 @@ void dfree(T*& p) {
 }
 
 const float* ev_times(const EvSet& s, float t[N_TIMES]) {
-    static const int pairs[N_TIMES][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {5, 6}, {6, 7}};
+    static const int pairs[N_TIMES][2] = {{0, 1}, {1, 2}, {8, 3}, {3, 4}, {5, 6}, {6, 7}};
     for (int k = 0; k < N_TIMES; ++k) {
         t[k] = 0.f;
         (void)hipEventElapsedTime(&t[k], s.e[pairs[k][0]], s.e[pairs[k][1]]);
@@ -203,7 +213,7 @@ const float* ev_times(const EvSet& s, float t[N_TIMES]) {
 void harvest(splat_ctx* c, int r) {
     EvSet& s = c->ring[r];
     if (!s.used) return;
-    (void)hipEventSynchronize(s.e[N_EV - 1]);
+    (void)hipEventSynchronize(s.e[7]);
     float t[N_TIMES];
     ev_times(s, t);
     for (int k = 0; k < N_TIMES; ++k) c->acc_ms[k] += t[k];
@@ -211,11 +221,14 @@ void harvest(splat_ctx* c, int r) {
     const FrameStatus& st = c->h_status[r];
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) c->bucket_overflow = true;
+    if (st.overflow == 3) c->sort_grid_miss = true;
+    if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; }
     s.used = false;
 }
 
 int sync_all(splat_ctx* c) {
     if (c->bin_stream) HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
+    if (c->sort_stream) HIP_TRY(c, hipStreamSynchronize(c->sort_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     return SPLAT_OK;
@@ -226,6 +239,7 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     int rc = sync_all(c);
     if (rc != SPLAT_OK) return rc;
     c->m_alloc = 0;
+    c->sort_hint = false;                  // another target geometry: the list-length profile is unknown again
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens);
         HIP_TRY(c, hipMalloc(&s.lens, sizeof(unsigned int) * (size_t)(m + 1)));
@@ -316,7 +330,12 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
     harvest(c, r);
     const int si = (int)(c->frame_idx++ % (uint64_t)slots_in_use(c));
     Slot& s = c->slots[si];
+    // pipeline depth 1: everything on the caller's stream.  2: K1..K3 of frame N+1 on the bin stream
+    // under the compositor of frame N.  3: K1 + scan of frame N+2 on the bin stream, K2 + K3 of
+    // frame N+1 on the sort stream, compositor of frame N on the caller's stream -- the bin chain is
+    // the longest of the three under contention, so splitting it raises the frame rate.
     hipStream_t bs = c->pipeline ? c->bin_stream : c->stream;
+    hipStream_t ss = c->pipeline >= 3 ? c->sort_stream : bs;
     const unsigned int m = c->n_tiles;
     if (c->pipeline) {
         // order this frame's binning after whatever the caller queued before the call (it may have
@@ -328,15 +347,26 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), bs));
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, s.d_status);
     HIP_TRY(c, hipEventRecord(ev.e[1], bs));
-    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, c->cap, c->fc.bucket_cap);
+    if (c->sort_hint) {
+        c->grid_big = std::min<uint64_t>(m, (uint64_t)c->hint_ge8192 + c->hint_ge8192 / 4 + 16);
+        c->grid_mid = std::min<uint64_t>(m, (uint64_t)c->hint_ge2048 + c->hint_ge2048 / 4 + 64);
+    } else {
+        c->grid_big = m; c->grid_mid = m;
+    }
+    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid);
     HIP_TRY(c, hipEventRecord(ev.e[2], bs));
+    if (ss != bs) {
+        HIP_TRY(c, hipEventRecord(s.ev_binned, bs));
+        HIP_TRY(c, hipStreamWaitEvent(ss, s.ev_binned, 0));
+    }
+    HIP_TRY(c, hipEventRecord(ev.e[8], ss));
     if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
-        launch_emit(bs, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[3], bs));
-    launch_sort(bs, m, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[4], bs));
+        launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[3], ss));
+    launch_sort(ss, m, c->grid_big, c->grid_mid, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status);
+    HIP_TRY(c, hipEventRecord(ev.e[4], ss));
     if (c->pipeline) {
-        HIP_TRY(c, hipEventRecord(s.ev_ready, bs));
+        HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_ready, 0));
     }
     HIP_TRY(c, hipEventRecord(ev.e[5], c->stream));
@@ -360,6 +390,10 @@ int finish_frame(splat_ctx* c) {
     if (rc != SPLAT_OK) return rc;
     if (c->last_ring >= 0) c->last = c->h_status[c->last_ring];
     for (int k = 0; k < EV_RING; ++k) harvest(c, k);
+    if (c->sort_grid_miss) {            // the hint has been refreshed from the frame that missed
+        c->sort_grid_miss = false;
+        return fail(c, SPLAT_ERR_CAPACITY, "more long tile lists than the sort launches covered; frame must be re-rendered");
+    }
     if (c->bucket_overflow) {
         c->bucket_overflow = false;
         c->bucket_failed = true; c->bucket_m = c->n_tiles;
@@ -375,7 +409,7 @@ int finish_frame(splat_ctx* c) {
     return SPLAT_OK;
 }
 
-int slots_in_use(const splat_ctx* c) { return c->pipeline ? N_SLOTS : 1; }
+int slots_in_use(const splat_ctx* c) { return c->pipeline >= 3 ? 3 : (c->pipeline ? 2 : 1); }
 
 // Pick the binning path for a frame over m tiles and make sure its key storage exists.
 int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
@@ -457,7 +491,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e1 = std::getenv("SPLAT_EARLY_EPS")) c->early_eps = (float)std::atof(e1);
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
-    if (const char* e4 = std::getenv("SPLAT_PIPELINE")) c->pipeline = std::atoi(e4) != 0;
+    if (const char* e4 = std::getenv("SPLAT_PIPELINE")) { c->pipeline = std::atoi(e4); if (c->pipeline <= 1) c->pipeline = 0; if (c->pipeline > 3) c->pipeline = 3; }
     if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;
     if (const char* e7 = std::getenv("SPLAT_CULL")) c->cull_blocks = std::atoi(e7) != 0;
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
@@ -473,11 +507,15 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         // stream, and its short streaming kernels should not queue behind a frame-long compositor
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if ((e = hipStreamCreateWithPriority(&c->bin_stream, hipStreamNonBlocking, hi)) != hipSuccess) return bail("hipStreamCreate", e);
+        int prio = hi;
+        if (const char* ep = std::getenv("SPLAT_BIN_PRIO")) prio = std::atoi(ep) > 0 ? hi : (std::atoi(ep) < 0 ? lo : (lo + hi) / 2);
+        if ((e = hipStreamCreateWithPriority(&c->bin_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
+        if ((e = hipStreamCreateWithPriority(&c->sort_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
     }
     for (Slot& s : c->slots) {
         if ((e = hipMalloc(&s.d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
         if ((e = hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&s.ev_binned, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     if ((e = hipHostMalloc(&c->h_status, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipHostMalloc(status)", e);
@@ -493,11 +531,13 @@ void splat_destroy(splat_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->bin_stream) (void)hipStreamSynchronize(c->bin_stream);
+    if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
+        if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);
         if (s.ev_free) (void)hipEventDestroy(s.ev_free);
     }
     dfree(c->d_img);
@@ -512,6 +552,7 @@ void splat_destroy(splat_ctx* c) {
         for (auto& ev : s.e)
             if (ev) (void)hipEventDestroy(ev);
     if (c->bin_stream) (void)hipStreamDestroy(c->bin_stream);
+    if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -579,6 +620,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     cleanup();
     c->n = n;
     c->bucket_failed = false;              // key storage is sized at the first frame (prepare_binning)
+    c->sort_hint = false;
     return SPLAT_OK;
 }
 
@@ -634,7 +676,7 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     fc.bucket_cap = 0;          // count only
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
     launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, c->bounds, c->culled, s.d_status);
-    launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, ~0ull, 0u);
+    launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, ~0ull, 0u, nt, nt);
     HIP_TRY(c, hipGetLastError());
     std::vector<unsigned int> off((size_t)nt + 1);
     HIP_TRY(c, hipMemcpyAsync(off.data(), s.offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost, c->stream));
@@ -667,7 +709,7 @@ int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int
         if (!sync && !stats) return SPLAT_OK;
         rc = finish_frame(c);
         // the frame was skipped on the device; its storage has been grown / its path switched: redo
-        if (rc == SPLAT_ERR_CAPACITY && (c->fc.bucket_cap || c->cap > c->last.n_pairs)) continue;
+        if (rc == SPLAT_ERR_CAPACITY && (c->fc.bucket_cap || c->last.overflow == 3 || c->cap > c->last.n_pairs)) continue;
         break;
     }
     if (rc != SPLAT_OK) return rc;
@@ -745,8 +787,8 @@ int splat_stream_wait(splat_ctx* c, const uint32_t* argb_out) {
         if (c->s_used[k] && c->s_dst[k] == argb_out) {
             HIP_TRY(c, hipEventSynchronize(c->s_copied[k]));
             for (int r = 0; r < EV_RING; ++r)          // statuses of finished frames: did one overflow?
-                if (c->ring[r].used && hipEventQuery(c->ring[r].e[N_EV - 1]) == hipSuccess) harvest(c, r);
-            if (c->overflow_want || c->bucket_overflow) return finish_frame(c);
+                if (c->ring[r].used && hipEventQuery(c->ring[r].e[7]) == hipSuccess) harvest(c, r);
+            if (c->overflow_want || c->bucket_overflow || c->sort_grid_miss) return finish_frame(c);
             return SPLAT_OK;
         }
     }

@@ -658,7 +658,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
                                                     unsigned int* __restrict__ offsets, unsigned int* __restrict__ cursor,
                                                     unsigned int* __restrict__ order, unsigned int* __restrict__ lens,
                                                     FrameStatus* __restrict__ status,
-                                                    unsigned long long capacity, unsigned int bucket_cap) {
+                                                    unsigned long long capacity, unsigned int bucket_cap,
+                                                    unsigned int grid_big, unsigned int grid_mid) {
     constexpr int NCLS = 64;
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int hist[NCLS];
@@ -713,6 +714,14 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         status->max_tile_len = mx;
         unsigned int run = 0;
         for (int cidx = NCLS - 1; cidx >= 0; --cidx) { start[cidx] = run; run += hist[cidx]; }
+        // The sort launches for long lists cover only a prefix of `order` (their workgroups need most
+        // of a CU's LDS just to start, and thousands of them doing nothing starve under a concurrent
+        // compositor); the prefixes were sized from an earlier frame.  Lists >= 8192 / >= 2048 keys
+        // form whole length classes, i.e. exact prefixes of `order`.
+        const unsigned int ge8192 = start[cls_of(8192u)] + hist[cls_of(8192u)];
+        const unsigned int ge2048 = start[cls_of(2048u)] + hist[cls_of(2048u)];
+        status->n_ge8192 = ge8192; status->n_ge2048 = ge2048;
+        if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid)) status->overflow = 3u;
     }
     __syncthreads();   // lens[] written above by this workgroup are visible to it
     for (unsigned int k = tid; k < m; k += 1024) order[atomicAdd(&start[cls_of(lens[k])], 1u)] = k;
@@ -1413,17 +1422,18 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
-                 unsigned int bucket_cap) {
+                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid) {
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
-                       bucket_cap);
+                       bucket_cap, grid_big, grid_mid);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
     if (!n) return;
     hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256 * EMIT_G)), dim3(256), 0, s, fc, depth, rect, orig, vislist, cursor, keys, status);
 }
-void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order,
-                 const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2, FrameStatus* status) {
+void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, const unsigned int* offsets,
+                 const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
+                 FrameStatus* status) {
     if (!n_tiles) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1436,9 +1446,12 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, const unsigned int* offset
     static const char* rm = std::getenv("SPLAT_SORT_RADIX_MIN");     // lists up to this length use the bitonic network
     static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
     // longest class first (the tiles are ordered longest-first too)
-    hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(n_tiles), dim3(1024), (sort_lds_bytes<1024, 16384>()), s, offsets, order,
+    grid_big = std::min(grid_big, n_tiles); grid_mid = std::min(grid_mid, n_tiles);
+    if (grid_big)
+    hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(grid_big), dim3(1024), (sort_lds_bytes<1024, 16384>()), s, offsets, order,
                        lens, keys, keys2, status, 8192u, radix_min, 1);
-    hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(n_tiles), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
+    if (grid_mid)
+    hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(grid_mid), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
                        lens, keys, keys2, status, 2048u, radix_min, 0);
     hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
                        lens, keys, keys2, status, 0u, radix_min, 0);
@@ -1449,7 +1462,11 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
-    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status);
+    // SPLAT_COMP_LDS_PAD: extra dynamic LDS per workgroup, i.e. an occupancy cap (12 KB are in use:
+    // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
+    static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
+    static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
+    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status);
 }
 
 }  // namespace splat
