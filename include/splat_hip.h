@@ -136,8 +136,10 @@ void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the ker
 /* Run on a caller-owned hipStream_t (e.g. the stream a device image / RCCL gather lives on). */
 int splat_set_stream(splat_ctx* ctx, void* hip_stream);
 /* Accumulated per-kernel device time since the last reset, from HIP events recorded on the
- * context's stream around every launch: ms[0..5] = preprocess, scan, emit, sort, composite,
- * status read-back; *frames = frames accumulated.  Waits for outstanding frames. */
+ * kernels' own streams around the launches: ms[0..5] = preprocess, scan, emit, sort, composite,
+ * status read-back; *frames = frames that carried events.  Event records cost queue bubbles, so
+ * only every SPLAT_TIMING_EVERY-th frame (default 8) of an asynchronous run carries them, plus every
+ * frame rendered with a stats pointer; averages = ms[k] / *frames.  Waits for outstanding frames. */
 int splat_get_timing(splat_ctx* ctx, double ms[6], uint64_t* frames, int32_t reset);
 
 /* Debug / stage parity: results of the last frame. */

@@ -32,6 +32,7 @@ constexpr int N_SLOTS = 3;
 struct EvSet {
     hipEvent_t e[N_EV];
     bool used = false;
+    bool timed = false;        // the per-kernel events e0..e6, e8 were recorded for this frame
 };
 
 struct Slot {                  // everything one frame writes before the image
@@ -115,6 +116,7 @@ struct splat_ctx {
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
     int early_min = 256;                   // SPLAT_EARLY_MIN
     int prio_len = 0x3fffffff;             // SPLAT_PRIO_LEN
+    int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
     int pipeline = 2;                      // frames in flight on the device (SPLAT_PIPELINE = 1 | 2 | 3, see enqueue_frame)
     std::string err;
 };
@@ -214,10 +216,12 @@ void harvest(splat_ctx* c, int r) {
     EvSet& s = c->ring[r];
     if (!s.used) return;
     (void)hipEventSynchronize(s.e[7]);
-    float t[N_TIMES];
-    ev_times(s, t);
-    for (int k = 0; k < N_TIMES; ++k) c->acc_ms[k] += t[k];
-    c->acc_frames++;
+    if (s.timed) {
+        float t[N_TIMES];
+        ev_times(s, t);
+        for (int k = 0; k < N_TIMES; ++k) c->acc_ms[k] += t[k];
+        c->acc_frames++;
+    }
     const FrameStatus& st = c->h_status[r];
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) c->bucket_overflow = true;
@@ -323,9 +327,14 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
 
 // Enqueue one frame.  Never blocks the host unless the event ring wraps onto a frame that is
 // still running (32 frames behind).
-int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
+// `timed`: record the per-kernel timing events.  Every hipEventRecord is a barrier packet that
+// drains its queue for a few microseconds -- nine of them per frame were ~25 us of bubbles in a
+// 590 us frame -- so untimed frames (all but every `timing_every`-th of an asynchronous run) record
+// only the one event that tells the host the frame's status has arrived.
+int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
     const int r = c->ring_next;
     EvSet& ev = c->ring[r];
+    auto mark = [&](int k, hipStream_t st) -> hipError_t { return timed ? hipEventRecord(ev.e[k], st) : hipSuccess; };
     c->ring_next = (c->ring_next + 1) % EV_RING;
     harvest(c, r);
     const int si = (int)(c->frame_idx++ % (uint64_t)slots_in_use(c));
@@ -343,10 +352,10 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
         // for a caller that interleaves uploads), and after the compositor that last used the slot
         if (s.used) HIP_TRY(c, hipStreamWaitEvent(bs, s.ev_free, 0));
     }
-    HIP_TRY(c, hipEventRecord(ev.e[0], bs));
+    HIP_TRY(c, mark(0, bs));
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), bs));
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, s.d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[1], bs));
+    HIP_TRY(c, mark(1, bs));
     if (c->sort_hint) {
         c->grid_big = std::min<uint64_t>(m, (uint64_t)c->hint_ge8192 + c->hint_ge8192 / 4 + 16);
         c->grid_mid = std::min<uint64_t>(m, (uint64_t)c->hint_ge2048 + c->hint_ge2048 / 4 + 64);
@@ -354,30 +363,31 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb) {
         c->grid_big = m; c->grid_mid = m;
     }
     launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid);
-    HIP_TRY(c, hipEventRecord(ev.e[2], bs));
+    HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
         HIP_TRY(c, hipEventRecord(s.ev_binned, bs));
         HIP_TRY(c, hipStreamWaitEvent(ss, s.ev_binned, 0));
     }
-    HIP_TRY(c, hipEventRecord(ev.e[8], ss));
+    HIP_TRY(c, mark(8, ss));
     if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
         launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[3], ss));
+    HIP_TRY(c, mark(3, ss));
     launch_sort(ss, m, c->grid_big, c->grid_mid, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[4], ss));
+    HIP_TRY(c, mark(4, ss));
     if (c->pipeline) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_ready, 0));
     }
-    HIP_TRY(c, hipEventRecord(ev.e[5], c->stream));
+    HIP_TRY(c, mark(5, c->stream));
     launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status);
-    HIP_TRY(c, hipEventRecord(ev.e[6], c->stream));
+    HIP_TRY(c, mark(6, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
     if (c->pipeline) HIP_TRY(c, hipEventRecord(s.ev_free, c->stream));
     HIP_TRY(c, hipGetLastError());
     s.used = true;
     ev.used = true;
+    ev.timed = timed;
     c->last_ring = r;
     c->last_slot = si;
     return SPLAT_OK;
@@ -444,7 +454,7 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->bytes_algorithmic = c->n * 148ull + c->last.n_visible * 48ull + c->last.n_pairs * 60ull +
                             (uint64_t)c->fc.W * (uint64_t)(c->fc.row_px1 - c->fc.row_px0) * 4ull;
     float t[N_TIMES] = {0};
-    if (c->last_ring >= 0) ev_times(c->ring[c->last_ring], t);   // events stay valid after harvest
+    if (c->last_ring >= 0 && c->ring[c->last_ring].timed) ev_times(c->ring[c->last_ring], t);   // events stay valid after harvest
     st->ms_preprocess = t[0]; st->ms_scan = t[1]; st->ms_emit = t[2]; st->ms_sort = t[3]; st->ms_composite = t[4];
     st->ms_total = t[0] + t[1] + t[2] + t[3] + t[4];
 }
@@ -492,6 +502,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
     if (const char* e4 = std::getenv("SPLAT_PIPELINE")) { c->pipeline = std::atoi(e4); if (c->pipeline <= 1) c->pipeline = 0; if (c->pipeline > 3) c->pipeline = 3; }
+    if (const char* e9 = std::getenv("SPLAT_TIMING_EVERY")) c->timing_every = std::max(1, std::atoi(e9));
     if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;
     if (const char* e7 = std::getenv("SPLAT_CULL")) c->cull_blocks = std::atoi(e7) != 0;
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
@@ -704,7 +715,8 @@ int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int
     for (int attempt = 0; attempt < 4; ++attempt) {
         rc = prepare_binning(c, c->n_tiles, &c->fc);
         if (rc != SPLAT_OK) return rc;
-        rc = enqueue_frame(c, (uint32_t*)d_argb);
+        const bool timed = stats != nullptr || c->timing_every <= 1 || (c->frame_idx % (uint64_t)c->timing_every) == 0;
+        rc = enqueue_frame(c, (uint32_t*)d_argb, timed);
         if (rc != SPLAT_OK) return rc;
         if (!sync && !stats) return SPLAT_OK;
         rc = finish_frame(c);
