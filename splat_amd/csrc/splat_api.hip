@@ -353,7 +353,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
         if (s.used) HIP_TRY(c, hipStreamWaitEvent(bs, s.ev_free, 0));
     }
     HIP_TRY(c, mark(0, bs));
-    HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), bs));
+    // (the slot's status is zero: cleared behind the read-back of the frame that used it last)
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, s.d_status);
     HIP_TRY(c, mark(1, bs));
     if (c->sort_hint) {
@@ -383,6 +383,8 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
     HIP_TRY(c, mark(6, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
+    // zero the status for the slot's next frame here, off the binning stream's critical path
+    HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
     if (c->pipeline) HIP_TRY(c, hipEventRecord(s.ev_free, c->stream));
     HIP_TRY(c, hipGetLastError());
     s.used = true;
@@ -525,6 +527,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     }
     for (Slot& s : c->slots) {
         if ((e = hipMalloc(&s.d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
+        if ((e = hipMemset(s.d_status, 0, sizeof(FrameStatus))) != hipSuccess) return bail("hipMemset(status)", e);
         if ((e = hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_binned, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -691,6 +694,7 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     HIP_TRY(c, hipGetLastError());
     std::vector<unsigned int> off((size_t)nt + 1);
     HIP_TRY(c, hipMemcpyAsync(off.data(), s.offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));     // frames expect a zeroed status
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < n_rows; ++r)
         row_pairs[r] = (uint64_t)off[(size_t)(r + 1) * fc.tiles_x] - (uint64_t)off[(size_t)r * fc.tiles_x];
@@ -846,6 +850,7 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
         HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
         launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, nullptr, nullptr, s.d_status);
         HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), c->stream));
+        HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     std::vector<Rec> r(n); std::vector<float> d(n); std::vector<ushort4> q(n);
