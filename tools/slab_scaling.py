@@ -22,23 +22,29 @@ loads = R.tile_row_loads(cam_c)
 print("row loads: total %d, max row %d" % (loads.sum(), loads.max()))
 
 
-def slab_time(slab, reps=10):
+def slab_time(slab, reps=40):
+    """wall time per frame of this slab alone on the GPU, frames enqueued back to back (they overlap
+    on the device exactly as in bench.py)"""
+    import time
     R.set_slab(*slab)
     for _ in range(3):
         R.render_device(cam_c, img.data_ptr(), sync=True)
-    R.timing(reset=True)
+    for _ in range(5):
+        img.zero_(); R.render_device(cam_c, img.data_ptr())
+    R.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(reps):
         img.zero_()
         R.render_device(cam_c, img.data_ptr())
-    ms, frames = R.timing(reset=True)
-    return sum(ms[k] for k in ("preprocess", "scan", "emit", "sort", "composite")) / frames
+    R.sync(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
 
 
 for world in (1, 2, 4, 8):
     for name, slabs in (("equal", sdist.slab_partition(H, world)),
                         ("balanced", sdist.slab_partition_balanced(loads, world, row_overhead=2000.0))):
         t = [slab_time(s) for s in slabs]
-        print("world %d %-8s rows %s  slab ms %s  -> max %.3f ms = %.0f fps (gpu time only)" %
+        print("world %d %-8s rows %s  slab ms %s  -> max %.3f ms = %.0f fps (one rank's frames back to back; gather not included)" %
               (world, name, [b - a for a, b in slabs], ["%.2f" % x for x in t], max(t), 1000.0 / max(t)))
         if world == 1:
             break
