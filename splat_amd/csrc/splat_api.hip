@@ -110,8 +110,8 @@ struct splat_ctx {
     // sort launch sizes: the long-list sort launches cover a prefix of the longest-first tile order,
     // sized from the most recent harvested frame (+25 % + slack); the device validates, a miss redoes the frame
     bool sort_hint = false, sort_grid_miss = false;
-    unsigned int hint_ge8192 = 0, hint_ge2048 = 0;
-    unsigned int grid_big = 0, grid_mid = 0;      // what the frame being enqueued uses
+    unsigned int hint_ge8192 = 0, hint_ge2048 = 0, hint_ge16384 = 0;
+    unsigned int grid_big = 0, grid_mid = 0, grid_long = 0;      // what the frame being enqueued uses
     FrameStatus last{};
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
     int early_min = 256;                   // SPLAT_EARLY_MIN
@@ -226,7 +226,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) c->bucket_overflow = true;
     if (st.overflow == 3) c->sort_grid_miss = true;
-    if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; }
+    if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
     s.used = false;
 }
 
@@ -359,10 +359,11 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
     if (c->sort_hint) {
         c->grid_big = std::min<uint64_t>(m, (uint64_t)c->hint_ge8192 + c->hint_ge8192 / 4 + 16);
         c->grid_mid = std::min<uint64_t>(m, (uint64_t)c->hint_ge2048 + c->hint_ge2048 / 4 + 64);
+        c->grid_long = std::min<uint64_t>(m, (uint64_t)c->hint_ge16384 + c->hint_ge16384 / 4 + 8);
     } else {
-        c->grid_big = m; c->grid_mid = m;
+        c->grid_big = m; c->grid_mid = m; c->grid_long = m;
     }
-    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid);
+    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long);
     HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
         HIP_TRY(c, hipEventRecord(s.ev_binned, bs));
@@ -372,7 +373,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
     if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
         launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
     HIP_TRY(c, mark(3, ss));
-    launch_sort(ss, m, c->grid_big, c->grid_mid, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status);
+    launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status);
     HIP_TRY(c, mark(4, ss));
     if (c->pipeline) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
@@ -690,7 +691,7 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     fc.bucket_cap = 0;          // count only
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
     launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, c->bounds, c->culled, s.d_status);
-    launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, ~0ull, 0u, nt, nt);
+    launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, ~0ull, 0u, nt, nt, nt);
     HIP_TRY(c, hipGetLastError());
     std::vector<unsigned int> off((size_t)nt + 1);
     HIP_TRY(c, hipMemcpyAsync(off.data(), s.offsets, sizeof(unsigned int) * off.size(), hipMemcpyDeviceToHost, c->stream));

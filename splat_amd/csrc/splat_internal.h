@@ -53,6 +53,7 @@ struct FrameStatus {
     unsigned long long n_iter_scan;  // compositor (wave, record) iterations: phase A (front-to-back scan)
     unsigned long long n_iter_blend; //                                       phase B (exact blend)
     unsigned int n_ge8192, n_ge2048;    // tiles whose list has >= 8192 / >= 2048 keys: in `order` they are a prefix
+    unsigned int n_ge16384, pad_;       // likewise >= 16384 (the lists sorted as several runs and merged)
     unsigned long long n_blocks_culled; // K1 blocks skipped by the bounds test (filled on the host from the block flags)
 };
 
@@ -72,12 +73,12 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
                        FrameStatus* status);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
-                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid);
+                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long);
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 // grid_big / grid_mid: how many entries of `order` (longest lists first) the 1024- and 512-thread
 // sort launches cover; the scan validates them against the frame's actual list lengths.
-void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, const unsigned int* offsets,
+void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
                  FrameStatus* status);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,

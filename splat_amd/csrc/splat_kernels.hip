@@ -659,7 +659,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
                                                     unsigned int* __restrict__ order, unsigned int* __restrict__ lens,
                                                     FrameStatus* __restrict__ status,
                                                     unsigned long long capacity, unsigned int bucket_cap,
-                                                    unsigned int grid_big, unsigned int grid_mid) {
+                                                    unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long) {
     constexpr int NCLS = 64;
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int hist[NCLS];
@@ -720,8 +720,9 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         // form whole length classes, i.e. exact prefixes of `order`.
         const unsigned int ge8192 = start[cls_of(8192u)] + hist[cls_of(8192u)];
         const unsigned int ge2048 = start[cls_of(2048u)] + hist[cls_of(2048u)];
-        status->n_ge8192 = ge8192; status->n_ge2048 = ge2048;
-        if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid)) status->overflow = 3u;
+        const unsigned int ge16384 = start[cls_of(16384u)] + hist[cls_of(16384u)];
+        status->n_ge8192 = ge8192; status->n_ge2048 = ge2048; status->n_ge16384 = ge16384;
+        if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid || ge16384 > grid_long)) status->overflow = 3u;
     }
     __syncthreads();   // lens[] written above by this workgroup are visible to it
     for (unsigned int k = tid; k < m; k += 1024) order[atomicAdd(&start[cls_of(lens[k])], 1u)] = k;
@@ -1012,6 +1013,9 @@ constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 51
 
 // One workgroup per tile; a launch handles the lists with lo < n <= CAP (three size classes, so
 // that mid-sized lists get two workgroups per CU instead of one LDS-filling one).
+// chunks > 0 (the 1024-thread class): a list of up to chunks * CAP keys is sorted as that many
+// CAP-sized runs, one workgroup each, which merge_runs_kernel then merges; only a list longer than
+// that takes the slow route (radix passes through global memory by its first workgroup).
 template <int NT, int CAP>
 __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __restrict__ offsets,
                                                          const unsigned int* __restrict__ order,
@@ -1019,13 +1023,28 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
                                                          unsigned long long* __restrict__ keys,
                                                          unsigned long long* __restrict__ keys2,
                                                          FrameStatus* __restrict__ status, unsigned int lo,
-                                                         unsigned int radix_min, int last) {
+                                                         unsigned int radix_min, int chunks, unsigned int grid0,
+                                                         unsigned int grid_long) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
     if (status->overflow) return;
-    const unsigned int tile = order[blockIdx.x];
-    const unsigned int b = offsets[tile];
-    const unsigned int n = lens[tile];
+    // workgroups [0, grid0) take run 0 of the first grid0 lists; the next 3 * grid_long ones take runs
+    // 1..3 of the first grid_long lists (those >= 16384 keys are a prefix of the longest-first order)
+    unsigned int oi = blockIdx.x, chunk = 0u;
+    if (chunks && blockIdx.x >= grid0) { const unsigned int r = blockIdx.x - grid0; chunk = 1u + r / grid_long; oi = r % grid_long; }
+    const unsigned int tile = order[oi];
+    unsigned int b = offsets[tile];
+    unsigned int n = lens[tile];
+    if (n < 2 || n <= lo) return;
+    const bool too_long = n > (unsigned int)CAP * (unsigned int)max(chunks, 1);
+    if (chunks && n > (unsigned int)CAP && !too_long) {          // this workgroup's run of a long list
+        if (chunk * (unsigned int)CAP >= n) return;
+        b += chunk * (unsigned int)CAP;
+        n = min((unsigned int)CAP, n - chunk * (unsigned int)CAP);
+        if (n < 2) return;
+    } else if (chunk != 0) {
+        return;
+    }
     // histograms live right behind the keys in use: a list that leaves room gets 512 bins
     constexpr unsigned int NW = NT / 64;
     const unsigned int keys_bytes = ((min(n, (unsigned int)CAP) * 8u) + 15u) & ~15u;
@@ -1033,7 +1052,6 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
     unsigned int* hist = reinterpret_cast<unsigned int*>(smem + keys_bytes);
     unsigned int* tot = hist + (NW << lb);
     unsigned int* dbase = tot + (1u << lb);
-    if (n < 2 || n <= lo) return;
     if (n <= (unsigned int)CAP) {
         unsigned int mn = 0xffffffffu, mx = 0u;
         for (unsigned int t0 = threadIdx.x; t0 < n; t0 += 8u * NT) {     // eight loads in flight per thread
@@ -1054,8 +1072,8 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
             sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl);
         }
         for (unsigned int t = threadIdx.x; t < n; t += NT) keys[b + t] = s[t];
-    } else if (last) {
-        // longer than LDS: radix passes over the L2-resident bucket, then the same tie fix-up
+    } else if (chunks) {
+        // longer than chunks * CAP: radix passes over the L2-resident bucket, then the same tie fix-up
         unsigned long long* g = keys + b;
         unsigned int mn = 0xffffffffu, mx = 0u;
         for (unsigned int t = threadIdx.x; t < n; t += NT) {
@@ -1082,6 +1100,78 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
             bitonic_sort(g, n, threadIdx.x, NT);       // exact network, slow: only for long runs of equal depth
         }
     }
+}
+
+// Merge path: how many of the first d outputs of merge(A[0..la), B[0..lb)) come from A.  Keys are
+// unique (the index half), so there are no ties.
+template <typename PA, typename PB>
+__device__ __forceinline__ unsigned int merge_path(unsigned int d, unsigned int la, unsigned int lb, PA A, PB B) {
+    unsigned int lo = d > lb ? d - lb : 0u, hi = min(d, la);
+    while (lo < hi) {
+        const unsigned int mid = (lo + hi) >> 1;
+        if (A[mid] < B[d - 1u - mid]) lo = mid + 1u; else hi = mid;
+    }
+    return lo;
+}
+
+// K3b -- lists of CAP < n <= 4 CAP keys, which sort_tiles_kernel left as up to four sorted runs of
+// CAP keys: two levels of pairwise merging, keys -> keys2 -> keys (an absent run is an empty one,
+// so a two-run list simply gets copied back by the second level).  One 1024-thread workgroup per
+// list; each level walks its output in tiles of MERGE_T keys: the tile's inputs (found with one
+// merge-path search per tile boundary, all boundaries searched at once) are staged in LDS, every
+// thread merge-path-searches its eight outputs there and writes them.
+constexpr unsigned int MERGE_T = 8192;
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void merge_runs_kernel(const unsigned int* __restrict__ offsets,
+                                                         const unsigned int* __restrict__ order,
+                                                         const unsigned int* __restrict__ lens,
+                                                         unsigned long long* __restrict__ keys,
+                                                         unsigned long long* __restrict__ keys2,
+                                                         const FrameStatus* __restrict__ status) {
+    __shared__ unsigned long long sm[MERGE_T];
+    __shared__ unsigned int split[4 * CAP / MERGE_T + 2];
+    if (status->overflow) return;
+    const unsigned int tile = order[blockIdx.x];
+    const unsigned int n = lens[tile];
+    if (n <= (unsigned int)CAP || n > 4u * (unsigned int)CAP) return;
+    const unsigned int tid = threadIdx.x;
+    const size_t base = offsets[tile];
+    auto merge = [&](const unsigned long long* A, unsigned int la, const unsigned long long* B, unsigned int lb,
+                     unsigned long long* dst) {
+        const unsigned int total = la + lb, ntile = (total + MERGE_T - 1u) / MERGE_T;
+        if (tid <= ntile) split[tid] = merge_path(min(tid * MERGE_T, total), la, lb, A, B);
+        __syncthreads();
+        for (unsigned int k = 0; k < ntile; ++k) {
+            const unsigned int k0 = k * MERGE_T, k1 = min(k0 + MERGE_T, total);
+            const unsigned int i0 = split[k], i1 = split[k + 1], j0 = k0 - i0, na = i1 - i0, nb = (k1 - k0) - na;
+            for (unsigned int t = tid; t < na; t += NT) sm[t] = A[i0 + t];
+            for (unsigned int t = tid; t < nb; t += NT) sm[na + t] = B[j0 + t];
+            __syncthreads();
+            constexpr unsigned int E = MERGE_T / NT;
+            const unsigned int q0 = tid * E;
+            if (q0 < k1 - k0) {
+                const unsigned long long* sA = sm;
+                const unsigned long long* sB = sm + na;
+                unsigned int ia = merge_path(q0, na, nb, sA, sB), ib = q0 - ia;
+#pragma unroll
+                for (unsigned int e = 0; e < E; ++e) {
+                    if (q0 + e < k1 - k0) {
+                        const bool take_a = (ib >= nb) || (ia < na && sA[ia] < sB[ib]);
+                        dst[k0 + q0 + e] = take_a ? sA[ia] : sB[ib];
+                        ia += take_a ? 1u : 0u; ib += take_a ? 0u : 1u;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    const unsigned int r1 = min(n, (unsigned int)CAP), r2 = min(n, 2u * CAP), r3 = min(n, 3u * CAP);
+    unsigned long long* g = keys + base;
+    unsigned long long* h = keys2 + base;
+    merge(g, r1, g + r1, r2 - r1, h);                 // runs 0, 1 -> h[0 .. r2)
+    merge(g + r2, r3 - r2, g + r3, n - r3, h + r2);   // runs 2, 3 -> h[r2 .. n)
+    __syncthreads();                                  // (orders this workgroup's global writes and reads)
+    merge(h, r2, h + r2, n - r2, g);                  // -> the list, sorted, back in place
 }
 
 // Does ANY sample s = lo + k (k = 0..count-1, all exactly representable) satisfy |s - c| <= h ?
@@ -1422,16 +1512,16 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
-                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid) {
+                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long) {
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
-                       bucket_cap, grid_big, grid_mid);
+                       bucket_cap, grid_big, grid_mid, grid_long);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
     if (!n) return;
     hipLaunchKernelGGL(emit_kernel, dim3(blocks_for(n, 256 * EMIT_G)), dim3(256), 0, s, fc, depth, rect, orig, vislist, cursor, keys, status);
 }
-void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, const unsigned int* offsets,
+void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
                  FrameStatus* status) {
     if (!n_tiles) return;
@@ -1447,14 +1537,21 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
     static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
     // longest class first (the tiles are ordered longest-first too)
     grid_big = std::min(grid_big, n_tiles); grid_mid = std::min(grid_mid, n_tiles);
-    if (grid_big)
-    hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(grid_big), dim3(1024), (sort_lds_bytes<1024, 16384>()), s, offsets, order,
-                       lens, keys, keys2, status, 8192u, radix_min, 1);
+    if (grid_big) {
+        // four workgroups per list: lists of 16385..65536 keys are sorted as runs of 16384 and merged
+        // (two-pass binning only: one-pass buckets hold at most 16384 keys and there is no keys2)
+        grid_long = keys2 ? std::min(grid_long, grid_big) : 0u;
+        hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(grid_big + 3u * grid_long), dim3(1024), (sort_lds_bytes<1024, 16384>()), s,
+                           offsets, order, lens, keys, keys2, status, 8192u, radix_min, keys2 ? 4 : 1, grid_big, std::max(grid_long, 1u));
+        if (grid_long)
+            hipLaunchKernelGGL((merge_runs_kernel<1024, 16384>), dim3(grid_long), dim3(1024), 0, s, offsets, order, lens, keys, keys2,
+                               status);
+    }
     if (grid_mid)
     hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(grid_mid), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
-                       lens, keys, keys2, status, 2048u, radix_min, 0);
+                       lens, keys, keys2, status, 2048u, radix_min, 0, 0u, 1u);
     hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
-                       lens, keys, keys2, status, 0u, radix_min, 0);
+                       lens, keys, keys2, status, 0u, radix_min, 0, 0u, 1u);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, const unsigned long long* keys, const Rec* recs,

@@ -244,22 +244,27 @@ def test_deterministic_and_repeatable(R):
 
 
 def test_long_tile_lists_all_sort_paths():
-    """every Gaussian on the same few tiles: lists > 2048 (big LDS sort) and > 16384 (global path);
+    """every Gaussian on the same few tiles: lists > 2048 (big LDS sort), 16385..65536 (sorted as runs
+    of 16384 by four workgroups, then merged in two levels) and longer (radix through global memory);
     also exercises pair-buffer growth (tiny initial capacity)."""
-    r = splat_amd.Renderer(pair_capacity=1000)
-    try:
-        g = splat_amd.synthetic_scene(40000, 17)
-        g.positions[:, :3] *= 0.02                    # squeeze the cloud into ~1 tile
-        g.positions[:20000, 0] += 0.35                # and a second cluster
-        g.compute_cov3d(r)
-        cam = make_camera(96, 96)
-        img, st, ref, ost = render_both(r, g, cam, 0.01)
-        assert st.max_tile_len > 16384, st.max_tile_len
-        assert st.n_pairs == ost.n_tile_pairs
-        mx, cnt = image_diff(img, ref)
-        assert mx <= TOL_LSB, (mx, cnt)
-    finally:
-        r.close()
+    runs_seen = set()
+    for n, second in ((40000, 20000), (60000, 8000), (93000, 8000), (130000, 10000)):
+        r = splat_amd.Renderer(pair_capacity=1000)
+        try:
+            g = splat_amd.synthetic_scene(n, 17)
+            g.positions[:, :3] *= 0.02                    # squeeze the cloud into ~1 tile
+            g.positions[:second, 0] += 0.35               # and a second cluster
+            g.compute_cov3d(r)
+            cam = make_camera(96, 96)
+            img, st, ref, ost = render_both(r, g, cam, 0.01)
+            assert st.max_tile_len > 16384, st.max_tile_len
+            runs_seen.add(min(5, -(-st.max_tile_len // 16384)))
+            assert st.n_pairs == ost.n_tile_pairs
+            mx, cnt = image_diff(img, ref)
+            assert mx <= TOL_LSB, (n, mx, cnt)
+        finally:
+            r.close()
+    assert {2, 3, 4, 5} & runs_seen >= {3, 4, 5} or runs_seen >= {2, 4, 5}, runs_seen      # merge of 2-3 and of 4 runs, and the global path
 
 
 def test_binning_paths_agree():
