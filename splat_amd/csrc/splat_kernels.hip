@@ -1301,8 +1301,11 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         if (!(x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f)) {
             auto q = [&](float x, float y) { return a * x * x + 2.0f * b * x * y + c * y * y; };
             auto cl = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
-            qmin = fminf(fminf(q(x0, cl(-b * x0 / c, y0, y1)), q(x1, cl(-b * x1 / c, y0, y1))),
-                         fminf(q(cl(-b * y0 / a, x0, x1), y0), q(cl(-b * y1 / a, x0, x1), y1)));
+            // (v_rcp, 1 ulp: this is a bound with a 1e-3 margin, not the reference's arithmetic --
+            // four IEEE divisions were a third of the staging instructions)
+            const float nbc = -b * __builtin_amdgcn_rcpf(c), nba = -b * __builtin_amdgcn_rcpf(a);
+            qmin = fminf(fminf(q(x0, cl(nbc * x0, y0, y1)), q(x1, cl(nbc * x1, y0, y1))),
+                         fminf(q(cl(nba * y0, x0, x1), y0), q(cl(nba * y1, x0, x1), y1)));
         }
         const float pmax = -0.5f * qmin;
         return !(pmax + 1e-3f * (1.0f + fabsf(pmax)) < r.c.w);
