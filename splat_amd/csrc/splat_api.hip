@@ -114,7 +114,8 @@ struct splat_ctx {
     unsigned int grid_big = 0, grid_mid = 0, grid_long = 0;      // what the frame being enqueued uses
     FrameStatus last{};
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
-    int early_min = 256;                   // SPLAT_EARLY_MIN
+    int early_min = 512;                   // SPLAT_EARLY_MIN
+    int early_scan8 = 4;                   // SPLAT_EARLY_SCAN8
     int prio_len = 0x3fffffff;             // SPLAT_PRIO_LEN
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
     int pipeline = 2;                      // frames in flight on the device (SPLAT_PIPELINE = 1 | 2 | 3, see enqueue_frame)
@@ -309,6 +310,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->y_up = c->cfg.y_up; fc->sample_half = c->cfg.sample_half; fc->zclip = c->cfg.zclip;
     fc->zmin = c->cfg.zmin; fc->zmax = c->cfg.zmax;
     fc->early_eps = c->early_eps; fc->early_min = c->early_min; fc->prio_len = c->prio_len;
+    fc->early_scan8 = c->early_scan8;
     fc->bucket_cap = 0;
     fc->corrected = (c->cfg.mode == SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
     // (a singular cov2d needs lowpass == 0 or a non-PSD cov3d; with lowpass == 0 every Gaussian is
@@ -503,6 +505,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     c->cfg = *cfg;
     if (const char* e1 = std::getenv("SPLAT_EARLY_EPS")) c->early_eps = (float)std::atof(e1);
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
+    if (const char* e11 = std::getenv("SPLAT_EARLY_SCAN8")) c->early_scan8 = std::min(8, std::max(1, std::atoi(e11)));
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
     if (const char* e4 = std::getenv("SPLAT_PIPELINE")) { c->pipeline = std::atoi(e4); if (c->pipeline <= 1) c->pipeline = 0; if (c->pipeline > 3) c->pipeline = 3; }
     if (const char* e9 = std::getenv("SPLAT_TIMING_EVERY")) c->timing_every = std::max(1, std::atoi(e9));

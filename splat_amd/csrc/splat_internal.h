@@ -30,6 +30,7 @@ struct FrameConst {
     int row_px0, row_px1;  // slab pixel rows [row_px0, row_px1)
     float early_eps;       // compositor early-out: transmittance below which a pixel stops needing layers; 0 = off
     int early_min;         // shortest list the early-out is tried on
+    int early_scan8;       // the transmittance scan gives up after this many eighths of the list
     int prio_len;          // lists >= prio_len / 2x / 4x run at wave priority 1 / 2 / 3
     unsigned int bucket_cap; // one-pass binning: keys per tile bucket (0: two-pass binning with exact lists)
     int corrected;         // SPLAT_MODE_CORRECTED_PROJECTION: J enters transposed (perspective-shear terms kept)

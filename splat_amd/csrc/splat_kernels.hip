@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         unsigned int sp = inside ? beg : 0xffffffffu;    // per lane: first layer the lane needs
         bool done = !inside;
         // a strip that has not saturated after half of its list will not save enough to pay for the scan
-        const unsigned int giveup = beg + ((end - beg) >> 1);
+        const unsigned int giveup = end - (unsigned int)(((unsigned long long)(end - beg) * (unsigned int)fc.early_scan8) >> 3);
         Rec r;
         unsigned int cntN = min(64u, end - beg), bsN = end - cntN;
         fetch(bsN, cntN, r);
