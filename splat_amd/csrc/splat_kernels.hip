@@ -1364,14 +1364,23 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
             const unsigned int bs = bsN, cnt = cntN;
             const unsigned int k = stage(r, cnt, bs, false);
             if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }
+            // the walk itself only tests coverage (six VALU per record) and remembers which record of
+            // the batch each pixel met first; the exact alpha is evaluated once per batch, every lane
+            // on its own record
+            unsigned int jsel = 0xffffffffu;
             for (unsigned int j = k; j-- > 0;) {
-                const float4 a = L.a[j], b = L.b[j];
-                bool cov;
-                const float alpha = frag_alpha(a, b, exp_neg, cov);      // exact, 0 when rejected
-                const bool take = cov & !found;
-                alast = take ? alpha : alast;
+                const float4 a = L.a[j];
+                const bool cov = (fabsf(sxm - a.x) <= a.z) & (fabsf(a.y - sym) <= a.w);
+                jsel = (cov & !found) ? j : jsel;
                 found = found | cov;
                 if (__builtin_amdgcn_ballot_w64(!found) == 0ull) break;
+            }
+            if (__builtin_amdgcn_ballot_w64(jsel != 0xffffffffu) != 0ull) {
+                const unsigned int jr = (jsel != 0xffffffffu) ? jsel : 0u;
+                const float4 a = L.a[jr], b = L.b[jr];
+                bool cov;
+                const float alpha = frag_alpha(a, b, exp_neg, cov);      // exact, 0 when rejected
+                alast = (jsel != 0xffffffffu) ? alpha : alast;
             }
             if (__builtin_amdgcn_ballot_w64(!found) == 0ull || bs == beg) break;
         }
