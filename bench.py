@@ -51,8 +51,8 @@ def cpu_baseline(g, cam_c, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--orbit", action="store_true",
                     help="step the camera yaw by 10 degrees every frame (the 36-pose orbit of src/main.rs:53-60) "
