@@ -359,9 +359,11 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, s.d_status);
     HIP_TRY(c, mark(1, bs));
     if (c->sort_hint) {
-        c->grid_big = std::min<uint64_t>(m, (uint64_t)c->hint_ge8192 + c->hint_ge8192 / 4 + 16);
-        c->grid_mid = std::min<uint64_t>(m, (uint64_t)c->hint_ge2048 + c->hint_ge2048 / 4 + 64);
-        c->grid_long = std::min<uint64_t>(m, (uint64_t)c->hint_ge16384 + c->hint_ge16384 / 4 + 8);
+        // generous: an asynchronous frame that misses is lost (reported at the next sync), idle extra
+        // workgroups of a launch that has the chip to itself cost next to nothing
+        c->grid_big = std::min<uint64_t>(m, 2ull * c->hint_ge8192 + 32);
+        c->grid_mid = std::min<uint64_t>(m, (uint64_t)c->hint_ge2048 + c->hint_ge2048 / 2 + 128);
+        c->grid_long = std::min<uint64_t>(m, 2ull * c->hint_ge16384 + 8);
     } else {
         c->grid_big = m; c->grid_mid = m; c->grid_long = m;
     }
