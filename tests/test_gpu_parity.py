@@ -267,6 +267,37 @@ def test_long_tile_lists_all_sort_paths():
     assert {2, 3, 4, 5} & runs_seen >= {3, 4, 5} or runs_seen >= {2, 4, 5}, runs_seen      # merge of 2-3 and of 4 runs, and the global path
 
 
+@pytest.mark.parametrize("buckets", ["1", "0"])
+def test_close_up_camera_many_big_rectangles(buckets):
+    """camera inside a dense cloud: most Gaussians cover hundreds of tiles, so the blocks' close-ups go
+    through the 64x64-tile cell aggregation (K1 one-pass) / the direct path (two-pass); lists, pair
+    count and frame must still be the oracle's"""
+    import os
+    saved = os.environ.get("SPLAT_BUCKETS")
+    os.environ["SPLAT_BUCKETS"] = buckets
+    try:
+        r = splat_amd.Renderer()
+        try:
+            g = splat_amd.synthetic_scene(6000, 61)
+            g.positions[:, :3] *= 0.25
+            g.scales[:] *= 6.0                       # fat splats
+            g.compute_cov3d(r)
+            cam = make_camera(1088, 1600, pos=(0.05, 0.02, 0.6))      # 100 x 68 tiles: two cells across
+            img, st, ref, ost = render_both(r, g, cam, 0.3)
+            assert st.n_pairs == ost.n_tile_pairs and st.n_visible == ost.n_visible
+            assert st.n_pairs > 150 * st.n_visible, (st.n_pairs, st.n_visible)     # hundreds of tiles per Gaussian
+            assert image_diff(img, ref)[0] <= TOL_LSB
+            n_tiles = 100 * 68
+            off, order = r.tile_lists(n_tiles, st.n_pairs)
+            assert off[-1] == st.n_pairs
+        finally:
+            r.close()
+    finally:
+        os.environ.pop("SPLAT_BUCKETS", None)
+        if saved is not None:
+            os.environ["SPLAT_BUCKETS"] = saved
+
+
 def test_binning_paths_agree():
     """One-pass binning (per-tile buckets filled by K1) and two-pass binning (count, scan, emit) must
     give the same lists and the same frame; a tile that outgrows its bucket, or buckets that do not
