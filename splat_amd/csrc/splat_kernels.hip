@@ -736,6 +736,80 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
     for (unsigned int k = tid; k < m; k += 1024) order[atomicAdd(&start[cls_of(lens[k])], 1u)] = k;
 }
 
+// The scan of one-pass binning has no prefix sum to do (a list starts at its bucket): lengths, the
+// frame totals, and the longest-first tile order.  The order is a counting sort by length class whose
+// counters are per-wave rows of LDS (8160 atomics on a handful of shared class counters serialised:
+// most of the old kernel's 16 us); thread t keeps the same tiles in both passes, so its wave's row
+// offsets are its own.
+__global__ __launch_bounds__(1024) void scan_bucket_kernel(unsigned int m, unsigned int* __restrict__ counts,
+                                                           unsigned int* __restrict__ offsets,
+                                                           unsigned int* __restrict__ order, unsigned int* __restrict__ lens,
+                                                           FrameStatus* __restrict__ status, unsigned int bucket_cap,
+                                                           unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long) {
+    constexpr int NCLS = 64;
+    __shared__ unsigned int row[16][NCLS];
+    __shared__ unsigned int start[NCLS];
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned int wmax[16];
+    const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    auto cls_of = [](unsigned int c) -> unsigned int {
+        if (c == 0) return 0u;
+        unsigned int msb = 31u - (unsigned int)__clz((int)c);
+        unsigned int half = msb ? ((c >> (msb - 1)) & 1u) : 0u;
+        return min(1u + 2u * msb + half, (unsigned int)NCLS - 1u);
+    };
+    row[wave][lane] = 0;
+    __syncthreads();
+    unsigned long long sum = 0;
+    unsigned int mx = 0;
+    for (unsigned int k = tid; k < m; k += 1024) {
+        const unsigned int c = counts[k];
+        counts[k] = 0;
+        const unsigned int len = min(c, bucket_cap);
+        lens[k] = len;
+        offsets[k] = k * bucket_cap;
+        sum += c; mx = max(mx, c);
+        atomicAdd(&row[wave][cls_of(len)], 1u);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+        sum += (unsigned long long)__shfl_xor((long long)sum, o);
+    }
+    if (lane == 0) { wsum[wave] = sum; wmax[wave] = mx; }
+    __syncthreads();
+    if (tid < NCLS) {                      // class tid: its total, and every wave's offset inside the class
+        unsigned int acc = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const unsigned int t = row[w][tid]; row[w][tid] = acc; acc += t; }
+        start[tid] = acc;                  // (total for now)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < 16; ++w) { tot += wsum[w]; mx = max(mx, wmax[w]); }
+        unsigned int run = 0, ge[3] = {0, 0, 0};
+        const unsigned int c8 = cls_of(8192u), c2 = cls_of(2048u), c16 = cls_of(16384u);
+        for (int cidx = NCLS - 1; cidx >= 0; --cidx) {
+            const unsigned int t = start[cidx];
+            start[cidx] = run; run += t;
+            if ((unsigned int)cidx == c16) ge[0] = run;
+            if ((unsigned int)cidx == c8) ge[1] = run;
+            if ((unsigned int)cidx == c2) ge[2] = run;
+        }
+        offsets[m] = (unsigned int)tot;
+        status->n_pairs = tot;
+        status->max_tile_len = mx;
+        status->n_ge16384 = ge[0]; status->n_ge8192 = ge[1]; status->n_ge2048 = ge[2];
+        status->overflow = (mx > bucket_cap) ? 2u : ((ge[1] > grid_big || ge[2] > grid_mid || ge[0] > grid_long) ? 3u : 0u);
+    }
+    __syncthreads();
+    for (unsigned int k = tid; k < m; k += 1024) {
+        const unsigned int cls = cls_of(lens[k]);       // (written by this very thread)
+        order[start[cls] + atomicAdd(&row[wave][cls], 1u)] = k;
+    }
+}
+
 // K2 -- one thread per Gaussian slot: claim a slot in every overlapped tile's bucket and write the
 // 64-bit key (depth_key << 32 | ORIGINAL index).  Bucket order is arbitrary; K3 fixes it.
 constexpr int EMIT_G = 1;              // Gaussians per thread in K2 (4 measured slower: 0.10 -> 0.17 ms)
@@ -1533,8 +1607,12 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
-                       bucket_cap, grid_big, grid_mid, grid_long);
+    if (bucket_cap)
+        hipLaunchKernelGGL(scan_bucket_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, order, lens, status, bucket_cap,
+                           grid_big, grid_mid, grid_long);
+    else
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
+                           bucket_cap, grid_big, grid_mid, grid_long);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
