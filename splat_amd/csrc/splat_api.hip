@@ -66,7 +66,7 @@ struct splat_ctx {
     float4* planes = nullptr;
     unsigned int* orig = nullptr;          // slot -> original Gaussian index (Morton order of position)
     BlockBounds* bounds = nullptr;         // per K1 block of 256 slots (block culling)
-    unsigned char* culled = nullptr;       // per block: 1 if the last K1 skipped it
+    unsigned int* culled = nullptr;        // per block info word written by the last K1 (see launch_preprocess)
     bool cull_blocks = true;               // SPLAT_CULL=0 disables
     std::vector<unsigned int> h_orig;
     // per-frame buffers
@@ -453,10 +453,16 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->n_iter_scan = c->last.n_iter_scan;
     st->n_iter_blend = c->last.n_iter_blend;
     st->n_blocks_culled = 0;
-    if (c->fc.cull_blocks && c->culled && c->last_ring >= 0) {      // the frame has finished: count its block flags
-        std::vector<unsigned char> f((c->n + 255) / 256);
-        if (hipMemcpy(f.data(), c->culled, f.size(), hipMemcpyDeviceToHost) == hipSuccess)
-            for (unsigned char v : f) st->n_blocks_culled += v;
+    if (c->culled && c->last_ring >= 0 && (c->fc.cull_blocks || c->fc.bucket_cap)) {   // the frame has finished: sum its block words
+        std::vector<unsigned int> f((c->n + 255) / 256);
+        if (hipMemcpy(f.data(), c->culled, f.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess) {
+            uint64_t vis = 0, sing = 0;
+            for (unsigned int v : f) {
+                if (v & 0x80000000u) { st->n_blocks_culled++; continue; }
+                vis += v & 0x1ffu; sing += (v >> 9) & 0x1ffu;
+            }
+            if (c->fc.bucket_cap) { st->n_visible = vis; st->n_singular = sing; }     // (two-pass binning counts on the device)
+        }
     }
     st->bytes_algorithmic = c->n * 148ull + c->last.n_visible * 48ull + c->last.n_pairs * 60ull +
                             (uint64_t)c->fc.W * (uint64_t)(c->fc.row_px1 - c->fc.row_px0) * 4ull;
@@ -623,8 +629,8 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     block_bounds(n, pos4, cov3d, c->h_orig, hb);
     UP_TRY(hipMalloc(&c->bounds, sizeof(BlockBounds) * hb.size()));
     UP_TRY(hipMemcpyAsync(c->bounds, hb.data(), sizeof(BlockBounds) * hb.size(), hipMemcpyHostToDevice, c->stream));
-    UP_TRY(hipMalloc(&c->culled, hb.size()));
-    UP_TRY(hipMemsetAsync(c->culled, 0, hb.size(), c->stream));
+    UP_TRY(hipMalloc(&c->culled, hb.size() * sizeof(unsigned int)));
+    UP_TRY(hipMemsetAsync(c->culled, 0, hb.size() * sizeof(unsigned int), c->stream));
     UP_TRY(hipMalloc(&d_pos, sizeof(float) * 4 * n));
     UP_TRY(hipMalloc(&d_cov, sizeof(float) * 9 * n));
     UP_TRY(hipMalloc(&d_op, sizeof(float) * n));

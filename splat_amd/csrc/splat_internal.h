@@ -70,7 +70,8 @@ void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float
 void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d);
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
                        float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
-                       const BlockBounds* bounds, unsigned char* culled /* one flag per block, written when culling */,
+                       const BlockBounds* bounds,
+                       unsigned int* blockinfo /* per block: bit 31 = skipped by culling; one-pass binning: visible | singular << 9 */,
                        FrameStatus* status);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,

@@ -331,7 +331,7 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
 // The caller has run bin_preinit() and a barrier.
 __device__ __forceinline__ void bin_bucket(BinShared& sh, bool vis, bool singular, int tx0, int tx1, int ty0, int ty1, int tiles_x,
                                            unsigned int* __restrict__ gcount, unsigned long long* __restrict__ keys,
-                                           unsigned long long key, unsigned int bcap, FrameStatus* __restrict__ status) {
+                                           unsigned long long key, unsigned int bcap, unsigned int* __restrict__ blockinfo) {
     const unsigned int tid = threadIdx.x, lane = tid & 63u;
     auto put = [&](unsigned int tile, unsigned int slot, unsigned long long k) {
         if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
@@ -378,10 +378,9 @@ __device__ __forceinline__ void bin_bucket(BinShared& sh, bool vis, bool singula
     const int bx0 = sh.box[0], by0 = sh.box[1];
     const bool any = sh.box[2] >= 0;
     const bool hashed = any && (sh.box[2] - bx0) < 64 && (sh.box[3] - by0) < 64;
-    if (tid == 0) {
-        if (sh.nvis) atomicAdd(&status->n_visible, (unsigned long long)sh.nvis);
-        if (sh.nsing) atomicAdd(&status->n_singular, (unsigned long long)sh.nsing);
-    }
+    // block statistics as a plain store (summed on the host when statistics are asked for): 5860
+    // atomics per frame on one counter are not free on the memory-side atomic unit the reservations use
+    if (tid == 0) blockinfo[blockIdx.x] = sh.nvis | (sh.nsing << 9);
     if (hashed) {
         // reserve every touched tile's run in its bucket: one returning global atomic per (block, tile)
         for (int e = (int)tid; e < AGG_CAP; e += 256) {
@@ -481,7 +480,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                                          unsigned int* __restrict__ vislist,
                                                          unsigned long long* __restrict__ keys,
                                                          const BlockBounds* __restrict__ bounds,
-                                                         unsigned char* __restrict__ culled,
+                                                         unsigned int* __restrict__ blockinfo,
                                                          FrameStatus* __restrict__ status) {
     __shared__ BinShared sh;
     __shared__ unsigned int swave[4];
@@ -491,7 +490,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     // many atomics on one counter took longer than the blocks they counted)
     if (fc.cull_blocks) {
         const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
-        if (threadIdx.x == 0) culled[blockIdx.x] = reach ? 0 : 1;
+        if (threadIdx.x == 0) blockinfo[blockIdx.x] = reach ? 0u : 0x80000000u;     // (one-pass binning overwrites a 0 with its counts)
         if (!reach) return;
     }
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -629,7 +628,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     }
     if (BUCKET) {
         const unsigned long long key = in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)orig[i]) : 0ull;
-        bin_bucket(sh, in_slab, singular, tx0, tx1, ty0, ty1, fc.tiles_x, counts, keys, key, fc.bucket_cap, status);
+        bin_bucket(sh, in_slab, singular, tx0, tx1, ty0, ty1, fc.tiles_x, counts, keys, key, fc.bucket_cap, blockinfo);
         return;
     }
     // compact the slots that reach the slab into vislist (K2 runs over those only)
@@ -1594,15 +1593,16 @@ void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* 
 }
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
                        float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
-                       const BlockBounds* bounds, unsigned char* culled, FrameStatus* status) {
+                       const BlockBounds* bounds, unsigned int* blockinfo, FrameStatus* status) {
     if (!n) return;
-    if (!bounds || !culled) fc.cull_blocks = 0;
+    if (!bounds || !blockinfo) fc.cull_blocks = 0;
+    if (!blockinfo) fc.bucket_cap = 0;
     if (fc.bucket_cap)
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth,
-                           rect, counts, vislist, keys, bounds, culled, status);
+                           rect, counts, vislist, keys, bounds, blockinfo, status);
     else
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth,
-                           rect, counts, vislist, keys, bounds, culled, status);
+                           rect, counts, vislist, keys, bounds, blockinfo, status);
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
