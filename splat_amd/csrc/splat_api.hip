@@ -114,7 +114,7 @@ struct splat_ctx {
     unsigned int grid_big = 0, grid_mid = 0, grid_long = 0;      // what the frame being enqueued uses
     FrameStatus last{};
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
-    int early_min = 512;                   // SPLAT_EARLY_MIN
+    int early_min = 768;                   // SPLAT_EARLY_MIN
     int early_scan8 = 4;                   // SPLAT_EARLY_SCAN8
     int prio_len = 0x3fffffff;             // SPLAT_PRIO_LEN
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
