@@ -197,13 +197,13 @@ __device__ __forceinline__ void expand_big(BinShared& sh, int tiles_x, F f) {
 
 // G Gaussians per thread per call: the fixed costs (bbox reduce, table zero/flush, ~6 barriers)
 // are paid once per 256*G Gaussians.
-// PREINIT: the caller has already zeroed the whole table, reset box/nbig and passed a barrier
-// (K1 does it before its long vertex stage, which saves two barriers here).
+// bin_preinit: K1<BUCKET> zeroes the table and resets box / nbig / counters before its long vertex
+// stage (bin_bucket expects that and a barrier).
 __device__ __forceinline__ void bin_preinit(BinShared& sh) {
     for (int e = (int)threadIdx.x; e < AGG_CAP; e += 256) sh.table[e] = 0;
     if (threadIdx.x == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; sh.nvis = 0; sh.nsing = 0; }
 }
-template <bool EMIT, int G, bool PREINIT = false>
+template <bool EMIT, int G>
 __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], const int (&tx0)[G], const int (&tx1)[G],
                                           const int (&ty0)[G], const int (&ty1)[G], int tiles_x,
                                           unsigned int* __restrict__ gcount, unsigned long long* __restrict__ keys,
@@ -242,10 +242,8 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
             }
         }
     };
-    if (!PREINIT) {
-        if (tid == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
-        __syncthreads();
-    }
+    if (tid == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; }
+    __syncthreads();
     {   // block bounding box of the aggregated rectangles: wave reduce, then one LDS atomic per wave
         int a = 0x7fffffff, b = 0x7fffffff, c = -1, d = -1;
 #pragma unroll
@@ -269,10 +267,8 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
     const int area = (sh.box[2] >= 0) ? bw * bh : 0;
     const bool agg = area > 0 && area <= AGG_CAP;
     if (agg) {
-        if (!PREINIT) {
-            for (int e = (int)tid; e < area; e += 256) sh.table[e] = 0;
-            __syncthreads();
-        }
+        for (int e = (int)tid; e < area; e += 256) sh.table[e] = 0;
+        __syncthreads();
 #pragma unroll
         for (int g = 0; g < G; ++g)
             each_tile(g, [&](int tx, int ty, unsigned long long) { atomicAdd(&sh.table[(ty - by0) * bw + (tx - bx0)], 1u); });
