@@ -89,6 +89,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     n, W, H, seed = WORKLOADS[args.workload]
+    # per-kernel HIP events ride on every 8th asynchronous frame by default (each record is a queue
+    # bubble); a short timed region needs them on every frame to have launches to average over
+    os.environ.setdefault("SPLAT_TIMING_EVERY", "8" if args.steps >= 64 else "1")
     R = splat_amd.Renderer(device=local)
     g = splat_amd.synthetic_scene(n, seed)
     g.compute_cov3d(R)                                   # K0 on the GPU (load-time, not timed)
