@@ -78,7 +78,9 @@ struct splat_ctx {
     // the buckets would not fit bucket_bytes, or a tile outgrew the largest LDS-sortable bucket
     bool use_buckets = true;
     bool bucket_failed = false;            // sticky until the scene / target geometry changes
-    uint64_t bucket_bytes = 8ull << 30;    // SPLAT_BUCKET_BYTES
+    uint64_t bucket_bytes = 48ull << 30;   // SPLAT_BUCKET_BYTES: all key buffers of all slots together
+    unsigned int bucket_min = 0;           // a tile outgrew a smaller bucket: buckets of at least this many keys
+    unsigned int bucket_want = 0;          // longest list of a harvested frame that overflowed its bucket
     unsigned int bucket_m = 0;             // tile count bucket_failed refers to
     uint64_t frame_idx = 0;
     int last_slot = -1;                    // buffer slot of the most recent frame (debug getters)
@@ -225,7 +227,7 @@ void harvest(splat_ctx* c, int r) {
     }
     const FrameStatus& st = c->h_status[r];
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
-    if (st.overflow == 2) c->bucket_overflow = true;
+    if (st.overflow == 2) { c->bucket_overflow = true; c->bucket_want = std::max(c->bucket_want, st.max_tile_len); }
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
     s.used = false;
@@ -285,14 +287,21 @@ uint64_t default_pair_capacity(const splat_ctx* c) {
 }
 
 // Bucket size for one-pass binning over m tiles, or 0 for the two-pass path.  A bucket never needs
-// more than n entries nor more than the LDS sort holds (16384); all buckets must fit the byte
-// budget and 32-bit list positions.
-unsigned int choose_bucket_cap(splat_ctx* c, unsigned int m) {
+// more than n entries; up to 16384 keys a list sorts in LDS, up to 65536 as four runs plus a merge
+// through a second key buffer (buckets of that size only once a frame needed them); all buffers
+// of all slots must fit the byte budget, and list positions 32 bits.
+constexpr unsigned int BUCKET_MAX = 65536;
+unsigned int choose_bucket_cap(splat_ctx* c, unsigned int m, bool* need_keys2) {
+    *need_keys2 = false;
     if (!c->use_buckets || c->cfg.pair_capacity || m == 0) return 0;
     if (c->bucket_failed && c->bucket_m == m) return 0;
     uint64_t cap = 1024;
     while (cap < 16384 && cap < c->n) cap <<= 1;
-    if ((uint64_t)m * cap * 8ull > c->bucket_bytes || (uint64_t)m * cap >= 0xFFFFFFF0ull) return 0;
+    cap = std::max<uint64_t>(cap, c->bucket_min);
+    if (cap > BUCKET_MAX) return 0;
+    *need_keys2 = cap > 16384;
+    const uint64_t bytes = (uint64_t)m * cap * 8ull * (*need_keys2 ? 2u : 1u) * (uint64_t)slots_in_use(c);
+    if (bytes > c->bucket_bytes || (uint64_t)m * cap >= 0xFFFFFFF0ull) return 0;
     return (unsigned int)cap;
 }
 
@@ -412,9 +421,15 @@ int finish_frame(splat_ctx* c) {
         return fail(c, SPLAT_ERR_CAPACITY, "more long tile lists than the sort launches covered; frame must be re-rendered");
     }
     if (c->bucket_overflow) {
+        // larger buckets (lists up to 65536 keys sort as runs + merge) if they fit, else exact lists
         c->bucket_overflow = false;
-        c->bucket_failed = true; c->bucket_m = c->n_tiles;
-        return fail(c, SPLAT_ERR_CAPACITY, "a tile outgrew its bucket; switched to two-pass binning, frame must be re-rendered");
+        uint64_t want = (((uint64_t)c->bucket_want + c->bucket_want / 4) + 1023u) & ~1023ull;   // + 25 %, in steps of 1024 keys
+        want = std::max<uint64_t>(want, 16384 + 1024);
+        if (want > BUCKET_MAX && c->bucket_want <= BUCKET_MAX) want = BUCKET_MAX;
+        c->bucket_want = 0;
+        if (want <= BUCKET_MAX) c->bucket_min = std::max<unsigned int>(c->bucket_min, (unsigned int)want);
+        else { c->bucket_failed = true; c->bucket_m = c->n_tiles; }
+        return fail(c, SPLAT_ERR_CAPACITY, "a tile outgrew its bucket; storage regrown, frame must be re-rendered");
     }
     if (c->overflow_want) {
         uint64_t want = (uint64_t)((double)c->overflow_want * 1.25) + 1024;
@@ -430,9 +445,10 @@ int slots_in_use(const splat_ctx* c) { return c->pipeline >= 3 ? 3 : (c->pipelin
 
 // Pick the binning path for a frame over m tiles and make sure its key storage exists.
 int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
-    fc->bucket_cap = choose_bucket_cap(c, m);
+    bool need2 = false;
+    fc->bucket_cap = choose_bucket_cap(c, m, &need2);
     if (fc->bucket_cap) {
-        int rc = ensure_keys(c, (uint64_t)m * fc->bucket_cap, false);
+        int rc = ensure_keys(c, (uint64_t)m * fc->bucket_cap, need2);
         if (rc == SPLAT_OK) return rc;
         if (rc != SPLAT_ERR_CAPACITY) return rc;
         c->bucket_failed = true; c->bucket_m = m;      // no room for the buckets: exact lists instead
@@ -645,7 +661,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
 #undef UP_TRY
     cleanup();
     c->n = n;
-    c->bucket_failed = false;              // key storage is sized at the first frame (prepare_binning)
+    c->bucket_failed = false; c->bucket_min = 0;   // key storage is sized at the first frame (prepare_binning)
     c->sort_hint = false;
     return SPLAT_OK;
 }

@@ -1609,7 +1609,8 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
     if (bucket_cap)
     {
         static const char* env = std::getenv("SPLAT_SCAN_THREADS");
-        static const int nt = env ? std::atoi(env) : 256;
+        // small grids: 256 threads start at once beside a busy compositor; 4K-sized ones need the width
+        const int nt = env ? std::atoi(env) : (m > 12000u ? 1024 : 256);
         if (nt == 256)
             hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(1), dim3(256), 0, s, m, counts, offsets, order, lens, status, bucket_cap,
                                grid_big, grid_mid, grid_long);

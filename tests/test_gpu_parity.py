@@ -342,23 +342,31 @@ def test_binning_paths_agree():
     assert image_diff(out["one"][0], ref)[0] <= TOL_LSB
 
 
-def test_bucket_overflow_falls_back_to_two_pass():
-    """a tile list longer than the largest bucket (16384): the frame is redone with two-pass binning"""
+def test_bucket_overflow_grows_buckets_then_falls_back_to_two_pass():
+    """a tile list longer than its bucket: the frame is redone with larger buckets (up to 65536 keys:
+    sorted as runs of 16384 + merge through the second key buffer), and with two-pass binning beyond"""
+    import os
+    forced_two_pass = os.environ.get("SPLAT_BUCKETS") == "0"
     r = splat_amd.Renderer()
     try:
-        g = splat_amd.synthetic_scene(40000, 17)
-        g.positions[:, :3] *= 0.02
-        g.compute_cov3d(r)
-        cam = make_camera(96, 96)
-        img, st, ref, ost = render_both(r, g, cam, 0.01)
-        assert st.max_tile_len > 16384 and r.binning_mode() == 0
-        assert st.n_pairs == ost.n_tile_pairs
-        assert image_diff(img, ref)[0] <= TOL_LSB
-        # a scene that fits afterwards goes back to one-pass
+        for n, want_mode in ((40000, "grown"), (130000, "two-pass")):
+            g = splat_amd.synthetic_scene(n, 17)
+            g.positions[:, :3] *= 0.02
+            g.compute_cov3d(r)
+            cam = make_camera(96, 96)
+            img, st, ref, ost = render_both(r, g, cam, 0.01)
+            assert st.max_tile_len > 16384
+            if not forced_two_pass:
+                if want_mode == "grown":
+                    assert st.max_tile_len <= 65536 and r.binning_mode() >= st.max_tile_len, (st.max_tile_len, r.binning_mode())
+                else:
+                    assert st.max_tile_len > 65536 and r.binning_mode() == 0, (st.max_tile_len, r.binning_mode())
+            assert st.n_pairs == ost.n_tile_pairs
+            assert image_diff(img, ref)[0] <= TOL_LSB
+        # a scene that fits afterwards goes back to ordinary one-pass buckets
         g2 = gpu_scene(r, 20000, 5)
         img, st, ref, ost = render_both(r, g2, make_camera(96, 96), 0.01)
-        import os
-        assert (r.binning_mode() > 0 or os.environ.get("SPLAT_BUCKETS") == "0") and image_diff(img, ref)[0] <= TOL_LSB
+        assert (0 < r.binning_mode() <= 16384 or forced_two_pass) and image_diff(img, ref)[0] <= TOL_LSB
     finally:
         r.close()
 
