@@ -119,6 +119,7 @@ struct splat_ctx {
     int early_min = 768;                   // SPLAT_EARLY_MIN
     int early_scan8 = 4;                   // SPLAT_EARLY_SCAN8
     int prio_len = 0x3fffffff;             // SPLAT_PRIO_LEN
+    unsigned int fused_sort_max = 2048;    // SPLAT_FUSED_SORT: lists up to this length are sorted inside the compositor (0: off)
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
     int pipeline = 2;                      // frames in flight on the device (SPLAT_PIPELINE = 1 | 2 | 3, see enqueue_frame)
     std::string err;
@@ -386,14 +387,14 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
     if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
         launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
     HIP_TRY(c, mark(3, ss));
-    launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status);
+    launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
     if (c->pipeline) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_ready, 0));
     }
     HIP_TRY(c, mark(5, c->stream));
-    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status);
+    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->fused_sort_max);
     HIP_TRY(c, mark(6, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
@@ -533,6 +534,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
     if (const char* e4 = std::getenv("SPLAT_PIPELINE")) { c->pipeline = std::atoi(e4); if (c->pipeline <= 1) c->pipeline = 0; if (c->pipeline > 3) c->pipeline = 3; }
     if (const char* e9 = std::getenv("SPLAT_TIMING_EVERY")) c->timing_every = std::max(1, std::atoi(e9));
+    if (const char* e13 = std::getenv("SPLAT_FUSED_SORT")) c->fused_sort_max = std::min(2048, std::max(0, std::atoi(e13)));
     if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;
     if (const char* e7 = std::getenv("SPLAT_CULL")) c->cull_blocks = std::atoi(e7) != 0;
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);

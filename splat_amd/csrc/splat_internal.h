@@ -82,10 +82,12 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
 // sort launches cover; the scan validates them against the frame's actual list lengths.
 void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
-                 FrameStatus* status);
+                 FrameStatus* status, unsigned int fused_sort_max = 0);
+// fused_sort_max: lists of up to this many keys (<= 2048) are sorted by the compositor's workgroups
+// themselves (launch_sort must be given the same value and then leaves them alone); 0 = off.
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
-                      const unsigned int* order, const unsigned int* lens, const unsigned long long* keys, const Rec* recs,
-                      uint32_t* argb, FrameStatus* status);
+                      const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
+                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max = 0);
 
 }  // namespace splat
 #endif

@@ -1091,6 +1091,40 @@ __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src,
 template <int NT, int CAP>
 constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 512) * 4; }
 
+// Sort one list of n <= CAP keys (global, at g) through this workgroup's LDS (smem: sort_lds_bytes<NT, CAP>()),
+// in place.  Used by sort_tiles_kernel and, for short lists, by the compositor's workgroup itself.
+template <int NT, int CAP>
+__device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned long long* __restrict__ g, unsigned int n,
+                                                 unsigned int radix_min, FrameStatus* __restrict__ status) {
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
+    // histograms live right behind the keys in use: a list that leaves room gets 512 bins
+    constexpr unsigned int NW = NT / 64;
+    const unsigned int keys_bytes = ((n * 8u) + 15u) & ~15u;
+    const int lb = (keys_bytes + (NW + 2u) * 512u * 4u <= sort_lds_bytes<NT, CAP>()) ? 9 : 8;
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + keys_bytes);
+    unsigned int* tot = hist + (NW << lb);
+    unsigned int* dbase = tot + (1u << lb);
+    unsigned int mn = 0xffffffffu, mx = 0u;
+    for (unsigned int t0 = threadIdx.x; t0 < n; t0 += 8u * NT) {     // eight loads in flight per thread
+        unsigned long long k[8];
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; k[u] = (t < n) ? g[t] : 0ull; }
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) {
+            const unsigned int t = t0 + u * NT;
+            if (t < n) { s[t] = k[u]; mn = min(mn, (unsigned int)(k[u] >> 32)); mx = max(mx, (unsigned int)(k[u] >> 32)); }
+        }
+    }
+    if (n <= radix_min) {
+        __syncthreads();
+        bitonic_sort(s, n, threadIdx.x, NT);   // few steps: cheaper than the radix passes
+    } else {
+        const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, false, lb);   // (its barriers publish s[])
+        sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl);
+    }
+    for (unsigned int t = threadIdx.x; t < n; t += NT) g[t] = s[t];
+}
+
 // One workgroup per tile; a launch handles the lists with lo < n <= CAP (three size classes, so
 // that mid-sized lists get two workgroups per CU instead of one LDS-filling one).
 // chunks > 0 (the 1024-thread class): a list of up to chunks * CAP keys is sorted as that many
@@ -1106,7 +1140,6 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
                                                          unsigned int radix_min, int chunks, unsigned int grid0,
                                                          unsigned int grid_long) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
     if (status->overflow) return;
     // workgroups [0, grid0) take run 0 of the first grid0 lists; the next 3 * grid_long ones take runs
     // 1..3 of the first grid_long lists (those >= 16384 keys are a prefix of the longest-first order)
@@ -1125,36 +1158,14 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
     } else if (chunk != 0) {
         return;
     }
-    // histograms live right behind the keys in use: a list that leaves room gets 512 bins
-    constexpr unsigned int NW = NT / 64;
-    const unsigned int keys_bytes = ((min(n, (unsigned int)CAP) * 8u) + 15u) & ~15u;
-    const int lb = (keys_bytes + (NW + 2u) * 512u * 4u <= sort_lds_bytes<NT, CAP>()) ? 9 : 8;
-    unsigned int* hist = reinterpret_cast<unsigned int*>(smem + keys_bytes);
-    unsigned int* tot = hist + (NW << lb);
-    unsigned int* dbase = tot + (1u << lb);
     if (n <= (unsigned int)CAP) {
-        unsigned int mn = 0xffffffffu, mx = 0u;
-        for (unsigned int t0 = threadIdx.x; t0 < n; t0 += 8u * NT) {     // eight loads in flight per thread
-            unsigned long long k[8];
-#pragma unroll
-            for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; k[u] = (t < n) ? keys[b + t] : 0ull; }
-#pragma unroll
-            for (unsigned int u = 0; u < 8; ++u) {
-                const unsigned int t = t0 + u * NT;
-                if (t < n) { s[t] = k[u]; mn = min(mn, (unsigned int)(k[u] >> 32)); mx = max(mx, (unsigned int)(k[u] >> 32)); }
-            }
-        }
-        if (n <= radix_min) {
-            __syncthreads();
-            bitonic_sort(s, n, threadIdx.x, NT);   // few steps: cheaper than the radix passes
-        } else {
-            const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, false, lb);   // (its barriers publish s[])
-            sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl);
-        }
-        for (unsigned int t = threadIdx.x; t < n; t += NT) keys[b + t] = s[t];
+        sort_list_in_lds<NT, CAP>(smem, keys + b, n, radix_min, status);
     } else if (chunks) {
         // longer than chunks * CAP: radix passes over the L2-resident bucket, then the same tie fix-up
         unsigned long long* g = keys + b;
+        unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)CAP * 8);
+        unsigned int* tot = hist + (NT / 64) * 256;
+        unsigned int* dbase = tot + 256;
         unsigned int mn = 0xffffffffu, mx = 0u;
         for (unsigned int t = threadIdx.x; t < n; t += NT) {
             const unsigned int d = (unsigned int)(g[t] >> 32);
@@ -1320,16 +1331,28 @@ struct WaveLds { float4 a[64]; float4 b[64]; float4 c[64]; };   // one batch of 
 __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned int* __restrict__ lens,
-                                                              const unsigned long long* __restrict__ keys,
+                                                              unsigned long long* __restrict__ keys,
                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
-                                                              FrameStatus* __restrict__ status) {
-    __shared__ WaveLds slds[4];
+                                                              FrameStatus* __restrict__ status, unsigned int fused_sort_max,
+                                                              unsigned int radix_min) {
+    // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
+    // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
+    // their own -- the short lists are most of the tiles, and their sort then runs beside the next
+    // frame's K1 like the rest of this kernel instead of in the phase where the chip idles), then the
+    // four waves' private record batches.
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
+    static_assert(sizeof(WaveLds) * 4 <= sort_lds_bytes<256, 2048>(), "staging fits the sort workspace");
+    WaveLds* slds = reinterpret_cast<WaveLds*>(smem);
     if (status->overflow) return;
     const unsigned int tile = order[blockIdx.x];
     const unsigned int tid = threadIdx.x;
     const unsigned int beg = __builtin_amdgcn_readfirstlane(offsets[tile]);
     const unsigned int end = beg + __builtin_amdgcn_readfirstlane(lens[tile]);
     if (beg == end) return;
+    if (end - beg >= 2u && end - beg <= fused_sort_max) {
+        sort_list_in_lds<256, 2048>(smem, keys + beg, end - beg, radix_min, status);
+        __syncthreads();          // the sorted list is in global memory, the LDS is free for the batches
+    }
     const unsigned int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     // The longest lists are the critical path of the launch: let their waves win VALU arbitration
     // against the short-list waves that share their SIMD (priority 0..3 by list length).
@@ -1579,6 +1602,11 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
 // ---------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------
+static unsigned int sort_radix_min() {
+    static const char* rm = std::getenv("SPLAT_SORT_RADIX_MIN");     // lists up to this length use the bitonic network
+    static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
+    return radix_min;
+}
 static inline unsigned int blocks_for(uint64_t n, unsigned int bs) { return (unsigned int)((n + bs - 1) / bs); }
 
 void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
@@ -1632,7 +1660,7 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
 }
 void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
-                 FrameStatus* status) {
+                 FrameStatus* status, unsigned int fused_sort_max) {
     if (!n_tiles) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1642,8 +1670,7 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
                                   hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds_bytes<512, 8192>());
         attr_set = true;
     }
-    static const char* rm = std::getenv("SPLAT_SORT_RADIX_MIN");     // lists up to this length use the bitonic network
-    static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
+    const unsigned int radix_min = sort_radix_min();
     // longest class first (the tiles are ordered longest-first too)
     grid_big = std::min(grid_big, n_tiles); grid_mid = std::min(grid_mid, n_tiles);
     if (grid_big) {
@@ -1659,12 +1686,13 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
     if (grid_mid)
     hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(grid_mid), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
                        lens, keys, keys2, status, 2048u, radix_min, 0, 0u, 1u);
-    hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
-                       lens, keys, keys2, status, 0u, radix_min, 0, 0u, 1u);
+    if (fused_sort_max < 2048u)      // (lists up to fused_sort_max are sorted by the compositor's own workgroups)
+        hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
+                           lens, keys, keys2, status, fused_sort_max, radix_min, 0, 0u, 1u);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
-                      const unsigned int* order, const unsigned int* lens, const unsigned long long* keys, const Rec* recs,
-                      uint32_t* argb, FrameStatus* status) {
+                      const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
+                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
@@ -1672,7 +1700,8 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
     static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
     static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
-    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status);
+    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status,
+                       fused_sort_max, sort_radix_min());
 }
 
 }  // namespace splat
