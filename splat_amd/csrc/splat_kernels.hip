@@ -1284,13 +1284,17 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 // compensated product, v_exp_f32 on the fractional part, ldexp) without its overflow/underflow
 // selects -- x is a Gaussian exponent, <= 0 and far above -100 wherever the result is used.
 __device__ __forceinline__ float exp_neg(float x) {
+    // x * log2(e) as an unevaluated sum ph + pl (compensated product); v_exp_f32 takes the rounded part
+    // whole -- it does its own range reduction and x is a Gaussian exponent (<= 0, far above -100
+    // wherever the result is used), so ocml's integer / fraction split, its ldexp and its range
+    // selects are not needed -- and the residual enters to first order: 2^(ph+pl) = 2^ph (1 + pl ln 2).
     const float L2E_HI = __uint_as_float(0x3fb8aa3bu), L2E_LO = __uint_as_float(0x32a5705fu);
+    const float LN2 = 0.6931471805599453f;
     float ph = x * L2E_HI;
-    float e = rintf(ph);
     float pl = fmaf(x, L2E_HI, -ph);
     pl = fmaf(x, L2E_LO, pl);
-    float a = (ph - e) + pl;
-    return ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+    const float e = __builtin_amdgcn_exp2f(ph);
+    return fmaf(e * pl, LN2, e);
 }
 
 // k / 255.0f (IEEE) for every integer k in [0,255] in two instructions: 1/255 split into
