@@ -1404,16 +1404,20 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         const float a = r.b.x, b = r.b.y, c = r.b.z;
         if (!(a > 0.0f && c > 0.0f && a * c - b * b > 0.0f)) return true;      // not positive definite: keep
         const float x0 = xlo - r.a.x, x1 = xhi - r.a.x, y0 = r.a.y - yhi, y1 = r.a.y - ylo;
-        float qmin = 0.0f;
-        if (!(x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f)) {
-            auto q = [&](float x, float y) { return a * x * x + 2.0f * b * x * y + c * y * y; };
-            auto cl = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
-            // (v_rcp, 1 ulp: this is a bound with a 1e-3 margin, not the reference's arithmetic --
-            // four IEEE divisions were a third of the staging instructions)
-            const float nbc = -b * __builtin_amdgcn_rcpf(c), nba = -b * __builtin_amdgcn_rcpf(a);
-            qmin = fminf(fminf(q(x0, cl(nbc * x0, y0, y1)), q(x1, cl(nbc * x1, y0, y1))),
-                         fminf(q(cl(nba * y0, x0, x1), y0), q(cl(nba * y1, x0, x1), y1)));
-        }
+        // q is convex with its minimum (0) at the centre: over the rectangle the minimum is 0 if the centre
+        // is inside, else it lies on an edge that FACES the centre (from any point of a far edge q
+        // decreases along the segment towards the centre, which starts inside the rectangle) -- at most
+        // one vertical and one horizontal edge, each minimised in closed form along its length.
+        auto q = [&](float x, float y) { return a * x * x + 2.0f * b * x * y + c * y * y; };
+        auto cl = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+        // (v_rcp, 1 ulp: this is a bound with a 1e-3 margin, not the reference's arithmetic)
+        const float nbc = -b * __builtin_amdgcn_rcpf(c), nba = -b * __builtin_amdgcn_rcpf(a);
+        const bool xin = x0 <= 0.0f && x1 >= 0.0f, yin = y0 <= 0.0f && y1 >= 0.0f;
+        const float ex = (x0 > 0.0f) ? x0 : x1, ey = (y0 > 0.0f) ? y0 : y1;      // the facing edges (when the interval excludes 0)
+        const float qv = q(ex, cl(nbc * ex, y0, y1)), qh = q(cl(nba * ey, x0, x1), ey);
+        const float big = 3.0e38f;
+        float qmin = fminf(xin ? big : qv, yin ? big : qh);
+        if (xin && yin) qmin = 0.0f;
         const float pmax = -0.5f * qmin;
         return !(pmax + 1e-3f * (1.0f + fabsf(pmax)) < r.c.w);
     };
