@@ -443,6 +443,25 @@ def test_streamed_frames_equal_synchronous_frames(R):
         R.stream_wait(np.zeros((H, W), np.uint32))      # a buffer no frame was streamed to
 
 
+def test_timing_is_sampled_on_asynchronous_frames(R):
+    """per-kernel HIP events ride on every n-th asynchronous frame (default 8) and on every frame rendered
+    with statistics; splat_get_timing reports how many frames carried them"""
+    import torch
+    g = gpu_scene(R, 20000, 3)
+    R.upload(g)
+    cam = make_camera(128, 160).to_c(0.01)
+    img = torch.zeros((128, 160), dtype=torch.int32, device="cuda")
+    R.render_device(cam, img.data_ptr(), sync=True)
+    R.timing(reset=True)
+    for _ in range(32):
+        R.render_device(cam, img.data_ptr())
+    ms, frames = R.timing(reset=True)
+    assert 2 <= frames <= 32 and ms["composite"] > 0 and ms["preprocess"] > 0, (frames, ms)
+    st = R.render_device(cam, img.data_ptr(), sync=True, want_stats=True)
+    ms, frames = R.timing(reset=True)
+    assert frames == 1 and st.ms_composite > 0 and abs(ms["composite"] - st.ms_composite) < 1e-3
+
+
 def test_slabs_equal_full_frame(R):
     """multi-GPU decomposition: tile-row slabs rendered separately == the full frame, byte for byte"""
     g = gpu_scene(R, 30000, 19)
