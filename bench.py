@@ -174,6 +174,7 @@ def main():
         dist.all_reduce(comp, op=dist.ReduceOp.MAX)
 
     slab_check = None
+    exit_code, parity_ok = 0, True
     if world > 1 and rank == 0:
         # the gathered frame must equal the frame this rank renders alone, byte for byte
         R.set_slab(0, -1)
@@ -236,6 +237,8 @@ def main():
         }
         if slab_check is not None:
             out["multi_gpu_frame_equals_single_gpu_frame"] = slab_check
+            if not slab_check:
+                exit_code = 3
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or (os.cpu_count() or 1)
             ref, ost, cdt = cpu_baseline(g, poses[(frame_no[0] - 1) % len(poses)], threads)
@@ -247,12 +250,24 @@ def main():
                                              "preprocess %.0f ms, sort %.0f ms, raster %.0f ms)" %
                                              (ost.ms_preprocess, ost.ms_sort, ost.ms_raster)}
             out["parity"] = {"max_channel_diff_lsb": int(d.max()), "pixels_differing": int((d.max(0) > 0).sum()),
-                             "pixels": int(W * H), "fragments": int(ost.n_fragments)}
+                             "pixels": int(W * H), "fragments": int(ost.n_fragments),
+                             "pairs_equal": bool(int(tot[1]) == int(ost.n_tile_pairs) and int(tot[0]) == int(ost.n_visible)),
+                             "tolerance_lsb": 1,
+                             "against": "oracle/ (C++ restatement of src/gaussians.rs + src/pipelines.rs + src/camera.rs); "
+                                        "euc conventions ASSUMED, not pinned: y_up=1 from notes/screenshot.png (contradicts "
+                                        "SURVEY appendix B's recollection of CoordinateMode::VULKAN = y down), pixel-centre "
+                                        "samples, z-clip [0,1], inclusive rectangle -- euc@290e14c is not in the image"}
+            parity_ok = out["parity"]["max_channel_diff_lsb"] <= 1 and out["parity"]["pairs_equal"]
         print(json.dumps(out))
+        if not parity_ok:
+            sys.stderr.write("bench.py: PARITY MISS against the oracle: %s\n" % json.dumps(out["parity"]))
+            exit_code = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     R.close()
+    if exit_code:
+        sys.exit(exit_code)       # a fast frame that is not the reference's frame is not a result
 
 
 if __name__ == "__main__":

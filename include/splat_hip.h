@@ -75,8 +75,9 @@ typedef struct {
     uint64_t n_fallback;   /* compositor waves whose early-out could not be proven exact and were redone in full */
     uint64_t n_sort_fallback; /* tiles re-sorted by the exact bitonic network because depth ties were out of index order */
     uint64_t n_iter_scan;  /* compositor (wave, record) iterations spent in the front-to-back scan           */
-    uint64_t n_iter_blend; /* ... and in exact blending                                                      */
+    uint64_t n_iter_blend; /* ... and in exact blending (both measured on the frame the stats belong to)     */
     uint64_t n_blocks_culled; /* 256-Gaussian blocks K1 skipped: bounds cannot reach the slab / target      */
+    uint64_t flops_algorithmic; /* sum over pixels of (its tile's list length) * 25  */
 } splat_stats;
 
 /* Projected per-Gaussian record as the kernels keep it (debug / stage parity). */
@@ -117,12 +118,22 @@ int splat_tile_row_loads(splat_ctx* ctx, const splat_camera* cam, uint64_t* row_
  * Frames alternate between two device images, so frame N+1 renders while frame N crosses PCIe.
  * `argb_out` is complete after splat_stream_wait(ctx, argb_out) (or splat_sync); give each frame
  * in flight its own buffer, ideally pinned (splat_host_alloc) -- a pageable one works but the
- * copy then blocks the calling thread.  SPLAT_ERR_CAPACITY from the wait means the frame was
- * skipped on the device (storage has been grown): render it again. */
+ * copy then blocks the calling thread.  A streamed frame that outgrew its storage on the device (tile
+ * bucket, pair buffer, sort launch sizes: all sized from earlier frames) is detected by the wait, which
+ * grows the storage and renders that frame again into `argb_out` before it returns: a viewer loop never
+ * sees the miss (splat_frames_dropped() counts them). */
 int splat_render_stream(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb_out);
 int splat_stream_wait(splat_ctx* ctx, const uint32_t* argb_out);
 void* splat_host_alloc(uint64_t bytes);      /* page-locked host memory (hipHostMalloc); NULL on failure */
 void splat_host_free(void* p);
+
+/* Device images for callers without a HIP toolchain of their own (a Rust/C host using
+ * splat_render_device): plain allocations on the context's GPU, and copies ordered on the context's
+ * stream (the copy functions return when the data has arrived). */
+void* splat_device_alloc(splat_ctx* ctx, uint64_t bytes);          /* NULL on failure (splat_last_error) */
+void splat_device_free(splat_ctx* ctx, void* d_ptr);
+int splat_device_upload(splat_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
+int splat_device_download(splat_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
 
 /* render_to_buffer: blends the scene onto `argb` (in/out, host, w*h u32).  stats may be NULL. */
 int splat_render(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb, splat_stats* stats);
@@ -131,7 +142,12 @@ int splat_render(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb, splat_
  * context's stream; with sync != 0 (or stats != NULL) the call waits for completion. */
 int splat_render_device(splat_ctx* ctx, const splat_camera* cam, void* d_argb, int32_t sync,
                         splat_stats* stats);
-int splat_sync(splat_ctx* ctx);                       /* wait + report deferred errors */
+/* Wait for everything enqueued.  SPLAT_ERR_CAPACITY: an asynchronous frame (splat_render_device with
+ * sync == 0) was skipped on the device because it outgrew its storage -- its image was left untouched and
+ * the storage has been grown: render it again.  Reported once.  A synchronous render redoes its OWN frame
+ * internally and never returns this code for a frame that composited. */
+int splat_sync(splat_ctx* ctx);
+uint64_t splat_frames_dropped(const splat_ctx* ctx);  /* frames skipped on the device since splat_create (redone or reported) */
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */
 /* Run on a caller-owned hipStream_t (e.g. the stream a device image / RCCL gather lives on). */
 int splat_set_stream(splat_ctx* ctx, void* hip_stream);

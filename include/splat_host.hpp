@@ -90,6 +90,10 @@ public:
     // queued; the pixels are in `color` after wait_frame(color).  Keep two buffers in flight
     // (pinned ones from alloc_frame make the copy truly asynchronous).
     void wait_frame(const uint32_t* color);
+    // The scene is uploaded to the GPU once, at the first frame, and cached (the reference re-reads its
+    // public `gaussians` field on every render_to_buffer, src/pipelines.rs:67-79).  After mutating
+    // `gaussians` (edits, compute_cov3d after the first frame, ...) call this: the next frame uploads again.
+    void invalidate_scene() { uploaded_ = nullptr; }
     static uint32_t* alloc_frame(size_t pixels);
     static void free_frame(uint32_t* p);
 protected:

@@ -27,7 +27,7 @@ class Stats(C.Structure):
                 ("ms_preprocess", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float),
                 ("ms_sort", C.c_float), ("ms_composite", C.c_float), ("ms_total", C.c_float),
                 ("n_fallback", C.c_uint64), ("n_sort_fallback", C.c_uint64), ("n_iter_scan", C.c_uint64), ("n_iter_blend", C.c_uint64),
-                ("n_blocks_culled", C.c_uint64)]
+                ("n_blocks_culled", C.c_uint64), ("flops_algorithmic", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -54,6 +54,7 @@ SYMBOLS = [
     ("splat_render", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
     ("splat_render_device", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     ("splat_sync", C.c_int, [C.c_void_p]),
+    ("splat_frames_dropped", C.c_uint64, [C.c_void_p]),
     ("splat_stream", C.c_void_p, [C.c_void_p]),
     ("splat_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("splat_get_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),
@@ -63,6 +64,10 @@ SYMBOLS = [
     ("splat_binning_mode", C.c_int64, [C.c_void_p]),
     ("splat_render_stream", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p]),
     ("splat_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("splat_device_alloc", C.c_void_p, [C.c_void_p, C.c_uint64]),
+    ("splat_device_free", None, [C.c_void_p, C.c_void_p]),
+    ("splat_device_upload", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    ("splat_device_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     ("splat_host_alloc", C.c_void_p, [C.c_uint64]),
     ("splat_host_free", None, [C.c_void_p]),
 ]

@@ -96,6 +96,8 @@ struct splat_ctx {
     const uint32_t* s_dst[2] = {nullptr, nullptr};
     bool s_used[2] = {false, false};
     uint64_t s_idx = 0;
+    int s_ring[2] = {-1, -1};              // event-ring entry of the frame each streaming image holds
+    splat_camera s_cam[2] = {};            // ... and its camera (a frame skipped on the device is redone by splat_stream_wait)
     // slab
     int slab0 = 0, slab1 = -1;
     // timing
@@ -115,6 +117,14 @@ struct splat_ctx {
     unsigned int hint_ge8192 = 0, hint_ge2048 = 0, hint_ge16384 = 0;
     unsigned int grid_big = 0, grid_mid = 0, grid_long = 0;      // what the frame being enqueued uses
     FrameStatus last{};
+    // frames skipped on the device (their storage outgrown: see finish_frame).  A synchronous call redoes its own
+    // frame; a lost ASYNCHRONOUS frame is reported once, by the next splat_sync / splat_stream_wait
+    uint64_t frames_dropped = 0, frames_drop_reported = 0;
+    bool deferred_drop = false;
+    bool tight_grids = false;              // SPLAT_DBG_TIGHT_GRIDS: sort launches sized with no margin (tests force a miss)
+    uint2* d_iters = nullptr;              // per compositor wave: (scan, blend) iterations of a frame rendered with stats
+    unsigned int iters_alloc = 0;
+    bool iters_valid = false;
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
     int early_min = 768;                   // SPLAT_EARLY_MIN
     int early_scan8 = 4;                   // SPLAT_EARLY_SCAN8
@@ -227,6 +237,7 @@ void harvest(splat_ctx* c, int r) {
         c->acc_frames++;
     }
     const FrameStatus& st = c->h_status[r];
+    if (st.overflow) c->frames_dropped++;
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) { c->bucket_overflow = true; c->bucket_want = std::max(c->bucket_want, st.max_tile_len); }
     if (st.overflow == 3) c->sort_grid_miss = true;
@@ -343,7 +354,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
 // drains its queue for a few microseconds -- nine of them per frame were ~25 us of bubbles in a
 // 590 us frame -- so untimed frames (all but every `timing_every`-th of an asynchronous run) record
 // only the one event that tells the host the frame's status has arrived.
-int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
+int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = false) {
     const int r = c->ring_next;
     EvSet& ev = c->ring[r];
     auto mark = [&](int k, hipStream_t st) -> hipError_t { return timed ? hipEventRecord(ev.e[k], st) : hipSuccess; };
@@ -368,7 +379,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
     // (the slot's status is zero: cleared behind the read-back of the frame that used it last)
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, s.d_status);
     HIP_TRY(c, mark(1, bs));
-    if (c->sort_hint) {
+    if (c->sort_hint && c->tight_grids) {
+        c->grid_big = c->hint_ge8192; c->grid_mid = c->hint_ge2048; c->grid_long = c->hint_ge16384;
+    } else if (c->sort_hint) {
         // generous: an asynchronous frame that misses is lost (reported at the next sync), idle extra
         // workgroups of a launch that has the chip to itself cost next to nothing
         c->grid_big = std::min<uint64_t>(m, 2ull * c->hint_ge8192 + 32);
@@ -394,7 +407,19 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_ready, 0));
     }
     HIP_TRY(c, mark(5, c->stream));
-    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->fused_sort_max);
+    uint2* iters = nullptr;
+    c->iters_valid = false;
+    if (want_iters) {       // statistics frame: every compositor wave leaves its iteration counts (plain stores)
+        if (c->iters_alloc < m * 4u) {
+            dfree(c->d_iters); c->iters_alloc = 0;
+            HIP_TRY(c, hipMalloc(&c->d_iters, sizeof(uint2) * (size_t)m * 4u));
+            c->iters_alloc = m * 4u;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_iters, 0, sizeof(uint2) * (size_t)m * 4u, c->stream));
+        iters = c->d_iters;
+        c->iters_valid = true;
+    }
+    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->fused_sort_max, iters);
     HIP_TRY(c, mark(6, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
@@ -410,16 +435,23 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed) {
     return SPLAT_OK;
 }
 
-// Wait for everything enqueued; returns SPLAT_ERR_CAPACITY (after growing the pair buffer) if a
-// frame overflowed it -- that frame's composite was skipped and it must be rendered again.
-int finish_frame(splat_ctx* c) {
+// Wait for everything enqueued and harvest every frame's status.  Returns SPLAT_ERR_CAPACITY when at
+// least one harvested frame was skipped on the device because it outgrew its storage (pair buffer, tile
+// bucket, sort launch sizes): the storage / hints have then been grown for the next attempt.
+// *last_skipped tells whether the MOST RECENT frame is among the skipped ones -- only that one may be
+// redone by a synchronous caller (an older asynchronous frame that was lost must not make the current,
+// complete frame blend a second time onto the in/out image).
+int finish_frame(splat_ctx* c, bool* last_skipped = nullptr) {
+    if (last_skipped) *last_skipped = false;
     int rc = sync_all(c);
     if (rc != SPLAT_OK) return rc;
     if (c->last_ring >= 0) c->last = c->h_status[c->last_ring];
+    if (last_skipped) *last_skipped = c->last_ring >= 0 && c->last.overflow != 0;
     for (int k = 0; k < EV_RING; ++k) harvest(c, k);
+    const char* msg = nullptr;
     if (c->sort_grid_miss) {            // the hint has been refreshed from the frame that missed
         c->sort_grid_miss = false;
-        return fail(c, SPLAT_ERR_CAPACITY, "more long tile lists than the sort launches covered; frame must be re-rendered");
+        msg = "more long tile lists than the sort launches covered; frame must be re-rendered";
     }
     if (c->bucket_overflow) {
         // larger buckets (lists up to 65536 keys sort as runs + merge) if they fit, else exact lists
@@ -430,16 +462,37 @@ int finish_frame(splat_ctx* c) {
         c->bucket_want = 0;
         if (want <= BUCKET_MAX) c->bucket_min = std::max<unsigned int>(c->bucket_min, (unsigned int)want);
         else { c->bucket_failed = true; c->bucket_m = c->n_tiles; }
-        return fail(c, SPLAT_ERR_CAPACITY, "a tile outgrew its bucket; storage regrown, frame must be re-rendered");
+        msg = "a tile outgrew its bucket; storage regrown, frame must be re-rendered";
     }
     if (c->overflow_want) {
         uint64_t want = (uint64_t)((double)c->overflow_want * 1.25) + 1024;
         c->overflow_want = 0;
         rc = ensure_keys(c, want, true);
         if (rc != SPLAT_OK) return rc;
-        return fail(c, SPLAT_ERR_CAPACITY, "pair buffer overflowed; capacity grown, frame must be re-rendered");
+        msg = "pair buffer overflowed; capacity grown, frame must be re-rendered";
     }
-    return SPLAT_OK;
+    return msg ? fail(c, SPLAT_ERR_CAPACITY, msg) : SPLAT_OK;
+}
+
+// For the entry points that only wait (splat_sync, splat_get_*, ...): a skipped frame -- found now or left
+// pending by a synchronous render that was itself complete -- is reported once.
+int finish_and_report(splat_ctx* c) {
+    int rc = finish_frame(c);
+    c->frames_drop_reported = c->frames_dropped;
+    if (rc == SPLAT_OK && c->deferred_drop) {
+        c->deferred_drop = false;
+        return fail(c, SPLAT_ERR_CAPACITY, "an earlier asynchronous frame was skipped on the device (storage has been grown); render it again");
+    }
+    if (rc == SPLAT_ERR_CAPACITY) c->deferred_drop = false;
+    return rc;
+}
+
+// ... and for the ones that must quiesce the device on the way to something else (re-allocation, a count-only
+// pass): a loss found here stays pending for the next report.
+int finish_quiet(splat_ctx* c) {
+    int rc = finish_frame(c);
+    if (rc == SPLAT_ERR_CAPACITY) { c->deferred_drop = true; rc = SPLAT_OK; }
+    return rc;
 }
 
 int slots_in_use(const splat_ctx* c) { return c->pipeline >= 3 ? 3 : (c->pipeline ? 2 : 1); }
@@ -467,8 +520,7 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->max_tile_len = c->last.max_tile_len;
     st->n_fallback = c->last.n_fallback;
     st->n_sort_fallback = c->last.n_sort_fallback;
-    st->n_iter_scan = c->last.n_iter_scan;
-    st->n_iter_blend = c->last.n_iter_blend;
+    st->n_iter_scan = 0; st->n_iter_blend = 0;
     st->n_blocks_culled = 0;
     if (c->culled && c->last_ring >= 0 && (c->fc.cull_blocks || c->fc.bucket_cap)) {   // the frame has finished: sum its block words
         std::vector<unsigned int> f((c->n + 255) / 256);
@@ -481,8 +533,30 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
             if (c->fc.bucket_cap) { st->n_visible = vis; st->n_singular = sing; }     // (two-pass binning counts on the device)
         }
     }
-    st->bytes_algorithmic = c->n * 148ull + c->last.n_visible * 48ull + c->last.n_pairs * 60ull +
+    // (one-pass binning counts the visible Gaussians in the block words summed above, not on the device)
+    st->bytes_algorithmic = c->n * 148ull + st->n_visible * 48ull + c->last.n_pairs * 60ull +
                             (uint64_t)c->fc.W * (uint64_t)(c->fc.row_px1 - c->fc.row_px0) * 4ull;
+    // flops_alg = sum over pixels of (its tile's list length) * 25, and the compositor's
+    // measured (wave, record) iterations -- left by every wave of a frame rendered with a stats pointer
+    if (c->last_slot >= 0 && c->last_ring >= 0 && c->n_tiles) {
+        const Slot& sl = c->slots[c->last_slot];
+        const size_t m = c->n_tiles;
+        std::vector<unsigned int> len(m);
+        if (c->last.overflow == 0 && hipMemcpy(len.data(), sl.lens, sizeof(unsigned int) * m, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint64_t f = 0;
+            for (size_t t = 0; t < m; ++t) {
+                const int tx = (int)(t % (size_t)c->fc.tiles_x), ty = (int)(t / (size_t)c->fc.tiles_x) + c->fc.tile_row0;
+                const int pw = std::min(TILE, c->fc.W - tx * TILE), ph = std::min(TILE, std::min(c->fc.H, c->fc.row_px1) - ty * TILE);
+                if (pw > 0 && ph > 0) f += (uint64_t)len[t] * (uint64_t)(pw * ph);
+            }
+            st->flops_algorithmic = f * 25ull;
+        }
+        if (c->iters_valid && c->d_iters) {
+            std::vector<uint2> it(m * 4u);
+            if (hipMemcpy(it.data(), c->d_iters, sizeof(uint2) * it.size(), hipMemcpyDeviceToHost) == hipSuccess)
+                for (const uint2& v : it) { st->n_iter_scan += v.x; st->n_iter_blend += v.y; }
+        }
+    }
     float t[N_TIMES] = {0};
     if (c->last_ring >= 0 && c->ring[c->last_ring].timed) ev_times(c->ring[c->last_ring], t);   // events stay valid after harvest
     st->ms_preprocess = t[0]; st->ms_scan = t[1]; st->ms_emit = t[2]; st->ms_sort = t[3]; st->ms_composite = t[4];
@@ -537,6 +611,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e13 = std::getenv("SPLAT_FUSED_SORT")) c->fused_sort_max = std::min(2048, std::max(0, std::atoi(e13)));
     if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;
     if (const char* e7 = std::getenv("SPLAT_CULL")) c->cull_blocks = std::atoi(e7) != 0;
+    if (const char* e8 = std::getenv("SPLAT_DBG_TIGHT_GRIDS")) c->tight_grids = std::atoi(e8) != 0;
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
@@ -544,6 +619,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         return SPLAT_ERR_HIP;
     };
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = init_device_kernels()) != hipSuccess) return bail("hipFuncSetAttribute", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->own_stream = true;
     {   // the binning stream gets the highest priority: a separate hardware queue from the caller's
@@ -584,7 +660,7 @@ void splat_destroy(splat_ctx* c) {
         if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);
         if (s.ev_free) (void)hipEventDestroy(s.ev_free);
     }
-    dfree(c->d_img);
+    dfree(c->d_img); dfree(c->d_iters);
     for (int k = 0; k < 2; ++k) {
         dfree(c->s_img[k]);
         if (c->s_rendered[k]) (void)hipEventDestroy(c->s_rendered[k]);
@@ -607,7 +683,7 @@ void* splat_stream(splat_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int splat_set_stream(splat_ctx* c, void* stream) {
     if (!c) return SPLAT_ERR_INVALID;
-    int rc = finish_frame(c);
+    int rc = finish_quiet(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
@@ -620,7 +696,8 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     if (n && (!pos4 || !cov3d || !opacity || !sh)) return fail(c, SPLAT_ERR_INVALID, "NULL scene pointer");
     if (n >= 0xFFFFFFFFull) return fail(c, SPLAT_ERR_INVALID, "too many Gaussians (index is 32-bit)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    (void)finish_frame(c);
+    (void)finish_frame(c);          // (frames of the scene being replaced: nothing left to redo)
+    c->deferred_drop = false; c->frames_drop_reported = c->frames_dropped;
     int rc = sync_all(c);
     if (rc != SPLAT_OK) return rc;
     free_scene(c);
@@ -703,8 +780,8 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     if (!c) return SPLAT_ERR_INVALID;
     if (!row_pairs) return fail(c, SPLAT_ERR_INVALID, "row_pairs is NULL");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    int rc = finish_frame(c);
-    if (rc != SPLAT_OK && rc != SPLAT_ERR_CAPACITY) return rc;
+    int rc = finish_quiet(c);
+    if (rc != SPLAT_OK) return rc;
     const int s0 = c->slab0, s1 = c->slab1;
     c->slab0 = 0; c->slab1 = -1;
     FrameConst fc; unsigned int nt = 0;
@@ -750,13 +827,26 @@ int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int
         rc = prepare_binning(c, c->n_tiles, &c->fc);
         if (rc != SPLAT_OK) return rc;
         const bool timed = stats != nullptr || c->timing_every <= 1 || (c->frame_idx % (uint64_t)c->timing_every) == 0;
-        rc = enqueue_frame(c, (uint32_t*)d_argb, timed);
+        rc = enqueue_frame(c, (uint32_t*)d_argb, timed, stats != nullptr);
         if (rc != SPLAT_OK) return rc;
         if (!sync && !stats) return SPLAT_OK;
-        rc = finish_frame(c);
-        // the frame was skipped on the device; its storage has been grown / its path switched: redo
-        if (rc == SPLAT_ERR_CAPACITY && (c->fc.bucket_cap || c->last.overflow == 3 || c->cap > c->last.n_pairs)) continue;
-        break;
+        bool skipped = false;
+        rc = finish_frame(c, &skipped);
+        {   // frames lost besides this one (older asynchronous frames) are reported by the next splat_sync
+            const uint64_t pending = c->frames_dropped - c->frames_drop_reported;
+            if (pending > (skipped ? 1u : 0u)) c->deferred_drop = true;
+            c->frames_drop_reported = c->frames_dropped;
+        }
+        if (rc != SPLAT_ERR_CAPACITY) break;
+        if (!skipped) {
+            // THIS frame composited; what was lost is an older asynchronous frame.  Redoing the frame would
+            // blend it onto the in/out image a second time: report the loss at the next splat_sync instead.
+            c->deferred_drop = true;
+            rc = SPLAT_OK;
+            break;
+        }
+        // this frame was skipped on the device; its storage has been grown / its path switched: redo
+        if (!(c->fc.bucket_cap || c->last.overflow == 3 || c->cap > c->last.n_pairs)) break;
     }
     if (rc != SPLAT_OK) return rc;
     if (stats) fill_stats(c, stats);
@@ -772,7 +862,7 @@ int splat_render(splat_ctx* c, const splat_camera* cam, uint32_t* argb, splat_st
     if (rc != SPLAT_OK) return rc;
     size_t bytes = (size_t)fc.W * fc.H * 4;
     if (bytes > c->img_cap) {
-        (void)finish_frame(c);
+        (void)finish_quiet(c);
         dfree(c->d_img); c->img_cap = 0;
         HIP_TRY(c, hipMalloc(&c->d_img, bytes));
         c->img_cap = bytes;
@@ -815,6 +905,7 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
     HIP_TRY(c, hipMemsetAsync(c->s_img[k], 0, bytes, c->stream));
     rc = splat_render_device(c, cam, c->s_img[k], 0, nullptr);
     if (rc != SPLAT_OK) return rc;
+    c->s_ring[k] = c->last_ring; c->s_cam[k] = *cam;
     HIP_TRY(c, hipEventRecord(c->s_rendered[k], c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->s_rendered[k], 0));
     HIP_TRY(c, hipMemcpyAsync(argb_out, c->s_img[k], bytes, hipMemcpyDeviceToHost, c->copy_stream));
@@ -832,13 +923,58 @@ int splat_stream_wait(splat_ctx* c, const uint32_t* argb_out) {
         const int k = j == 0 ? newest : newest ^ 1;
         if (c->s_used[k] && c->s_dst[k] == argb_out) {
             HIP_TRY(c, hipEventSynchronize(c->s_copied[k]));
-            for (int r = 0; r < EV_RING; ++r)          // statuses of finished frames: did one overflow?
-                if (c->ring[r].used && hipEventQuery(c->ring[r].e[7]) == hipSuccess) harvest(c, r);
-            if (c->overflow_want || c->bucket_overflow || c->sort_grid_miss) return finish_frame(c);
+            // The frame's status arrived before its pixels left.  If it was skipped on the device (it outgrew
+            // its tile buckets / the sort launches sized from an earlier frame), grow the storage and render
+            // it again, synchronously, into the same buffer: a viewer loop never sees the miss.
+            const int r = c->s_ring[k];
+            const bool skipped = r >= 0 && c->h_status[r].overflow != 0;
+            if (!skipped) return SPLAT_OK;
+            int rc = finish_quiet(c);                 // every frame in flight lands; storage grown; other losses stay pending
+            if (rc != SPLAT_OK) return rc;
+            c->deferred_drop = false;
+            // (the OTHER image's frame, if it was lost too, is redone by its own wait: its status says so)
+            const size_t bytes = (size_t)c->s_cam[k].w * (size_t)c->s_cam[k].h * 4;
+            HIP_TRY(c, hipMemsetAsync(c->s_img[k], 0, bytes, c->stream));
+            rc = splat_render_device(c, &c->s_cam[k], c->s_img[k], 1, nullptr);
+            if (rc != SPLAT_OK) return rc;
+            c->s_ring[k] = c->last_ring;
+            HIP_TRY(c, hipMemcpyAsync(const_cast<uint32_t*>(argb_out), c->s_img[k], bytes, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
             return SPLAT_OK;
         }
     }
     return fail(c, SPLAT_ERR_INVALID, "no streamed frame is bound to this buffer");
+}
+
+void* splat_device_alloc(splat_ctx* c, uint64_t bytes) {
+    if (!c) return nullptr;
+    void* p = nullptr;
+    hipError_t e = hipSetDevice(c->cfg.device);
+    if (e == hipSuccess) e = hipMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1));
+    if (e != hipSuccess) { c->err = std::string("splat_device_alloc: ") + hipGetErrorString(e); return nullptr; }
+    return p;
+}
+void splat_device_free(splat_ctx* c, void* p) {
+    if (!c || !p) return;
+    (void)hipSetDevice(c->cfg.device);
+    (void)sync_all(c);                      // frames in flight may still be writing the image
+    (void)hipFree(p);
+}
+int splat_device_upload(splat_ctx* c, void* d_dst, const void* h_src, uint64_t bytes) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (bytes && (!d_dst || !h_src)) return fail(c, SPLAT_ERR_INVALID, "NULL pointer");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPLAT_OK;
+}
+int splat_device_download(splat_ctx* c, void* h_dst, const void* d_src, uint64_t bytes) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (bytes && (!h_dst || !d_src)) return fail(c, SPLAT_ERR_INVALID, "NULL pointer");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPLAT_OK;
 }
 
 void* splat_host_alloc(uint64_t bytes) {
@@ -850,8 +986,10 @@ void splat_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int splat_sync(splat_ctx* c) {
     if (!c) return SPLAT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    return finish_frame(c);
+    return finish_and_report(c);
 }
+
+uint64_t splat_frames_dropped(const splat_ctx* c) { return c ? c->frames_dropped : 0; }
 
 int splat_get_timing(splat_ctx* c, double ms_out[6], uint64_t* frames, int32_t reset) {
     if (!c) return SPLAT_ERR_INVALID;

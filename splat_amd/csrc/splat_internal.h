@@ -87,7 +87,9 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 // themselves (launch_sort must be given the same value and then leaves them alone); 0 = off.
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
-                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max = 0);
+                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max = 0,
+                      uint2* iters = nullptr /* per wave (scan, blend) iteration counts, statistics frames only */);
+hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 }  // namespace splat
 #endif

@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
                                                               unsigned long long* __restrict__ keys,
                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
-                                                              unsigned int radix_min) {
+                                                              unsigned int radix_min, uint2* __restrict__ iters) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -1595,14 +1595,9 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         start = (start - beg > depth) ? start - depth : beg;
     }
     const float A = (alast < 0.0f) ? (float)(old >> 24) : truncf(alast * 255.0f);   // alpha in {0} U [1/255, .99]
-#ifdef SPLAT_STATS_ITERS   // two same-address atomics per wave cost ~0.2 ms/frame: debug builds only
-    if (lane == 0) {
-        atomicAdd(&status->n_iter_scan, (unsigned long long)itA);
-        atomicAdd(&status->n_iter_blend, (unsigned long long)itB);
-    }
-#else
-    (void)itA; (void)itB;
-#endif
+    // statistics frames only (iters != nullptr): this wave's (scan, blend) iteration counts as one plain store
+    // (atomics on two frame-wide counters cost ~0.2 ms per frame)
+    if (iters != nullptr && lane == 0) iters[blockIdx.x * 4u + wave] = make_uint2(itA, itB);
     if (inside)
         argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
 }
@@ -1616,6 +1611,16 @@ static unsigned int sort_radix_min() {
     return radix_min;
 }
 static inline unsigned int blocks_for(uint64_t n, unsigned int bs) { return (unsigned int)((n + bs - 1) / bs); }
+
+// Per-DEVICE kernel attributes (the large sort classes need more dynamic LDS than the default limit): called by
+// splat_create with its device current, so every GPU a process opens a context on is covered.
+hipError_t init_device_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_kernel<1024, 16384>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds_bytes<1024, 16384>());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_kernel<512, 8192>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds_bytes<512, 8192>());
+}
 
 void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
                        const float* sh, const unsigned int* perm, float4* planes) {
@@ -1670,14 +1675,6 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
                  FrameStatus* status, unsigned int fused_sort_max) {
     if (!n_tiles) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_kernel<1024, 16384>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds_bytes<1024, 16384>());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_tiles_kernel<512, 8192>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, sort_lds_bytes<512, 8192>());
-        attr_set = true;
-    }
     const unsigned int radix_min = sort_radix_min();
     // longest class first (the tiles are ordered longest-first too)
     grid_big = std::min(grid_big, n_tiles); grid_mid = std::min(grid_mid, n_tiles);
@@ -1700,7 +1697,7 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
-                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max) {
+                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max, uint2* iters) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
@@ -1709,7 +1706,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
     static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
     hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status,
-                       fused_sort_max, sort_radix_min());
+                       fused_sort_max, sort_radix_min(), iters);
 }
 
 }  // namespace splat

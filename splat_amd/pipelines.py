@@ -25,6 +25,11 @@ class _Pipeline:
             self._renderer.upload(self.gaussians)
             self._uploaded = self.gaussians
 
+    def invalidate_scene(self):
+        """The GPU copy of `gaussians` is cached by object identity (the reference re-reads the field on
+        every render_to_buffer, src/pipelines.rs:67-79): call this after mutating the scene in place."""
+        self._uploaded = None
+
     def camera_constants(self):
         return self.camera.to_c(self.LOWPASS, self.SH_DIM)
 

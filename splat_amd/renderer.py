@@ -105,8 +105,32 @@ class Renderer:
                                                 C.byref(st) if want_stats else None))
         return st
 
+    # ---- device images without a HIP toolchain on the caller's side ------------------------
+    def device_image(self, init):
+        """Device copy of a uint32 [h,w] host image; returns its device address (free with device_free)."""
+        assert init.dtype == np.uint32 and init.flags.c_contiguous
+        p = self._L.splat_device_alloc(self._h, init.nbytes)
+        if not p:
+            raise SplatError(_lib.ERR_HIP, (self._L.splat_last_error(self._h) or b"").decode())
+        self._check(self._L.splat_device_upload(self._h, C.c_void_p(p), C.c_void_p(init.ctypes.data), init.nbytes))
+        return p
+
+    def device_download(self, d_ptr, h, w):
+        out = np.zeros((int(h), int(w)), np.uint32)
+        self._check(self._L.splat_device_download(self._h, C.c_void_p(out.ctypes.data), C.c_void_p(d_ptr), out.nbytes))
+        return out
+
+    def device_free(self, d_ptr):
+        self._L.splat_device_free(self._h, C.c_void_p(d_ptr))
+
     def sync(self):
+        """Wait for everything enqueued.  Raises SplatError(ERR_CAPACITY) once if an ASYNCHRONOUS frame was
+        skipped on the device (storage has been grown: render it again)."""
         self._check(self._L.splat_sync(self._h))
+
+    def frames_dropped(self):
+        """frames skipped on the device since the context was created (redone internally or reported)"""
+        return int(self._L.splat_frames_dropped(self._h))
 
     # ---- viewer-loop streaming (src/main.rs:69-78): cleared frame -> async copy into a host buffer
     def host_image(self, h, w):

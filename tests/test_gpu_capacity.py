@@ -1,0 +1,129 @@
+"""GPU tests (-m gpu) of the paths where a frame outgrows the storage sized from earlier frames
+(SPLAT_ERR_CAPACITY: tile bucket, pair buffer, sort launch sizes).  A frame that is skipped on the device
+leaves its image untouched; a synchronous call redoes its OWN frame, a lost asynchronous frame is reported
+once by splat_sync, and the streaming loop (src/main.rs:69-78) redoes it inside splat_stream_wait."""
+import os
+
+import numpy as np
+import pytest
+
+import splat_amd
+from splat_amd import _lib
+from splat_amd.renderer import SplatError
+from oracle import oracle as O
+from helpers import scene_dict, oracle_camera, image_diff, make_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_frame(g, cam, init=None):
+    h, w = int(cam.h), int(cam.w)
+    ref = np.zeros((h, w), np.uint32) if init is None else init.copy()
+    ref, ost = O.render(scene_dict(g), oracle_camera(cam, 0.01), O.default_conventions(), ref, nthreads=8)
+    return ref, ost
+
+
+@pytest.fixture()
+def scene_and_poses():
+    r = splat_amd.Renderer()
+    g = splat_amd.synthetic_scene(120000, 71)
+    g.compute_cov3d(r)
+    near = make_camera(256, 256, (0.0, 0.0, 5.0))
+    far = make_camera(256, 256, (0.0, 0.0, 40.0))     # the whole cloud on one or two tiles: lists far beyond a bucket
+    r.upload(g)
+    yield r, g, near, far
+    r.close()
+
+
+def test_lost_async_frame_is_reported_once_and_never_double_blends(scene_and_poses):
+    """an asynchronous frame that overflowed its bucket, followed by a synchronous frame.  The
+    synchronous frame composited: it must not be rendered a second time onto its in/out image because of the
+    older frame's sticky flag, and the loss must surface at the next splat_sync."""
+    r, g, near, far = scene_and_poses
+    rng = np.random.default_rng(5)
+    init = rng.integers(0, 2**32, (256, 256), dtype=np.uint64).astype(np.uint32)
+    a, b, c = r.device_image(init), r.device_image(init), r.device_image(init)
+    r.render_device(near.to_c(0.01), a, sync=True)                        # sizes buckets and sort launches for this pose
+    assert r.binning_mode() > 0, "one-pass binning expected"
+    dropped0 = r.frames_dropped()
+    r.render_device(far.to_c(0.01), b, sync=False)                        # outgrows its tile bucket: skipped on the device
+    st = r.render_device(near.to_c(0.01), c, sync=True, want_stats=True)  # complete; B's loss is pending
+    assert r.frames_dropped() == dropped0 + 1, "the far frame was expected to outgrow its bucket"
+    ref_near, ost = oracle_frame(g, near, init)
+    got_c = r.device_download(c, 256, 256)
+    assert st.n_pairs == ost.n_tile_pairs
+    mx, cnt = image_diff(got_c, ref_near)
+    assert mx <= 1 and cnt <= 1e-3 * got_c.size, (mx, cnt)                # blended exactly once
+    assert np.array_equal(r.device_download(b, 256, 256), init)           # the skipped frame left its image alone
+    with pytest.raises(SplatError) as e:
+        r.sync()
+    assert e.value.code == _lib.ERR_CAPACITY
+    r.sync()                                                              # reported once
+    # rendered again (synchronously this time) the lost frame is the oracle's
+    r.render_device(far.to_c(0.01), b, sync=True)
+    ref_far, _ = oracle_frame(g, far, init)
+    mx, cnt = image_diff(r.device_download(b, 256, 256), ref_far)
+    assert mx <= 1, (mx, cnt)
+    for p in (a, b, c):
+        r.device_free(p)
+
+
+def test_synchronous_frame_that_overflows_is_redone_internally(scene_and_poses):
+    r, g, near, far = scene_and_poses
+    img = np.zeros((256, 256), np.uint32)
+    r.render(near.to_c(0.01), img)
+    d0 = r.frames_dropped()
+    img = np.zeros((256, 256), np.uint32)
+    st = r.render(far.to_c(0.01), img)                # host image in and out: overflows, regrown, redone -- no error
+    assert r.frames_dropped() > d0
+    ref, ost = oracle_frame(g, far)
+    assert st.n_pairs == ost.n_tile_pairs
+    assert image_diff(img, ref)[0] <= 1
+    r.sync()                                          # nothing pending
+
+
+def test_streamed_frame_that_overflows_is_redone_by_the_wait(scene_and_poses):
+    """the viewer loop must survive the first frame whose list outgrows the bucket (C5-class
+    scenes, or an orbit whose list-length profile jumps): splat_stream_wait re-renders it."""
+    r, g, near, far = scene_and_poses
+    f0, f1 = r.host_image(256, 256), r.host_image(256, 256)
+    r.render_stream(near.to_c(0.01), f0)
+    r.stream_wait(f0)
+    d0 = r.frames_dropped()
+    r.render_stream(far.to_c(0.01), f1)               # skipped on the device ...
+    r.render_stream(near.to_c(0.01), f0)              # ... with another frame queued behind it
+    r.stream_wait(f1)                                 # ... and redone here
+    r.stream_wait(f0)
+    assert r.frames_dropped() > d0
+    ref_far, _ = oracle_frame(g, far)
+    ref_near, _ = oracle_frame(g, near)
+    assert image_diff(np.array(f1), ref_far)[0] <= 1 and np.array(f1).any()
+    assert image_diff(np.array(f0), ref_near)[0] <= 1
+
+
+def test_sort_launch_miss_with_tight_grids():
+    """the sort launches for long lists cover a prefix sized from the previous frame; with no margin
+    (SPLAT_DBG_TIGHT_GRIDS) a pose with more long lists than the last one misses, is skipped, and redone"""
+    saved = os.environ.get("SPLAT_DBG_TIGHT_GRIDS")
+    os.environ["SPLAT_DBG_TIGHT_GRIDS"] = "1"
+    try:
+        r = splat_amd.Renderer()
+    finally:
+        os.environ.pop("SPLAT_DBG_TIGHT_GRIDS", None)
+        if saved is not None:
+            os.environ["SPLAT_DBG_TIGHT_GRIDS"] = saved
+    try:
+        g = splat_amd.synthetic_scene(200000, 72)
+        g.compute_cov3d(r)
+        r.upload(g)
+        wide = make_camera(240, 320, (0.0, 0.0, 3.0))       # spread out: few lists reach 2048 keys
+        tight = make_camera(240, 320, (0.0, 0.0, 9.0))      # concentrated: many do
+        for cam in (wide, tight, wide, tight):
+            img = np.zeros((240, 320), np.uint32)
+            st = r.render(cam.to_c(0.01), img)
+            ref, ost = oracle_frame(g, cam)
+            assert st.n_pairs == ost.n_tile_pairs
+            assert image_diff(img, ref)[0] <= 1
+        assert r.frames_dropped() >= 1, "expected at least one sort-launch miss"
+    finally:
+        r.close()

@@ -1,0 +1,129 @@
+// valu_probe.hip -- issue cost of the VALU instructions the compositor is made of, on gfx950.
+// Question it answers: do the packed-f32 instructions (v_pk_mul_f32 /
+// v_pk_add_f32 / v_pk_fma_f32) retire two lanes' worth of work per issue slot at the rate of a
+// plain v_mul_f32 / v_fma_f32, i.e. is "two pixels per lane in even-aligned VGPR pairs" a way to
+// halve the compositor's instruction count?  Each kernel runs a long unrolled stream of one
+// instruction over 8 independent register chains and reports shader cycles (s_memtime) per
+// wave-instruction, at 1 and at 8 waves per SIMD.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o build/valu_probe tools/valu_probe.hip && build/valu_probe
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define REP8(X) X X X X X X X X
+
+template <int KIND>
+__global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters, float seed) {
+    float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
+    f2 p0 = {seed, seed}, p1 = p0 + 1.f, p2 = p0 + 2.f, p3 = p0 + 3.f, p4 = p0 + 4.f, p5 = p0 + 5.f, p6 = p0 + 6.f, p7 = p0 + 7.f;
+    const float m = 0.999f, c = 1e-3f;
+    const f2 pm = {0.999f, 0.998f}, pc = {1e-3f, 2e-3f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == 0) {          // v_fma_f32
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));)
+        } else if (KIND == 1) {   // v_mul_f32
+            REP8(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                              "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 2) {   // v_pk_fma_f32
+            REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                              "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm), "v"(pc));)
+        } else if (KIND == 3) {   // v_pk_mul_f32
+            REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                              "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm));)
+        } else if (KIND == 4) {   // v_pk_add_f32
+            REP8(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                              "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pc));)
+        } else if (KIND == 5) {   // v_exp_f32
+            REP8(asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+                              "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (KIND == 6) {   // v_trunc_f32
+            REP8(asm volatile("v_trunc_f32 %0, %0\n v_trunc_f32 %1, %1\n v_trunc_f32 %2, %2\n v_trunc_f32 %3, %3\n"
+                              "v_trunc_f32 %4, %4\n v_trunc_f32 %5, %5\n v_trunc_f32 %6, %6\n v_trunc_f32 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (KIND == 7) {   // v_med3_f32
+            REP8(asm volatile("v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n"
+                              "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));)
+        } else if (KIND == 8) {   // ONE dependent chain of v_mul_f32 (latency)
+            REP8(asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n"
+                              "v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n"
+                              : "+v"(a0) : "v"(m));)
+        } else if (KIND == 9) {   // ONE dependent chain of v_pk_mul_f32
+            REP8(asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n"
+                              "v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n"
+                              : "+v"(p0) : "v"(pm));)
+        } else if (KIND == 10) {  // v_cmp + v_cndmask pair
+            REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %9, vcc\n v_cmp_lt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %9, vcc\n"
+                              "v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %9, vcc\n v_cmp_lt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %9, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c) : "vcc");)
+        } else if (KIND == 11) {  // v_fma_mix? no: v_mul_f32 with clamp modifier
+            REP8(asm volatile("v_mul_f32 %0, %0, %8 clamp\n v_mul_f32 %1, %1, %8 clamp\n v_mul_f32 %2, %2, %8 clamp\n v_mul_f32 %3, %3, %8 clamp\n"
+                              "v_mul_f32 %4, %4, %8 clamp\n v_mul_f32 %5, %5, %8 clamp\n v_mul_f32 %6, %6, %8 clamp\n v_mul_f32 %7, %7, %8 clamp\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p2.y + p3.x + p4.y + p5.x + p6.y + p7.x;
+    if ((threadIdx.x & 63u) == 0) out[blockIdx.x * 4u + (threadIdx.x >> 6)] = t1 - t0;
+    if (s == 123.456f) out[0] = 0;      // keep the chains alive
+}
+
+template <int KIND>
+static void run(const char* name, int per_iter) {
+    const int iters = 2000;
+    unsigned long long* d = nullptr;
+    hipMalloc(&d, sizeof(unsigned long long) * 4 * 4096);
+    for (int blocks_per_cu : {1, 2, 4, 8}) {
+        const int grid = 256 * blocks_per_cu;
+        hipLaunchKernelGGL(probe<KIND>, dim3(grid), dim3(256), 0, 0, d, 10, 1.0f);      // warm-up
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(probe<KIND>, dim3(grid), dim3(256), 0, 0, d, iters, 1.0f);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(4 * grid);
+        hipMemcpy(h.data(), d, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+        std::sort(h.begin(), h.end());
+        const double med = (double)h[h.size() / 2];
+        const double n_inst = (double)iters * per_iter;
+        // s_memtime ticks at a constant 100 MHz on gfx9 (REFCLK); also derive cycles from wall time at the
+        // clock the chip actually ran: per-SIMD cost = launch time * f / (instructions per SIMD)
+        const double inst_per_simd = n_inst * blocks_per_cu;      // waves per SIMD == blocks per CU here
+        printf("%-28s waves/SIMD %d: memtime ticks/inst/wave %.4f   launch %.3f ms -> %.3f ns per wave-inst per SIMD (x2.4 GHz = %.2f cyc)\n",
+               name, blocks_per_cu, med / n_inst, ms, ms * 1e6 / inst_per_simd, ms * 1e6 / inst_per_simd * 2.4);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    hipFree(d);
+}
+
+int main() {
+    run<0>("v_fma_f32 x8 chains", 64);
+    run<1>("v_mul_f32 x8 chains", 64);
+    run<2>("v_pk_fma_f32 x8 chains", 64);
+    run<3>("v_pk_mul_f32 x8 chains", 64);
+    run<4>("v_pk_add_f32 x8 chains", 64);
+    run<5>("v_exp_f32 x8 chains", 64);
+    run<6>("v_trunc_f32 x8 chains", 64);
+    run<7>("v_med3_f32 x8 chains", 64);
+    run<8>("v_mul_f32 dependent", 64);
+    run<9>("v_pk_mul_f32 dependent", 64);
+    run<10>("v_cmp+v_cndmask (pairs)", 64);
+    run<11>("v_mul_f32 clamp x8", 64);
+    return 0;
+}
