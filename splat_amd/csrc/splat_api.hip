@@ -27,7 +27,7 @@ thread_local std::string g_create_error;
 constexpr int N_EV = 9;        // e0..e2 on the bin stream (start, K1, scan), e8, e3, e4 on the sort stream (start, K2, K3), e5..e7 on the caller's (K4 start, K4 end, status)
 constexpr int N_TIMES = 6;     // preprocess, scan, emit, sort, composite, status read-back
 constexpr int EV_RING = 32;
-constexpr int N_SLOTS = 3;
+constexpr int N_SLOTS = 4;
 
 struct EvSet {
     hipEvent_t e[N_EV];
@@ -367,7 +367,10 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // frame N+1 on the sort stream, compositor of frame N on the caller's stream -- the bin chain is
     // the longest of the three under contention, so splitting it raises the frame rate.
     hipStream_t bs = c->pipeline ? c->bin_stream : c->stream;
-    hipStream_t ss = c->pipeline >= 3 ? c->sort_stream : bs;
+    // 6: the bin + sort chains of consecutive frames alternate between two streams, so the chain of frame N+2
+    // (a latency chain: K1 -> scan -> sort) runs beside the chain of frame N+1 and the compositor of frame N
+    if (c->pipeline >= 6 && (c->frame_idx & 1ull)) bs = c->sort_stream;
+    hipStream_t ss = c->pipeline == 3 ? c->sort_stream : bs;     // (4, 5: three / four slots on two streams)
     const unsigned int m = c->n_tiles;
     if (c->pipeline) {
         // order this frame's binning after whatever the caller queued before the call (it may have
@@ -495,7 +498,7 @@ int finish_quiet(splat_ctx* c) {
     return rc;
 }
 
-int slots_in_use(const splat_ctx* c) { return c->pipeline >= 3 ? 3 : (c->pipeline ? 2 : 1); }
+int slots_in_use(const splat_ctx* c) { return c->pipeline >= 5 ? 4 : (c->pipeline >= 3 ? 3 : (c->pipeline ? 2 : 1)); }
 
 // Pick the binning path for a frame over m tiles and make sure its key storage exists.
 int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
@@ -606,7 +609,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
     if (const char* e11 = std::getenv("SPLAT_EARLY_SCAN8")) c->early_scan8 = std::min(8, std::max(1, std::atoi(e11)));
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
-    if (const char* e4 = std::getenv("SPLAT_PIPELINE")) { c->pipeline = std::atoi(e4); if (c->pipeline <= 1) c->pipeline = 0; if (c->pipeline > 3) c->pipeline = 3; }
+    if (const char* e4 = std::getenv("SPLAT_PIPELINE")) { c->pipeline = std::atoi(e4); if (c->pipeline <= 1) c->pipeline = 0; if (c->pipeline > 6) c->pipeline = 6; }
     if (const char* e9 = std::getenv("SPLAT_TIMING_EVERY")) c->timing_every = std::max(1, std::atoi(e9));
     if (const char* e13 = std::getenv("SPLAT_FUSED_SORT")) c->fused_sort_max = std::min(2048, std::max(0, std::atoi(e13)));
     if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;

@@ -155,13 +155,20 @@ constexpr int AGG_MAX_TILES = 64;
 constexpr int BIG_CAP = 256;           // close-up Gaussians handled per block-round
 
 struct BinShared {
-    unsigned int table[AGG_CAP];
+    // The close-up arrays share the table's memory: close-ups are expanded after the table has done its work
+    // (a workgroup barrier separates the two uses), and 6 KB less LDS per workgroup is room for another
+    // kernel's workgroups on the CU (the compositor of the previous frame runs beside K1).
+    union {
+        unsigned int table[AGG_CAP];
+        struct {
+            unsigned int big[BIG_CAP][4];  // the block's big rectangles: x0 | y0 << 16, width, tile count, first flat index
+            unsigned long long bigkey[BIG_CAP];
+        };
+    };
     int box[4];                        // min tx, min ty, max tx, max ty of the aggregated Gaussians
     unsigned int nbig;
     unsigned int nvis, nsing;          // block totals for the frame statistics (bin_bucket)
     unsigned int bigtotal;             // tiles of all big rectangles together
-    unsigned int big[BIG_CAP][4];      // the block's big rectangles: x0 | y0 << 16, width, tile count, first flat index
-    unsigned long long bigkey[BIG_CAP];
 };
 
 // Close-ups (more than AGG_MAX_TILES tiles): the tiles of ALL the block's big rectangles form one
@@ -1332,23 +1339,21 @@ struct WaveLds { float4 a[64]; float4 b[64]; float4 c[64]; };   // one batch of 
 #ifndef SPLAT_COMP_WAVES
 #define SPLAT_COMP_WAVES 1
 #endif
-__global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
-                                                              const unsigned int* __restrict__ order,
-                                                              const unsigned int* __restrict__ lens,
-                                                              unsigned long long* __restrict__ keys,
-                                                              const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
-                                                              FrameStatus* __restrict__ status, unsigned int fused_sort_max,
-                                                              unsigned int radix_min, uint2* __restrict__ iters) {
+// One tile (slot `item` of the longest-first tile order) by one workgroup; `smem` = sort_lds_bytes<256, 2048>() bytes.
+__device__ __forceinline__ void composite_tile(unsigned char* smem, const unsigned int item, const FrameConst& fc,
+                                               const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
+                                               const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
+                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
+                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
+                                               unsigned int radix_min, uint2* __restrict__ iters) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
     // frame's K1 like the rest of this kernel instead of in the phase where the chip idles), then the
     // four waves' private record batches.
-    __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     static_assert(sizeof(WaveLds) * 4 <= sort_lds_bytes<256, 2048>(), "staging fits the sort workspace");
     WaveLds* slds = reinterpret_cast<WaveLds*>(smem);
-    if (status->overflow) return;
-    const unsigned int tile = order[blockIdx.x];
+    const unsigned int tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)order[item]);
     const unsigned int tid = threadIdx.x;
     const unsigned int beg = __builtin_amdgcn_readfirstlane(offsets[tile]);
     const unsigned int end = beg + __builtin_amdgcn_readfirstlane(lens[tile]);
@@ -1597,9 +1602,24 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
     const float A = (alast < 0.0f) ? (float)(old >> 24) : truncf(alast * 255.0f);   // alpha in {0} U [1/255, .99]
     // statistics frames only (iters != nullptr): this wave's (scan, blend) iteration counts as one plain store
     // (atomics on two frame-wide counters cost ~0.2 ms per frame)
-    if (iters != nullptr && lane == 0) iters[blockIdx.x * 4u + wave] = make_uint2(itA, itB);
+    if (iters != nullptr && lane == 0) iters[item * 4u + wave] = make_uint2(itA, itB);
     if (inside)
         argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
+}
+
+// The launch: one workgroup per tile, slot blockIdx.x of the longest-first order.  (A persistent grid pulling
+// slots from a ticket counter, and the order composited as consecutive chunk launches, were both measured as
+// ways to cap the compositor's residency beside the next frame's K1: both slower -- DESIGN.md section 3.)
+__global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+                                                              const unsigned int* __restrict__ order,
+                                                              const unsigned int* __restrict__ lens,
+                                                              unsigned long long* __restrict__ keys,
+                                                              const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
+                                                              FrameStatus* __restrict__ status, unsigned int fused_sort_max,
+                                                              unsigned int radix_min, uint2* __restrict__ iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
+    if (status->overflow) return;
+    composite_tile(smem, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters);
 }
 
 // ---------------------------------------------------------------------------
