@@ -4,10 +4,17 @@
 A step = one frame: clear the device image + render_to_buffer's whole path (preprocess, binning,
 per-tile sort, exact compositing) with scene and image resident in HBM -- the region
 src/main.rs:71-75 times.  N=1 workload: C3, the 1.5M-Gaussian 'truck' stand-in at 1920x1080
-(synthetic, seed 3: no real PLY ships with the reference).  N>1: the same frame split into tile-row
-slabs across ranks (strong scaling) with one RCCL gather of slab rows to rank 0 per frame.
+(synthetic, seed 3: no real PLY ships with the reference).
 
-Prints ONE JSON line on rank 0.
+N>1 ("scaling": "strong"): the same frame split into load-balanced tile-row slabs, one per GPU, with ONE
+gather of slab rows to rank 0 per frame -- a grouped ncclSend / ncclRecv issued by the C ABI itself
+(splat_comm_gather, include/splat_hip.h "Multi-GPU").  Launched as one process per GPU
+(python -m torch.distributed.run ...): torch.distributed only carries the 128-byte RCCL id and the barrier.
+`--single-process` runs the same decomposition from ONE process (splat_multi_*: a host thread and a
+context per device, ncclCommInitAll).
+
+Prints ONE JSON line on rank 0; exits non-zero if the frame is not the oracle's frame (> 1 LSB, or a
+different (Gaussian, tile) pair count) or if the gathered frame differs from the single-GPU frame.
 """
 import argparse
 import json
@@ -28,6 +35,7 @@ WORKLOADS = {
     "C5": (6_000_000, 3840, 2160, 5),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ROW_OVERHEAD = 2000.0     # slab balancing: fixed cost of a tile row, in (Gaussian, tile) pairs
 
 
 def cpu_baseline(g, cam_c, threads):
@@ -48,6 +56,69 @@ def cpu_baseline(g, cam_c, threads):
     return img, st, dt
 
 
+def orbit_poses(pipe, cam):
+    poses = []
+    for _ in range(36):
+        poses.append(pipe.camera_constants())
+        cam.update_yaw_angle(10.0 * np.pi / 180.0)        # Key::Right, src/main.rs:57-60
+        cam.update_camera_pose()
+    return poses
+
+
+def single_process(args, n, W, H, seed):
+    """One process, one host thread + context per device (splat_multi_*)."""
+    import splat_amd
+    t_setup = time.perf_counter()
+    R0 = splat_amd.Renderer(device=0)
+    g = splat_amd.synthetic_scene(n, seed)
+    g.compute_cov3d(R0)
+    cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0))
+    cam.update_camera_pose()
+    pipe = splat_amd.GaussianSplatPipeline01(g, cam, renderer=R0)
+    cam_c = pipe.camera_constants()
+    poses = orbit_poses(pipe, cam) if args.orbit else [cam_c]
+    R0.upload(g)
+    full = np.zeros((H, W), np.uint32)
+    st = R0.render(cam_c, full)
+    R0.close()
+    # SPLAT_BENCH_SHARE_GPU=1 (testing only): every rank on device 0 (copy transport instead of RCCL)
+    M = splat_amd.MultiRenderer([0] * args.gpus if os.environ.get("SPLAT_BENCH_SHARE_GPU") == "1" else list(range(args.gpus)))
+    M.upload(g)
+    slabs = M.balance(cam_c)
+    for k in range(args.warmup):
+        M.render_frame(poses[k % len(poses)])
+    M.sync()
+    for r in range(args.gpus):
+        M.rank_timing(r, reset=True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        M.render_frame(poses[k % len(poses)])
+    M.sync()
+    dt = time.perf_counter() - t0
+    kern = [M.rank_timing(r, reset=True) for r in range(args.gpus)]
+    M.render_frame(cam_c)
+    M.sync()
+    same = bool(np.array_equal(M.download(H, W), full))
+    M.close()
+    per = {k: max(ms[k] / max(fr, 1) for ms, fr in kern) for k in kern[0][0]}
+    out = {
+        "metric": "frames_per_sec", "value": args.steps / dt, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d Gaussians @%dx%d, synthetic seed %d, Camera(0,0,5), Pipeline01 (lowpass 0.01, "
+                               "sh_dim 15), exact mode" % (args.workload, n, W, H, seed),
+                   "camera": "36-pose yaw orbit" if args.orbit else "fixed pose",
+                   "partition": "ONE process, %d host threads + contexts (splat_multi_*), load-balanced tile-row slabs %s, "
+                                "grouped ncclSend/ncclRecv to rank 0" % (args.gpus, [b - a for a, b in slabs]),
+                   "n_pairs": int(st.n_pairs), "n_visible": int(st.n_visible)},
+        "kernel_ms_slowest_rank": per,
+        "multi_gpu_frame_equals_single_gpu_frame": same,
+        "setup_s": time.perf_counter() - t_setup - dt,
+    }
+    print(json.dumps(out))
+    sys.exit(0 if same else 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,7 +128,10 @@ def main():
     ap.add_argument("--orbit", action="store_true",
                     help="step the camera yaw by 10 degrees every frame (the 36-pose orbit of src/main.rs:53-60) "
                          "instead of the fixed pose")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from one process (splat_multi_*: one host thread per device) instead of one rank per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the host-visible and orbit legs")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -66,18 +140,22 @@ def main():
     import splat_amd
     from splat_amd import dist as sdist
 
+    n, W, H, seed = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.single_process and world == 1 and args.gpus > 1:
+        return single_process(args, n, W, H, seed)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...   (or add --single-process)"
+                     % (args.gpus, args.gpus))
         args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # SPLAT_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0 over gloo, to exercise the N>1 code
-    # path on a single-GPU box; the real run is one rank per GPU over RCCL
+    # path on a single-GPU box (RCCL refuses ranks that share a device); the real run is one rank per GPU over RCCL
     share = os.environ.get("SPLAT_BENCH_SHARE_GPU") == "1"
     if share:
         local = 0
@@ -88,7 +166,6 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    n, W, H, seed = WORKLOADS[args.workload]
     # per-kernel HIP events ride on every 8th asynchronous frame by default (each record is a queue
     # bubble); a short timed region needs them on every frame to have launches to average over
     os.environ.setdefault("SPLAT_TIMING_EVERY", "8" if args.steps >= 64 else "1")
@@ -99,21 +176,32 @@ def main():
     cam.update_camera_pose()
     pipe = splat_amd.GaussianSplatPipeline01(g, cam, renderer=R)   # what the default binary uses
     cam_c = pipe.camera_constants()
-    poses = [cam_c]
-    if args.orbit:
-        poses = []
-        for k in range(36):
-            poses.append(pipe.camera_constants())
-            cam.update_yaw_angle(10.0 * np.pi / 180.0)        # Key::Right, src/main.rs:57-60
-            cam.update_camera_pose()
+    orbit = orbit_poses(pipe, cam)
+    poses = orbit if args.orbit else [cam_c]
     R.upload(g)
 
+    gather_kind = None
     if world > 1:
         # balanced contiguous slabs from per-tile-row pair counts; every rank derives the same partition
-        slabs = sdist.slab_partition_balanced(R.tile_row_loads(cam_c), world, row_overhead=2000.0)
+        slabs = splat_amd.slab_partition_native(R.tile_row_loads(cam_c), world, ROW_OVERHEAD)
+        if not share:
+            try:        # data plane: the C ABI's own communicator (RCCL); torch.distributed carries the id only
+                box = [splat_amd.Renderer.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0, device=torch.device("cuda", local))
+                R.comm_init(box[0], world, rank)
+                R.comm_set_slabs(slabs)
+                gather_kind = "native"
+            except Exception as e:      # keep the run alive on the other transport, and say so
+                sys.stderr.write("bench.py rank %d: native RCCL gather unavailable (%s); using torch.distributed\n" % (rank, e))
+        flag = torch.tensor([1 if gather_kind == "native" else 0], device="cuda")
+        if not share:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            gather_kind = "torch.distributed"
+            R.set_slab(*slabs[rank])
     else:
         slabs = sdist.slab_partition(H, world)
-    R.set_slab(*slabs[rank])
+        R.set_slab(*slabs[rank])
     stream = torch.cuda.Stream()
     R.set_stream(stream.cuda_stream)
     image = torch.zeros((H, W), dtype=torch.int32, device="cuda")
@@ -126,7 +214,9 @@ def main():
         with torch.cuda.stream(stream):
             image.zero_()                                        # color = Buffer2d::fill([W,H], 0)
             R.render_device(pose, image.data_ptr())              # enqueue only
-            if world > 1:
+            if gather_kind == "native":
+                R.comm_gather(image.data_ptr(), W, H, 0)         # grouped ncclSend / ncclRecv on the same stream
+            elif world > 1:
                 if share:
                     stream.synchronize()     # gloo's CUDA receive is not ordered after this stream's work (NCCL's is)
                 sdist.gather_slabs(image, slabs, rank)
@@ -150,16 +240,55 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kern_ms, frames = R.timing(reset=True)               # HIP events on the kernels' own stream
+    last_pose = poses[(frame_no[0] - 1) % len(poses)]
+    final = image.clone()
     # The context overlaps the binning + sort of frame N+1 (its own stream) with the compositor of
     # frame N, so the durations above include time shared with a neighbouring frame's kernels.  For
     # reference, a few frames with a sync after each (nothing overlaps): every kernel alone on the chip.
     iso_ms, iso_frames = None, 0
+    legs = {}
     if world == 1:
         with torch.cuda.stream(stream):
             for k in range(10):
                 image.zero_()
                 R.render_device(poses[k % len(poses)], image.data_ptr(), sync=True)
         iso_ms, iso_frames = R.timing(reset=True)
+        if not args.no_extra_legs:
+            K = 72
+            # (1) the 36-pose yaw orbit of src/main.rs:53-60, device resident like `value`
+            if not args.orbit:
+                for k in range(4):
+                    with torch.cuda.stream(stream):
+                        image.zero_(); R.render_device(orbit[k], image.data_ptr())
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for k in range(K):
+                    with torch.cuda.stream(stream):
+                        image.zero_(); R.render_device(orbit[k % 36], image.data_ptr())
+                torch.cuda.synchronize()
+                legs["orbit_36_poses_device_resident_fps"] = K / (time.perf_counter() - t1)
+            # (2) host-visible: the literal render_to_buffer -- host image in and out, synchronous (src/main.rs:71-75)
+            himg = np.zeros((H, W), np.uint32)
+            R.render(cam_c, himg)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                himg[:] = 0
+                R.render(cam_c, himg)
+            legs["host_visible_splat_render_fps"] = 20 / (time.perf_counter() - t1)
+            # (3) host-visible: the viewer loop (clear, render, present) with two pinned frames in flight
+            bufs = [R.host_image(H, W), R.host_image(H, W)]
+            R.render_stream(cam_c, bufs[0]); R.stream_wait(bufs[0])
+            t1 = time.perf_counter()
+            for k in range(K):
+                R.render_stream(cam_c, bufs[k & 1])
+                if k:
+                    R.stream_wait(bufs[(k - 1) & 1])
+            R.stream_wait(bufs[(K - 1) & 1])
+            legs["host_visible_splat_render_stream_fps"] = K / (time.perf_counter() - t1)
+            legs["host_visible_frames_equal_device_frame"] = bool(np.array_equal(bufs[(K - 1) & 1], himg))
+            legs["what"] = ("host-visible = pixels delivered to host memory (PCIe inclusive); never `value`.  %d frames each "
+                            "(splat_render: 20)" % K)
+            R.timing(reset=True)
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -167,7 +296,8 @@ def main():
     dt = float(t.item())
 
     # per-rank stats -> whole-frame totals
-    tot = torch.tensor([st.n_visible, st.n_pairs, st.bytes_algorithmic], dtype=torch.int64, device="cuda")
+    tot = torch.tensor([st.n_visible, st.n_pairs, st.bytes_algorithmic, st.flops_algorithmic, st.n_iter_scan, st.n_iter_blend],
+                       dtype=torch.int64, device="cuda")
     comp = torch.tensor([kern_ms["composite"] / max(frames, 1)], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -180,9 +310,9 @@ def main():
         R.set_slab(0, -1)
         full = torch.zeros((H, W), dtype=torch.int32, device="cuda")
         with torch.cuda.stream(stream):
-            R.render_device(poses[(frame_no[0] - 1) % len(poses)], full.data_ptr(), sync=True)
+            R.render_device(last_pose, full.data_ptr(), sync=True)
         torch.cuda.synchronize()
-        slab_check = bool(torch.equal(full, image))
+        slab_check = bool(torch.equal(full, final))
         R.set_slab(*slabs[rank])
     if rank == 0:
         per = {k: v / max(frames, 1) for k, v in kern_ms.items()}
@@ -212,8 +342,14 @@ def main():
             "config": {"workload": "%s: %d Gaussians @%dx%d, synthetic seed %d, Camera(0,0,5), Pipeline01 "
                                    "(lowpass 0.01, sh_dim 15), exact mode" % (args.workload, n, W, H, seed),
                        "camera": "36-pose yaw orbit, 10 degrees per frame" if args.orbit else "fixed pose",
-                       "partition": ("load-balanced tile-row slabs %s + RCCL gather" % [b - a for a, b in slabs]) if world > 1 else "single GPU",
-                       "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len), "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback), "wave_iters_scan": int(st.n_iter_scan), "wave_iters_blend": int(st.n_iter_blend), "k1_blocks_culled": int(st.n_blocks_culled)},
+                       "partition": ("one rank per GPU, load-balanced tile-row slabs %s, one gather of slab rows per frame: %s"
+                                     % ([b - a for a, b in slabs],
+                                        {"native": "grouped ncclSend/ncclRecv issued by the C ABI (splat_comm_gather)",
+                                         "torch.distributed": "torch.distributed batch_isend_irecv"}[gather_kind]))
+                                    if world > 1 else "single GPU",
+                       "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len),
+                       "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback),
+                       "k1_blocks_culled": int(st.n_blocks_culled)},
             "roofline": {"bound": "hbm", "kernel": "composite_exact_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": per["composite"], "bytes_per_launch": comp_bytes,
@@ -222,27 +358,38 @@ def main():
                                        "what": "the same kernel with a sync after every frame: in the timed region it shares "
                                                "the chip with the next frame's preprocess/scan/sort (cross-frame overlap)"}
                                       if iso and iso["composite"] > 0 else None),
-                         "valu_issue_util": valu_util, "counters_from": ("profiles/%s_pmc_*.csv" % prof_src) if prof_src else None,
-                         "note": "the compositor is bound by VALU issue, not by HBM: valu_issue_util = wave64 VALU "
-                                 "instructions x 2 cycles / (1024 SIMDs x launch cycles), from the committed SQ counter pass"},
-            "roofline_frame": {"bytes_algorithmic": int(st.bytes_algorithmic), "t_frame_ms": t_frame,
+                         "from_committed_profile": {"traffic": traffic is not None, "valu_issue_util": valu_util,
+                                                    "counters": ("profiles/%s_pmc_*.csv" % prof_src) if prof_src else None,
+                                                    "what": "HBM bytes per launch and VALU issue utilisation come from the committed "
+                                                            "rocprofv3 --pmc passes of this build (counters cannot be read inside "
+                                                            "bench.py); everything else in this object is measured in this run"},
+                         "compositor_work": {"flops_alg": int(tot[3]),
+                                             "gflops_alg_per_s": (int(tot[3]) / (per["composite"] * 1e-3) / 1e9) if per["composite"] > 0 else None,
+                                             "wave_record_iterations_scan": int(tot[4]), "wave_record_iterations_blend": int(tot[5]),
+                                             "what": "flops_alg = sum over pixels of its tile's list length x 25 (BASELINE.md section 4); "
+                                                     "iterations = (wave, record) steps the compositor actually took on the "
+                                                     "statistics frame (early-out + coverage compaction), 64 pixels each"},
+                         "note": "the compositor is bound by VALU issue and LDS latency, not by HBM (DESIGN.md section 4)"},
+            "roofline_frame": {"bytes_algorithmic": int(tot[2]), "t_frame_ms": t_frame,
                                "sum_of_kernel_ms": t_gpu,
-                               "achieved": st.bytes_algorithmic / (t_frame * 1e-3) / 1e9,
+                               "achieved": int(tot[2]) / (t_frame * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": st.bytes_algorithmic / (t_frame * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "frac": int(tot[2]) / (t_frame * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "note": "B_alg / wall time per frame; kernels of consecutive frames overlap, so the sum of "
                                        "their durations exceeds the frame time"},
             "kernel_ms": per,
             "kernel_ms_isolated": iso,
         }
+        if legs:
+            out["extra_legs"] = legs
         if slab_check is not None:
             out["multi_gpu_frame_equals_single_gpu_frame"] = slab_check
             if not slab_check:
                 exit_code = 3
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or (os.cpu_count() or 1)
-            ref, ost, cdt = cpu_baseline(g, poses[(frame_no[0] - 1) % len(poses)], threads)
-            gpu_img = image.cpu().numpy().view(np.uint32)
+            ref, ost, cdt = cpu_baseline(g, last_pose, threads)
+            gpu_img = final.cpu().numpy().view(np.uint32)
             d = np.abs(np.stack([((gpu_img >> s) & 255).astype(np.int32) - ((ref >> s) & 255).astype(np.int32)
                                  for s in (0, 8, 16, 24)]))
             out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": threads, "kind": "port",

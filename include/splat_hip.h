@@ -171,6 +171,65 @@ int splat_get_tile_lists(splat_ctx* ctx, uint32_t* tile_offsets, uint64_t n_offs
  * (default 48 GiB for all frame slots together) or a tile list longer than 65536 select two-pass. */
 int64_t splat_binning_mode(splat_ctx* ctx);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: one frame = disjoint TILE-ROW SLABS, one per GPU, every GPU holding the
+ * whole scene; the only exchange is one gather of slab pixel rows to the root per frame -- a grouped
+ * ncclSend / ncclRecv over xGMI, contiguous rows straight out of each peer's image into the root's.
+ * Pixels are independent given the ordered splat list (src/pipelines.rs:147-168), so the gathered frame
+ * equals the single-GPU frame byte for byte.  RCCL (librccl.so.1) is loaded on first use.
+ * Two forms, same kernels, same gather:
+ *   (A) one process per GPU (torchrun / MPI style): splat_comm_* on an ordinary context;
+ *   (B) one process, one host thread + context per device: splat_multi_* (ncclCommInitAll).
+ * What replaces what: the reference renders the whole frame in one render_to_buffer call
+ * (src/pipelines.rs:66-86); euc fans rows out to CPU threads -- these entry points fan tile rows out to GPUs.
+ * ------------------------------------------------------------------------------------------------ */
+#define SPLAT_UNIQUE_ID_BYTES 128
+
+/* Contiguous tile-row slabs minimising the heaviest slab: row_loads = splat_tile_row_loads() output,
+ * row_overhead = fixed cost per tile row in the same unit (pairs).  slabs_out: n_ranks x {row0, row1}.
+ * row_loads == NULL: equal split of n_rows.  Deterministic: every rank derives the same partition. */
+int splat_slab_partition(const uint64_t* row_loads, int32_t n_rows, int32_t n_ranks, double row_overhead,
+                         int32_t* slabs_out);
+
+/* (A) one process per GPU.  Rank 0 calls splat_comm_unique_id and hands the 128 bytes to the other ranks by
+ * its own means (a file, a socket, torch.distributed ...); every rank then calls splat_comm_init_rank on its
+ * context (collective: ncclCommInitRank on the context's device). */
+int splat_comm_unique_id(uint8_t id[SPLAT_UNIQUE_ID_BYTES]);
+int splat_comm_init_rank(splat_ctx* ctx, const uint8_t id[SPLAT_UNIQUE_ID_BYTES], int32_t n_ranks, int32_t rank);
+/* The partition (n_ranks x {row0,row1}, identical on every rank); also sets this context's own slab. */
+int splat_comm_set_slabs(splat_ctx* ctx, const int32_t* slabs);
+/* Gather: enqueued on the context's stream behind the frames rendered so far.  d_argb = this rank's w x h
+ * device image; afterwards (stream order) the root's image holds every rank's rows. */
+int splat_comm_gather(splat_ctx* ctx, void* d_argb, int32_t w, int32_t h, int32_t root);
+void splat_comm_destroy(splat_ctx* ctx);              /* also done by splat_destroy */
+
+/* (B) one process.  devices[i] = HIP ordinal of rank i (rank 0 is the root).  A device may be listed more than
+ * once (slabs then share that GPU; RCCL refuses duplicate devices, so rows travel as device-to-device copies
+ * ordered by events -- meant for testing the decomposition on a single-GPU box); SPLAT_MULTI_TRANSPORT=peer
+ * selects those copies for distinct devices too (hipMemcpyPeerAsync over xGMI). */
+typedef struct splat_multi splat_multi;
+int splat_multi_create(const splat_config* cfg /* device field ignored; NULL = defaults */, const int32_t* devices,
+                       int32_t n_devices, splat_multi** out);
+void splat_multi_destroy(splat_multi* m);
+const char* splat_multi_last_error(const splat_multi* m);   /* m may be NULL: last create() error */
+int splat_multi_upload_scene(splat_multi* m, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
+                             const float* sh);               /* replicated on every device, in parallel */
+/* Load-balanced slabs for this camera (count-only pass on the root + splat_slab_partition); cam == NULL:
+ * equal slabs.  The partition stays until the next call. */
+int splat_multi_balance(splat_multi* m, const splat_camera* cam);
+int splat_multi_get_slabs(const splat_multi* m, int32_t* slabs_out /* n_devices x {row0,row1} */);
+/* render_to_buffer across the devices: blends the scene onto `argb` (host, in/out, w*h u32).  stats (nullable)
+ * = sums over the slabs (a Gaussian that reaches two slabs counts in both). */
+int splat_multi_render(splat_multi* m, const splat_camera* cam, uint32_t* argb, splat_stats* stats);
+/* Viewer-loop frame (src/main.rs:69-78), device resident: every device clears its slab rows, renders them and
+ * sends them to the root's image.  Asynchronous: returns once the frame is queued on every device's thread;
+ * splat_multi_sync waits.  The root's image (device memory on devices[0]) is splat_multi_image(). */
+int splat_multi_render_frame(splat_multi* m, const splat_camera* cam);
+int splat_multi_sync(splat_multi* m);
+void* splat_multi_image(splat_multi* m);
+int splat_multi_download(splat_multi* m, uint32_t* argb_out, int32_t w, int32_t h);   /* root image -> host (after a sync) */
+splat_ctx* splat_multi_ctx(splat_multi* m, int32_t rank);  /* the rank's context (statistics, timing); not to be rendered on directly */
+
 #ifdef __cplusplus
 }
 #endif

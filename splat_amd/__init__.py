@@ -9,6 +9,7 @@ from .camera import Camera  # noqa: F401
 from .gaussians import GaussianList, naive_gaussians, load_from_ply, synthetic_scene, write_ply, trim_ply  # noqa: F401
 from .pipelines import GaussianSplatPipeline01, GaussianSplatPipeline02  # noqa: F401
 from .renderer import Renderer, SplatError  # noqa: F401
+from .multi import MultiRenderer, slab_partition_native  # noqa: F401
 
 MODE_EXACT = 0                  # SPLAT_MODE_EXACT: the reference's arithmetic
 MODE_CORRECTED_PROJECTION = 1   # SPLAT_MODE_CORRECTED_PROJECTION: EWA Jacobian with its shear terms (not the reference)

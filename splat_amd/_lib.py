@@ -70,7 +70,27 @@ SYMBOLS = [
     ("splat_device_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     ("splat_host_alloc", C.c_void_p, [C.c_uint64]),
     ("splat_host_free", None, [C.c_void_p]),
+    # multi-GPU
+    ("splat_slab_partition", C.c_int, [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_int32)]),
+    ("splat_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
+    ("splat_comm_init_rank", C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
+    ("splat_comm_set_slabs", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    ("splat_comm_gather", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    ("splat_comm_destroy", None, [C.c_void_p]),
+    ("splat_multi_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
+    ("splat_multi_destroy", None, [C.c_void_p]),
+    ("splat_multi_last_error", C.c_char_p, [C.c_void_p]),
+    ("splat_multi_upload_scene", C.c_int, [C.c_void_p, C.c_uint64, _fp, _fp, _fp, _fp]),
+    ("splat_multi_balance", C.c_int, [C.c_void_p, C.POINTER(CameraC)]),
+    ("splat_multi_get_slabs", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    ("splat_multi_render", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
+    ("splat_multi_render_frame", C.c_int, [C.c_void_p, C.POINTER(CameraC)]),
+    ("splat_multi_sync", C.c_int, [C.c_void_p]),
+    ("splat_multi_image", C.c_void_p, [C.c_void_p]),
+    ("splat_multi_download", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int32, C.c_int32]),
+    ("splat_multi_ctx", C.c_void_p, [C.c_void_p, C.c_int32]),
 ]
+UNIQUE_ID_BYTES = 128
 
 _LIB = None
 

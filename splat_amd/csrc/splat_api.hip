@@ -132,8 +132,16 @@ struct splat_ctx {
     unsigned int fused_sort_max = 2048;    // SPLAT_FUSED_SORT: lists up to this length are sorted inside the compositor (0: off)
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
     int pipeline = 2;                      // frames in flight on the device (SPLAT_PIPELINE = 1 | 2 | 3, see enqueue_frame)
+    splat::CommState* comm = nullptr;      // multi-GPU: RCCL communicator + partition (splat_multi.hip)
     std::string err;
 };
+
+namespace splat {
+CommState** ctx_comm_slot(splat_ctx* c) { return &c->comm; }
+hipStream_t ctx_stream(splat_ctx* c) { return c->stream; }
+int ctx_device(const splat_ctx* c) { return c->cfg.device; }
+int ctx_fail(splat_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
+}  // namespace splat
 
 namespace {
 
@@ -656,6 +664,7 @@ void splat_destroy(splat_ctx* c) {
     if (c->bin_stream) (void)hipStreamSynchronize(c->bin_stream);
     if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { comm_release(c->comm); c->comm = nullptr; }
     free_scene(c);
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.keys); dfree(s.keys2); dfree(s.d_status);

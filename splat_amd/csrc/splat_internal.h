@@ -91,5 +91,13 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       uint2* iters = nullptr /* per wave (scan, blend) iteration counts, statistics frames only */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
+// ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)
+struct CommState;                              // RCCL communicator + partition of one context
+CommState** ctx_comm_slot(splat_ctx* c);
+hipStream_t ctx_stream(splat_ctx* c);
+int ctx_device(const splat_ctx* c);
+int ctx_fail(splat_ctx* c, int code, const char* msg);
+void comm_release(CommState* s);               // splat_destroy -> here
+
 }  // namespace splat
 #endif

@@ -105,6 +105,29 @@ class Renderer:
                                                 C.byref(st) if want_stats else None))
         return st
 
+    # ---- multi-GPU, one process per GPU (form A of include/splat_hip.h "Multi-GPU") ---------
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128-byte RCCL id to hand to the other ranks"""
+        L = _lib.lib()
+        buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES)()
+        rc = L.splat_comm_unique_id(buf)
+        if rc != 0:
+            raise SplatError(rc, "splat_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(self._L.splat_comm_init_rank(self._h, buf, int(n_ranks), int(rank)))
+
+    def comm_set_slabs(self, slabs):
+        flat = (C.c_int32 * (2 * len(slabs)))(*[int(v) for s in slabs for v in s])
+        self._check(self._L.splat_comm_set_slabs(self._h, flat))
+
+    def comm_gather(self, d_ptr, w, h, root=0):
+        """enqueue the gather of slab rows to `root` on the context's stream (grouped ncclSend / ncclRecv)"""
+        self._check(self._L.splat_comm_gather(self._h, C.c_void_p(d_ptr), int(w), int(h), int(root)))
+
     # ---- device images without a HIP toolchain on the caller's side ------------------------
     def device_image(self, init):
         """Device copy of a uint32 [h,w] host image; returns its device address (free with device_free)."""

@@ -1,0 +1,112 @@
+"""The native multi-GPU layer of the C ABI (include/splat_hip.h "Multi-GPU", splat_amd/csrc/splat_multi.hip).
+
+CPU part (-m "not gpu"): splat_slab_partition against the Python partition it mirrors.
+GPU part (-m gpu): a frame rendered as slabs by several contexts -- one host thread each, rows gathered to the
+root -- must equal the single-context frame BYTE FOR BYTE (SURVEY.md section 8(e) correctness test).  A one-GPU
+box can list its device several times (copy transport; RCCL refuses duplicate devices), and can run RCCL
+itself with a single rank (ncclCommInitAll / ncclCommInitRank, library loading, partition plumbing)."""
+import numpy as np
+import pytest
+
+import splat_amd
+from splat_amd import dist as sdist
+from helpers import make_camera
+
+
+def test_native_partition_equals_python_partition():
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        n_rows = int(rng.integers(1, 140))
+        k = int(rng.integers(1, 12))
+        loads = (rng.random(n_rows) ** 3 * 1e6).astype(np.uint64)
+        if trial % 5 == 0:
+            loads[rng.integers(0, n_rows, n_rows // 2)] = 0          # empty tile rows
+        overhead = float(rng.choice([0.0, 2000.0]))
+        want = sdist.slab_partition_balanced(loads, k, row_overhead=overhead)
+        got = splat_amd.slab_partition_native(loads, k, overhead)
+        assert got == [tuple(s) for s in want], (n_rows, k, got, want)
+        # a partition: ordered, disjoint, covering
+        assert got[0][0] == 0 and max(b for _, b in got) == n_rows
+        for (a0, b0), (a1, b1) in zip(got, got[1:]):
+            assert b0 == a1 or (a1 == b1 == n_rows)
+
+
+def test_native_equal_partition():
+    for h, k in ((1080, 8), (2160, 8), (720, 3), (17, 4), (16, 1)):
+        want = sdist.slab_partition(h, k)
+        got = splat_amd.slab_partition_native(None, k, n_rows=(h + 15) // 16)
+        assert got == [tuple(s) for s in want]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0]])
+def test_multi_frame_equals_single_context_frame(devices):
+    g = splat_amd.synthetic_scene(60000, 33)
+    R = splat_amd.Renderer()
+    g.compute_cov3d(R)
+    cam = make_camera(392, 520, (0.1, 0.0, 4.0), yaw=0.3)      # 25 tile rows, the last one 8 px high
+    cam_c = cam.to_c(0.01)
+    R.upload(g)
+    rng = np.random.default_rng(3)
+    init = rng.integers(0, 2**32, (392, 520), dtype=np.uint64).astype(np.uint32)
+    single = init.copy()
+    st1 = R.render(cam_c, single)
+    clear = np.zeros((392, 520), np.uint32)
+    R.render(cam_c, clear)
+    R.close()
+
+    M = splat_amd.MultiRenderer(devices)
+    try:
+        M.upload(g)
+        slabs = M.balance(cam_c)
+        assert slabs[0][0] == 0 and max(b for _, b in slabs) == 25
+        # render_to_buffer form: blends onto the caller's host image
+        multi = init.copy()
+        stm = M.render(cam_c, multi)
+        assert np.array_equal(multi, single)
+        assert stm.n_pairs == st1.n_pairs            # tile rows are disjoint: pair counts add up exactly
+        # viewer-loop form: cleared frames, asynchronous, several in flight
+        for _ in range(5):
+            M.render_frame(cam_c)
+        M.sync()
+        assert np.array_equal(M.download(392, 520), clear)
+        # another target size re-partitions by itself
+        cam2 = make_camera(200, 300)
+        img2 = np.zeros((200, 300), np.uint32)
+        M.render(cam2.to_c(0.01), img2)
+        R2 = splat_amd.Renderer()
+        try:
+            R2.upload(g)
+            ref2 = np.zeros((200, 300), np.uint32)
+            R2.render(cam2.to_c(0.01), ref2)
+        finally:
+            R2.close()
+        assert np.array_equal(img2, ref2)
+    finally:
+        M.close()
+
+
+@pytest.mark.gpu
+def test_comm_single_rank_over_rccl():
+    """form (A) with one rank: RCCL is loaded, ncclGetUniqueId / ncclCommInitRank run on the GPU box, the partition
+    is applied, and a gather with nothing to exchange leaves the frame alone"""
+    g = splat_amd.synthetic_scene(20000, 34)
+    R = splat_amd.Renderer()
+    try:
+        g.compute_cov3d(R)
+        R.upload(g)
+        cam_c = make_camera(128, 192).to_c(0.01)
+        ref = np.zeros((128, 192), np.uint32)
+        R.render(cam_c, ref)
+        uid = splat_amd.Renderer.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        R.comm_init(uid, 1, 0)
+        R.comm_set_slabs(splat_amd.slab_partition_native(R.tile_row_loads(cam_c), 1, 2000.0))
+        d = R.device_image(np.zeros((128, 192), np.uint32))
+        R.render_device(cam_c, d)
+        R.comm_gather(d, 192, 128, 0)
+        R.sync()
+        assert np.array_equal(R.device_download(d, 128, 192), ref)
+        R.device_free(d)
+    finally:
+        R.close()
