@@ -64,6 +64,11 @@ struct Gaussian {               // src/gaussians.rs:30-38
 
 std::vector<Gaussian> naive_gaussians();
 std::vector<Gaussian> load_from_ply(const std::string& filename);
+struct GaussianList;
+// The loader on the fast path: the same decode, activations and recentring, straight into
+// the SoA upload buffers, on `threads` host threads (0 = all).  cov3d is left zero (compute_cov3d, K0 on the GPU).
+GaussianList load_from_ply_soa(const std::string& filename, int threads = 0);
+long long ply_vertex_count(const std::string& filename);      // header only
 
 struct GaussianList {           // src/gaussians.rs:408-416, SoA
     std::vector<float> positions;   // 4 x N (x,y,z,1)

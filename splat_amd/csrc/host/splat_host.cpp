@@ -8,7 +8,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -38,7 +41,7 @@ void rotation(float angle, const Vec3& axis, float R[9]) {
     R[3] = u[0] * u[1] * omc + u[2] * s;  R[4] = sqy + (1.0f - sqy) * c;        R[5] = u[1] * u[2] * omc - u[0] * s;
     R[6] = u[0] * u[2] * omc - u[1] * s;  R[7] = u[1] * u[2] * omc + u[0] * s;  R[8] = sqz + (1.0f - sqz) * c;
 }
-Vec3 apply(const float R[9], const Vec3& v) {
+Vec3 rotate3(const float R[9], const Vec3& v) {
     return {(R[0] * v[0] + R[1] * v[1]) + R[2] * v[2], (R[3] * v[0] + R[4] * v[1]) + R[5] * v[2],
             (R[6] * v[0] + R[7] * v[1]) + R[8] * v[2]};
 }
@@ -72,10 +75,10 @@ void Camera::compute_matrices() {
     if (cos_angle * sg > 0.99f) pitch_ = 0.0f;
     float Rx[9], Ry[9];
     rotation(yaw_, up_, Rx);
-    Vec3 p1 = add(apply(Rx, sub(position, target_)), target_);
+    Vec3 p1 = add(rotate3(Rx, sub(position, target_)), target_);
     Vec3 right = cross(up_, position);                         // the FIELD, src/camera.rs:58
     rotation(pitch_, right, Ry);
-    Vec3 eye = add(apply(Ry, sub(p1, target_)), target_);
+    Vec3 eye = add(rotate3(Ry, sub(p1, target_)), target_);
     // glm::look_at (right-handed)
     Vec3 z = normalize(sub(eye, target_)), x = normalize(cross(up_, z)), y = normalize(cross(z, x));
     Mat4 V; V.fill(0.0f);
@@ -149,18 +152,43 @@ std::vector<Gaussian> naive_gaussians() {
     return out;
 }
 
-// load_from_ply: mmap + direct decode of the vertex block (binary little endian or ascii); only
-// `float` properties are consumed, by name; a non-"vertex" element throws (the reference panics).
-std::vector<Gaussian> load_from_ply(const std::string& filename) {
+// ---- PLY (src/gaussians.rs:246-283 set_property, :375-405 load_from_ply) ---------------------------------------
+// mmap + direct decode of the vertex block (binary little endian or ascii); only `float` properties are
+// consumed, by name; a non-"vertex" element throws (the reference panics).  Binary files are decoded straight
+// into the SoA upload buffers (GaussianList) by `threads` host threads -- every value goes through the same
+// libm call whatever thread handles it, and the recentring stays one sequential f32 sum, so the result does not
+// depend on the thread count and equals the reference's load (and the oracle's reader) bit for bit.
+namespace {
+struct PlyProp { int offset, size; int dst; };      // dst: slot of the scatter table below, -1 = ignored
+struct PlyFile {
+    const char* base = nullptr; size_t len = 0;
+    int fmt = -1; long long n = -1; int stride = 0; size_t payload = 0;
+    std::vector<PlyProp> props;
+    ~PlyFile() { if (base) munmap((void*)base, len); }
+};
+// destination codes: 0-2 pos, 3-5 scale(exp), 6 opacity(sigmoid), 7-10 rot (i,j,k,w), 11.. sh[k]
+int ply_dst_of(const std::string& s) {
+    static const char* const names[] = {"x", "y", "z", "scale_0", "scale_1", "scale_2", "opacity",
+                                        "rot_1", "rot_2", "rot_3", "rot_0", "f_dc_0", "f_dc_1", "f_dc_2"};
+    for (int k = 0; k < 14; ++k)
+        if (s == names[k]) return k;
+    if (s.rfind("f_rest_", 0) == 0) {
+        int idx = std::atoi(s.c_str() + 7);
+        if (idx < 0 || idx > 44) throw std::runtime_error("f_rest index out of range");   // sh[3+index] would panic
+        return 14 + idx;
+    }
+    return -1;
+}
+void ply_open(const std::string& filename, PlyFile& f) {
     int fd = ::open(filename.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("cannot open " + filename);
     struct stat st;
     if (fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat " + filename); }
-    size_t len = (size_t)st.st_size;
-    const char* base = len ? (const char*)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    f.len = (size_t)st.st_size;
+    void* m = f.len ? mmap(nullptr, f.len, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
     ::close(fd);
-    if (len && base == MAP_FAILED) throw std::runtime_error("cannot map " + filename);
-    struct Unmap { const char* p; size_t n; ~Unmap() { if (p) munmap((void*)p, n); } } unmap{base, len};
+    if (f.len && m == MAP_FAILED) throw std::runtime_error("cannot map " + filename);
+    f.base = (const char*)m;
     auto type_size = [](const std::string& t) -> int {
         if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
         if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
@@ -168,38 +196,23 @@ std::vector<Gaussian> load_from_ply(const std::string& filename) {
         if (t == "double" || t == "float64") return 8;
         return 0;
     };
-    struct Prop { int offset, size; int dst; bool is_float; };   // dst: index into the 62-slot scatter table, -1 ignore
-    std::vector<Prop> props;
     size_t pos = 0;
     auto next_line = [&]() -> std::string {
         size_t e = pos;
-        while (e < len && base[e] != '\n') ++e;
-        std::string l(base + pos, e - pos);
-        pos = e < len ? e + 1 : e;
+        while (e < f.len && f.base[e] != '\n') ++e;
+        std::string l(f.base + pos, e - pos);
+        pos = e < f.len ? e + 1 : e;
         if (!l.empty() && l.back() == '\r') l.pop_back();
         return l;
     };
     if (next_line() != "ply") throw std::runtime_error(filename + ": not a PLY file");
-    int fmt = -1; long long n = -1; int stride = 0; bool done = false;
-    // destination codes: 0-2 pos, 3-5 scale(exp), 6 opacity(sigmoid), 7-10 rot (i,j,k,w), 11.. sh[k]
-    auto dst_of = [](const std::string& s) -> int {
-        static const char* const names[] = {"x", "y", "z", "scale_0", "scale_1", "scale_2", "opacity",
-                                            "rot_1", "rot_2", "rot_3", "rot_0", "f_dc_0", "f_dc_1", "f_dc_2"};
-        for (int k = 0; k < 14; ++k)
-            if (s == names[k]) return k;
-        if (s.rfind("f_rest_", 0) == 0) {
-            int idx = std::atoi(s.c_str() + 7);
-            if (idx < 0 || idx > 44) throw std::runtime_error("f_rest index out of range");   // sh[3+index] would panic
-            return 14 + idx;
-        }
-        return -1;
-    };
-    while (pos < len) {
+    bool done = false;
+    while (pos < f.len) {
         std::istringstream ls(next_line());
         std::string kw; ls >> kw;
-        if (kw == "format") { std::string f; ls >> f; fmt = f == "ascii" ? 0 : f == "binary_little_endian" ? 1 : -1; }
+        if (kw == "format") { std::string fm; ls >> fm; f.fmt = fm == "ascii" ? 0 : fm == "binary_little_endian" ? 1 : -1; }
         else if (kw == "element") {
-            std::string name; ls >> name >> n;
+            std::string name; ls >> name >> f.n;
             if (name != "vertex") throw std::runtime_error("Unexpected element!");
         } else if (kw == "property") {
             std::string ty, name; ls >> ty >> name;
@@ -207,44 +220,89 @@ std::vector<Gaussian> load_from_ply(const std::string& filename) {
             int sz = type_size(ty);
             if (!sz) throw std::runtime_error("unknown PLY type " + ty);
             bool isf = (ty == "float" || ty == "float32");
-            props.push_back({stride, sz, isf ? dst_of(name) : -1, isf});
-            stride += sz;
+            f.props.push_back({f.stride, sz, isf ? ply_dst_of(name) : -1});
+            f.stride += sz;
         } else if (kw == "end_header") { done = true; break; }
     }
-    if (!done || fmt < 0 || n < 0) throw std::runtime_error(filename + ": unsupported or incomplete PLY header");
-    std::vector<Gaussian> out((size_t)n);
-    auto store = [](Gaussian& g, int dst, float v) {
-        if (dst < 3) g.position[dst] = v;
-        else if (dst < 6) g.scale[dst - 3] = std::exp(v);                       // :264-266
-        else if (dst == 6) g.opacity = 1.0f / (1.0f + std::exp(-v));            // :267
-        else if (dst < 11) g.rotation[dst - 7] = v;                             // :268-271
-        else g.sh[dst - 11] = v;                                                // :272-279, no transpose
-    };
-    if (fmt == 1) {
-        if (pos + (size_t)n * stride > len) throw std::runtime_error(filename + ": truncated payload");
-        const char* p = base + pos;
-        for (long long i = 0; i < n; ++i, p += stride)
-            for (const Prop& pr : props)
-                if (pr.dst >= 0) { float v; std::memcpy(&v, p + pr.offset, 4); store(out[(size_t)i], pr.dst, v); }
+    if (!done || f.fmt < 0 || f.n < 0) throw std::runtime_error(filename + ": unsupported or incomplete PLY header");
+    f.payload = pos;
+    if (f.fmt == 1 && f.payload + (size_t)f.n * f.stride > f.len) throw std::runtime_error(filename + ": truncated payload");
+}
+// one decoded value into the SoA arrays (set_property, :261-279)
+inline void ply_store(GaussianList& l, size_t i, int dst, float v) {
+    if (dst < 3) l.positions[4 * i + dst] = v;
+    else if (dst < 6) l.scales[3 * i + dst - 3] = std::exp(v);                   // :264-266
+    else if (dst == 6) l.opacities[i] = 1.0f / (1.0f + std::exp(-v));            // :267
+    else if (dst < 11) l.rotations[4 * i + dst - 7] = v;                         // :268-271
+    else l.sh[48 * i + dst - 11] = v;                                            // :272-279, no transpose
+}
+}  // namespace
+
+GaussianList load_from_ply_soa(const std::string& filename, int threads) {
+    PlyFile f;
+    ply_open(filename, f);
+    const size_t n = (size_t)f.n;
+    GaussianList l;
+    l.num_gaussians = n;
+    l.positions.assign(4 * n, 0.0f); l.scales.assign(3 * n, 0.0f); l.opacities.assign(n, 0.0f);
+    l.rotations.assign(4 * n, 0.0f); l.sh.assign(48 * n, 0.0f); l.cov3d.assign(9 * n, 0.0f);
+    for (size_t i = 0; i < n; ++i) { l.positions[4 * i + 3] = 1.0f; l.rotations[4 * i + 3] = 1.0f; }   // Gaussian::new: identity quaternion
+    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(1, n / 4096));
+    if (f.fmt == 1) {
+        std::vector<PlyProp> used;
+        for (const PlyProp& p : f.props) if (p.dst >= 0) used.push_back(p);
+        auto work = [&](size_t a, size_t b) {
+            const char* p = f.base + f.payload + a * (size_t)f.stride;
+            for (size_t i = a; i < b; ++i, p += f.stride)
+                for (const PlyProp& pr : used) { float v; std::memcpy(&v, p + pr.offset, 4); ply_store(l, i, pr.dst, v); }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; ++t) th.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+        work(0, n / threads);
+        for (auto& x : th) x.join();
     } else {
-        const char* p = base + pos; const char* endp = base + len;
-        for (long long i = 0; i < n; ++i)
-            for (const Prop& pr : props) {
-                char* q = nullptr;
+        const char* p = f.base + f.payload; const char* endp = f.base + f.len;
+        for (size_t i = 0; i < n; ++i)
+            for (const PlyProp& pr : f.props) {
                 std::string tok;
                 while (p < endp && std::isspace((unsigned char)*p)) ++p;
                 while (p < endp && !std::isspace((unsigned char)*p)) tok.push_back(*p++);
                 if (tok.empty()) throw std::runtime_error(filename + ": truncated payload");
-                double v = std::strtod(tok.c_str(), &q);
-                if (pr.dst >= 0) store(out[(size_t)i], pr.dst, (float)v);
+                double v = std::strtod(tok.c_str(), nullptr);
+                if (pr.dst >= 0) ply_store(l, i, pr.dst, (float)v);
             }
     }
-    // recentre: sequential f32 sum (src/gaussians.rs:394-402)
-    Vec3 avg{0, 0, 0};
-    for (const Gaussian& g : out) { avg[0] += g.position[0]; avg[1] += g.position[1]; avg[2] += g.position[2]; }
-    float nf = (float)out.size();
-    avg[0] /= nf; avg[1] /= nf; avg[2] /= nf;
-    for (Gaussian& g : out) { g.position[0] -= avg[0]; g.position[1] -= avg[1]; g.position[2] -= avg[2]; }
+    // recentre: ONE sequential f32 sum in index order (src/gaussians.rs:394-402), then the subtraction in parallel
+    float ax = 0, ay = 0, az = 0;
+    for (size_t i = 0; i < n; ++i) { ax += l.positions[4 * i]; ay += l.positions[4 * i + 1]; az += l.positions[4 * i + 2]; }
+    const float nf = (float)n;
+    ax /= nf; ay /= nf; az /= nf;
+    auto sub = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) { l.positions[4 * i] -= ax; l.positions[4 * i + 1] -= ay; l.positions[4 * i + 2] -= az; }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; ++t) th.emplace_back(sub, n * t / threads, n * (t + 1) / threads);
+        sub(0, n / threads);
+        for (auto& x : th) x.join();
+    }
+    return l;
+}
+
+long long ply_vertex_count(const std::string& filename) { PlyFile f; ply_open(filename, f); return f.n; }
+
+// load_from_ply (src/gaussians.rs:375-405): the AoS `Vec<Gaussian>` the reference returns, from the same decode
+std::vector<Gaussian> load_from_ply(const std::string& filename) {
+    GaussianList l = load_from_ply_soa(filename, 0);
+    std::vector<Gaussian> out(l.num_gaussians);
+    for (size_t i = 0; i < out.size(); ++i) {
+        Gaussian& g = out[i];
+        for (int a = 0; a < 3; ++a) { g.position[a] = l.positions[4 * i + a]; g.scale[a] = l.scales[3 * i + a]; }
+        g.opacity = l.opacities[i];
+        std::memcpy(g.rotation.data(), &l.rotations[4 * i], 16);
+        std::memcpy(g.sh.data(), &l.sh[48 * i], 192);
+    }
     return out;
 }
 
@@ -344,23 +402,37 @@ void splat_host_camera(float h, float w, const float* pos, float yaw, float pitc
     if (update) cam.update_camera_pose();
     *out = cam.constants(lowpass, 15);
 }
-// returns n (or -1 with the message in err); arrays may be NULL to query the count
+// returns n (or -1 with the message in err); arrays may be NULL to query the count (header only)
 long long splat_host_load_ply(const char* path, float* pos4, float* scales3, float* opacity, float* rot4, float* sh48,
                               char* err, int errlen) {
     try {
-        std::vector<splat::Gaussian> v = splat::load_from_ply(path);
-        if (pos4) {
-            splat::GaussianList l = splat::GaussianList::from_vec(v, false);
-            std::memcpy(pos4, l.positions.data(), l.positions.size() * 4);
-            std::memcpy(scales3, l.scales.data(), l.scales.size() * 4);
-            std::memcpy(opacity, l.opacities.data(), l.opacities.size() * 4);
-            std::memcpy(rot4, l.rotations.data(), l.rotations.size() * 4);
-            std::memcpy(sh48, l.sh.data(), l.sh.size() * 4);
+        if (!pos4) {
+            return splat::ply_vertex_count(path);
         }
-        return (long long)v.size();
+        splat::GaussianList l = splat::load_from_ply_soa(path, 0);
+        std::memcpy(pos4, l.positions.data(), l.positions.size() * 4);
+        std::memcpy(scales3, l.scales.data(), l.scales.size() * 4);
+        std::memcpy(opacity, l.opacities.data(), l.opacities.size() * 4);
+        std::memcpy(rot4, l.rotations.data(), l.rotations.size() * 4);
+        std::memcpy(sh48, l.sh.data(), l.sh.size() * 4);
+        return (long long)l.num_gaussians;
     } catch (const std::exception& e) {
         if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
         return -1;
+    }
+}
+// the loader alone, timed: decode + activations + recentring into the SoA buffers with `threads` host threads
+// (0 = all); returns seconds, or -1.  *n_out = Gaussians loaded.
+double splat_host_time_load(const char* path, int threads, long long* n_out, char* err, int errlen) {
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        splat::GaussianList l = splat::load_from_ply_soa(path, threads);
+        auto t1 = std::chrono::steady_clock::now();
+        if (n_out) *n_out = (long long)l.num_gaussians;
+        return std::chrono::duration<double>(t1 - t0).count();
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1.0;
     }
 }
 void splat_host_cov3d(unsigned long long n, const float* scales3, const float* rot4, float* cov3d) {

@@ -1021,10 +1021,14 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     if (rc != SPLAT_OK) return rc;
     if (c->last_slot < 0) return fail(c, SPLAT_ERR_INVALID, "no frame rendered yet");
     const Slot& s = c->slots[c->last_slot];
+    // The 48-byte records are the ones the frame itself was composited from (written by whichever flavour of K1
+    // rendered it -- preprocess_kernel<true> on the default one-pass path); they are read FIRST.
+    std::vector<Rec> r(n); std::vector<float> d(n); std::vector<ushort4> q(n);
+    HIP_TRY(c, hipMemcpy(r.data(), s.recs, sizeof(Rec) * n, hipMemcpyDeviceToHost));
     {
-        // one-pass binning keeps depth and rectangle in registers only, and block culling skips
-        // whole blocks: recompute every Gaussian with the counting flavour of K1, culling off (same
-        // code, same values), then clear its counts again
+        // Depth and pixel rectangle exist only in registers on the one-pass path, and block culling skips whole
+        // blocks (whose records above are then stale, for Gaussians that reach nothing): recompute those two with
+        // the counting flavour of K1, culling off (same code, same values), then clear its counts again.
         FrameConst fc = c->fc;
         fc.bucket_cap = 0; fc.cull_blocks = 0;
         HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
@@ -1033,8 +1037,6 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
         HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    std::vector<Rec> r(n); std::vector<float> d(n); std::vector<ushort4> q(n);
-    HIP_TRY(c, hipMemcpy(r.data(), s.recs, sizeof(Rec) * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(d.data(), s.depth, sizeof(float) * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(q.data(), s.rect, sizeof(ushort4) * n, hipMemcpyDeviceToHost));
     for (uint64_t j = 0; j < n; ++j) {          // depth/rect live in slot order, records in original order

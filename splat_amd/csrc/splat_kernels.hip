@@ -623,6 +623,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         // fragments with power < pthr have alpha < 1/255 for certain (margin 1e-3 >> f32 error)
         float pthr = (opacity > 0.0f) ? (logf(1.0f / (255.0f * opacity)) - 1e-3f)
                                       : ((opacity <= 0.0f) ? 3.0e38f : -3.0e38f);
+        // A colour that is not finite (SH coefficients of +-inf / NaN) is stored as the finite value that blends
+        // to the same byte for every ACCEPTED fragment (alpha >= 1/255: +inf and FLT_MAX both saturate to 255,
+        // -inf / NaN / -FLT_MAX all end at 0 through the saturating cast, src/pipelines.rs:159-161), so that a
+        // REJECTED fragment's 0 * colour is 0 as in the reference, whose rejected fragment is (0,0,0,0)
+        // (src/pipelines.rs:135-143), and not 0 * inf = NaN.  Finite colours are untouched.
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float v = col[ch];
+            col[ch] = (v != v) ? -3.402823466e+38f : fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);
+        }
         Rec r;
         r.a = make_float4(cx, cy, hx, hy);
         r.b = make_float4(ca, fc.y_up ? cb : -cb, cc, opacity);   // cross term carries the y-axis sign (exact)

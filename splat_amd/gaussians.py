@@ -127,10 +127,16 @@ def write_ply(filename, raw, n):
         data.tofile(f)
 
 
-def trim_ply(src, dst, count=3):
-    """Fixture tooling, the counterpart of src/bin/00_ply_load.rs (`trim <in> <out>`: copy the first
-    three vertices into a new PLY with the same header): keeps the first `count` vertices of a
-    binary-little-endian or ascii PLY, any property list."""
+def trim_ply(src, dst, count=3, mode="first", seed=0):
+    """Fixture tooling, the counterpart of src/bin/00_ply_load.rs (`trim <in> <out>`: copy the
+    first three vertices into a new PLY with the same header).  Works on a binary-little-endian or ascii PLY
+    with any property list; the header is kept, only the vertex count changes.
+      mode="first":  the first `count` vertices (what the reference's tool does, with count = 3)
+      mode="random": `count` vertices drawn without replacement from a seeded generator, kept in file order
+                     (a subsample that still looks like the scene: for cutting small goldens from real scenes)
+    Returns the number of vertices written."""
+    if mode not in ("first", "random"):
+        raise ValueError("mode must be 'first' or 'random'")
     with open(src, "rb") as f:
         header = []
         while True:
@@ -155,7 +161,23 @@ def trim_ply(src, dst, count=3):
                 header[k] = ("element vertex %d\n" % count).encode()
             elif t[:1] == ["property"]:
                 stride += sizes[t[1]]
-        body = b"".join(f.readline() for _ in range(count)) if fmt == "ascii" else f.read(stride * count)
+        if fmt not in ("ascii", "binary_little_endian") or n is None:
+            raise ValueError("%s: unsupported PLY (format %r)" % (src, fmt))
+        if mode == "first":
+            body = b"".join(f.readline() for _ in range(count)) if fmt == "ascii" else f.read(stride * count)
+        else:
+            pick = np.sort(np.random.default_rng(seed).choice(n, size=count, replace=False))
+            if fmt == "ascii":
+                want, rows = set(pick.tolist()), []
+                for i in range(n):
+                    line = f.readline()
+                    if i in want:
+                        rows.append(line)
+                body = b"".join(rows)
+            else:
+                payload = np.memmap(src, dtype=np.dtype((np.void, stride)), mode="r", offset=f.tell(), shape=(n,))
+                body = np.ascontiguousarray(payload[pick]).tobytes()
+                del payload
     with open(dst, "wb") as f:
         f.write(b"".join(header))
         f.write(body)

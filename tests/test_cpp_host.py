@@ -147,3 +147,41 @@ def test_plain_c_client(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "splat_amd", "render_c"), out], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "4 visible" in r.stdout and os.path.getsize(out) == len("P6\n320 240\n255\n") + 320 * 240 * 3
+
+
+GOLD_KAT = None
+
+
+def _kat():
+    global GOLD_KAT
+    if GOLD_KAT is None:
+        import json
+        GOLD_KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "notebook_kat.json")))
+    return GOLD_KAT
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_cpp_and_python_cameras_vs_reference_derived_vectors(H, ci):
+    """the C++ camera and the oracle's are the same code typed twice, so "bit equal to the
+    oracle" proves little.  Here BOTH host cameras (C++ splat::Camera, Python splat_amd.Camera) are held directly
+    against the view / projection matrices and htan/focal that the reference's own Python prototype produced
+    (tests/golden/notebook_kat.json, generated by make_notebook_kat.py from notes/util.py)."""
+    case = _kat()["cases"][ci]
+    want_v, want_p = np.array(case["view"]), np.array(case["proj"])
+    # C++ (libsplat_host.so)
+    out = _lib.CameraC()
+    p = np.asarray(case["pos"], np.float32)
+    H.splat_host_camera(float(case["h"]), float(case["w"]), _fp(p), 0.0, 0.0, 1, 0.3, C.byref(out))
+    V = np.array(out.view[:]).reshape(4, 4).T            # column-major -> [row][col]
+    P = np.array(out.proj[:]).reshape(4, 4).T
+    np.testing.assert_allclose(V, want_v, atol=2e-7)
+    np.testing.assert_allclose(P, want_p, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose([out.htanx, out.htany, out.focal], case["htanfovxy_focal"], rtol=1e-6)
+    # Python (splat_amd/camera.py)
+    cam = splat_amd.Camera(case["h"], case["w"], case["pos"])
+    cam.update_camera_pose()
+    np.testing.assert_allclose(cam.get_view_matrix(), want_v, atol=2e-7)
+    np.testing.assert_allclose(cam.get_project_matrix(), want_p, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(cam.get_htanfovxy_focal(), case["htanfovxy_focal"], rtol=1e-6)
+    c = cam.to_c(0.3)
+    assert list(c.view) == list(out.view) and list(c.proj) == list(out.proj)     # and the two mirrors agree bit for bit

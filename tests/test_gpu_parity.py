@@ -230,6 +230,25 @@ def test_empty_and_degenerate_scenes(R):
     assert not img.any()
 
 
+def test_non_finite_colours_follow_the_reference(R):
+    """SH coefficients of +-inf / NaN.  An ACCEPTED fragment saturates (inf -> 255, -inf and
+    NaN -> 0 through `as u8`, src/pipelines.rs:159-161); a REJECTED fragment is (0,0,0,0) in the reference
+    (src/pipelines.rs:135-143) and must leave RGB alone -- not 0 * inf = NaN -> 0."""
+    g = gpu_scene(R, 3000, 27)
+    g.sh[0:600:3, 0] = np.inf
+    g.sh[1:600:3, 1] = -np.inf
+    g.sh[2:600:3, 2] = np.nan
+    g.sh[600:800, :3] = np.inf
+    cam = make_camera(160, 208)
+    rng = np.random.default_rng(2)
+    init = rng.integers(0, 2**32, (160, 208), dtype=np.uint64).astype(np.uint32)
+    img, st, ref, ost = render_both(R, g, cam, 0.01, init=init)
+    mx, cnt = image_diff(img, ref)
+    assert st.n_pairs == ost.n_tile_pairs
+    assert mx <= TOL_LSB, (mx, cnt)
+    assert cnt <= 1e-3 * img.size, (mx, cnt)
+
+
 def test_deterministic_and_repeatable(R):
     """atomics place pairs in arbitrary bucket order; the sort makes the frame deterministic"""
     g = gpu_scene(R, 40000, 8)

@@ -153,3 +153,57 @@ def test_trim_ply_first_three(tmp_path):
     assert a["pos4"].shape[0] == 3
     assert np.array_equal(a["sh"], O.load_ply(p)["sh"][:3])          # payload copied verbatim
     assert np.allclose(a["rot"][:, 3], raw["rot_0"][:3])
+
+
+def test_trim_ply_random_k(tmp_path):
+    """SURVEY section 8(f)-4: the random-k subsampler -- seeded, without replacement, file order kept, payload verbatim;
+    binary and ascii"""
+    p, raw = _write_fixture(tmp_path, n=400, seed=4)
+    full = O.load_ply(p)
+    out = str(tmp_path / "rand.ply")
+    assert splat_amd.trim_ply(p, out, count=37, mode="random", seed=9) == 37
+    a = O.load_ply(out)
+    pick = np.sort(np.random.default_rng(9).choice(400, size=37, replace=False))
+    assert len(set(pick.tolist())) == 37
+    assert np.array_equal(a["sh"], full["sh"][pick])                     # the chosen vertices, in file order
+    assert np.array_equal(a["opacity"], full["opacity"][pick])
+    out2 = str(tmp_path / "rand2.ply")
+    splat_amd.trim_ply(p, out2, count=37, mode="random", seed=9)
+    assert open(out, "rb").read() == open(out2, "rb").read()            # deterministic
+    splat_amd.trim_ply(p, out2, count=37, mode="random", seed=10)
+    assert open(out, "rb").read() != open(out2, "rb").read()
+    assert splat_amd.trim_ply(p, out2, count=1000, mode="random") == 400   # count clamps to the file
+    # ascii source
+    src = str(tmp_path / "ascii.ply")
+    with open(src, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 6\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        for i in range(6):
+            f.write("%d %d %d\n" % (i, 10 * i, 100 * i))
+    dst = str(tmp_path / "ascii_r.ply")
+    assert splat_amd.trim_ply(src, dst, count=3, mode="random", seed=1) == 3
+    rows = open(dst).read().split("end_header\n")[1].strip().split("\n")
+    want = np.sort(np.random.default_rng(1).choice(6, size=3, replace=False))
+    assert [int(r.split()[0]) for r in rows] == want.tolist()
+    with pytest.raises(ValueError):
+        splat_amd.trim_ply(src, dst, mode="middle")
+
+
+def test_threaded_loader_is_independent_of_the_thread_count(tmp_path):
+    """SURVEY section 8(f)-1: the loader on the fast path decodes straight into the SoA buffers on many host threads;
+    the result must not depend on how many (same libm call per value, ONE sequential f32 sum for the recentring)
+    and must be the oracle reader's, bit for bit"""
+    import ctypes as C
+    import os
+    raw = splat_amd.gaussians.synthetic_raw(20000, 8)
+    p = str(tmp_path / "t.ply")
+    splat_amd.write_ply(p, raw, 20000)
+    g = splat_amd.load_from_ply(p)                   # all host threads
+    a = O.load_ply(p)
+    assert np.array_equal(g.positions, a["pos4"]) and np.array_equal(g.scales, a["scales"])
+    assert np.array_equal(g.opacities, a["opacity"]) and np.array_equal(g.rotations, a["rot"]) and np.array_equal(g.sh, a["sh"])
+    L = C.CDLL(os.path.join(os.path.dirname(splat_amd.__file__), "libsplat_host.so"))
+    L.splat_host_time_load.restype = C.c_double
+    L.splat_host_time_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
+    n = C.c_longlong()
+    for threads in (1, 3, 0):
+        assert L.splat_host_time_load(p.encode(), threads, C.byref(n), None, 0) > 0 and n.value == 20000
