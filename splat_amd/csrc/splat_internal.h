@@ -12,6 +12,7 @@ constexpr int TILE = SPLAT_TILE;
 constexpr int SCENE_PLANES = 16;  // float4 planes per Gaussian (see pack_scene_kernel)
 constexpr int LIVE_PLANES = 10;   // planes read per frame at sh_dim <= 27 (160 B / Gaussian)
 
+
 // Everything a frame's kernels need, passed by value (kernarg -> SGPRs).
 struct FrameConst {
     float view[16];

@@ -154,12 +154,14 @@ constexpr int AGG_MAX_TILES = 64;
 
 constexpr int BIG_CAP = 256;           // close-up Gaussians handled per block-round
 
-struct BinShared {
+template <int CAP>
+struct BinSharedT {
+    static constexpr int cap = CAP;
     // The close-up arrays share the table's memory: close-ups are expanded after the table has done its work
     // (a workgroup barrier separates the two uses), and 6 KB less LDS per workgroup is room for another
     // kernel's workgroups on the CU (the compositor of the previous frame runs beside K1).
     union {
-        unsigned int table[AGG_CAP];
+        unsigned int table[CAP];
         struct {
             unsigned int big[BIG_CAP][4];  // the block's big rectangles: x0 | y0 << 16, width, tile count, first flat index
             unsigned long long bigkey[BIG_CAP];
@@ -167,24 +169,35 @@ struct BinShared {
     };
     int box[4];                        // min tx, min ty, max tx, max ty of the aggregated Gaussians
     unsigned int nbig;
-    unsigned int nvis, nsing;          // block totals for the frame statistics (bin_bucket)
+    unsigned int nvis, nsing;          // block totals for the frame statistics (BucketBinner)
     unsigned int bigtotal;             // tiles of all big rectangles together
 };
+using BinShared = BinSharedT<AGG_CAP>;       // two-pass binning: dense table over the block's tile bounding box
+// One-pass binning hashes tile coordinates into a HASH_DIM x HASH_DIM table (see BucketBinner).  32 x 32 tiles =
+// 512 x 512 pixels covers the footprint of 256 Morton neighbours at every pose measured; a block that does not
+// fit places its pairs one atomic each.  Against 64 x 64: a quarter of the table to clear and to scan per block,
+// four reservations per thread to keep in registers instead of sixteen, 10 KB less LDS per workgroup.
+#ifndef SPLAT_HASH_BITS
+#define SPLAT_HASH_BITS 5
+#endif
+constexpr int HASH_BITS = SPLAT_HASH_BITS, HASH_DIM = 1 << HASH_BITS, HASH_CAP = HASH_DIM * HASH_DIM;
+using BucketShared = BinSharedT<(HASH_CAP * 4 > BIG_CAP * 24 ? HASH_CAP : BIG_CAP * 6)>;   // (the close-up arrays need 6 KB)
 
 // Close-ups (more than AGG_MAX_TILES tiles): the tiles of ALL the block's big rectangles form one
 // flat index space that the 256 threads stride over, so every returning global atomic of the
 // block is in flight at once (rectangle by rectangle it was one memory round trip per rectangle:
 // 0.6-13 k cycles per block on C3, and unbounded for a camera inside the scene).
 // Call with sh.nbig rectangles stored (add_big) and a barrier passed; ends without a barrier.
-__device__ __forceinline__ void add_big(BinShared& sh, int tx0, int tx1, int ty0, int ty1, unsigned long long key) {
+template <typename SH>
+__device__ __forceinline__ void add_big(SH& sh, int tx0, int tx1, int ty0, int ty1, unsigned long long key) {
     const unsigned int k = atomicAdd(&sh.nbig, 1u);
     const unsigned int w = (unsigned int)(tx1 - tx0 + 1);
     sh.big[k][0] = (unsigned int)tx0 | ((unsigned int)ty0 << 16); sh.big[k][1] = w;
     sh.big[k][2] = w * (unsigned int)(ty1 - ty0 + 1);
     sh.bigkey[k] = key;
 }
-template <typename F>
-__device__ __forceinline__ void expand_big(BinShared& sh, int tiles_x, F f) {
+template <typename SH, typename F>
+__device__ __forceinline__ void expand_big(SH& sh, int tiles_x, F f) {
     const unsigned int tid = threadIdx.x, nbig = sh.nbig;
     if (tid == 0) {
         unsigned int run = 0;
@@ -205,9 +218,9 @@ __device__ __forceinline__ void expand_big(BinShared& sh, int tiles_x, F f) {
 // G Gaussians per thread per call: the fixed costs (bbox reduce, table zero/flush, ~6 barriers)
 // are paid once per 256*G Gaussians.
 // bin_preinit: K1<BUCKET> zeroes the table and resets box / nbig / counters before its long vertex
-// stage (bin_bucket expects that and a barrier).
-__device__ __forceinline__ void bin_preinit(BinShared& sh) {
-    for (int e = (int)threadIdx.x; e < AGG_CAP; e += 256) sh.table[e] = 0;
+// stage (BucketBinner expects that and a barrier).
+__device__ __forceinline__ void bin_preinit(BucketShared& sh) {
+    for (int e = (int)threadIdx.x; e < HASH_CAP; e += 256) sh.table[e] = 0;
     if (threadIdx.x == 0) { sh.box[0] = 0x7fffffff; sh.box[1] = 0x7fffffff; sh.box[2] = -1; sh.box[3] = -1; sh.nbig = 0; sh.nvis = 0; sh.nsing = 0; }
 }
 template <bool EMIT, int G>
@@ -325,25 +338,45 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
 // One-pass binning for K1<BUCKET>: the same aggregation as bin_block<EMIT>, reorganised to need
 // three barriers instead of six (a K1 block is latency bound: every barrier also waits for the
 // slowest of its four waves).  The LDS table is addressed by a hash of the tile coordinates,
-//     slot(tx, ty) = (ty & 63) * 64 + ((tx + 17 ty) & 63),
-// which is collision-free whenever the block's tile bounding box is at most 64 x 64 -- so counting can
+//     slot(tx, ty) = (ty mod D) * D + ((tx + 17 ty) mod D),      D = HASH_DIM
+// which is collision-free whenever the block's tile bounding box is at most D x D -- so counting can
 // start before the bounding box is known; the box (LDS atomics, no barrier of its own) is only
 // needed afterwards, to validate the hash and to turn slots back into tiles.  A block that fails the
-// validation (incoherent: its Gaussians are spread over more than 64 tiles in x or y) places its
+// validation (incoherent: its Gaussians are spread over more than D tiles in x or y) places its
 // pairs with one global atomic each.  Block statistics ride on the same barriers.
+//
+// Two phases, so that the caller can put independent work between them:
+//   reserve()  count the block's pairs per tile in LDS, then ISSUE one returning global atomic per touched
+//              tile (the reservation of the block's run in that tile's bucket).  The results stay in
+//              registers: nothing waits for them yet.
+//   place()    wait for the reservations, hand out the slots with LDS atomics, store the keys.
+// K1 evaluates the SH colour and writes the record in between: the round trip to the memory-side atomic
+// unit (a third of a block's life when it was waited for on the spot) hides under the SH planes' loads.
 // The caller has run bin_preinit() and a barrier.
-__device__ __forceinline__ void bin_bucket(BinShared& sh, bool vis, bool singular, int tx0, int tx1, int ty0, int ty1, int tiles_x,
-                                           unsigned int* __restrict__ gcount, unsigned long long* __restrict__ keys,
-                                           unsigned long long key, unsigned int bcap, unsigned int* __restrict__ blockinfo) {
-    const unsigned int tid = threadIdx.x, lane = tid & 63u;
-    auto put = [&](unsigned int tile, unsigned int slot, unsigned long long k) {
+struct BucketBinner {
+    static constexpr int LANE_T = 9;       // see bin_block
+    static constexpr int NRES = HASH_CAP / 256;
+    BucketShared& sh;
+    const int tiles_x;
+    unsigned int* __restrict__ const gcount;
+    unsigned long long* __restrict__ const keys;
+    const unsigned int bcap;
+    // this thread's rectangle
+    int tx0, tx1, ty0, ty1, w, ntiles;
+    bool small, big, hashed, any;
+    int bx0, by0;
+    unsigned int res[NRES];                // reservations in flight: bucket position of the block's run, per table slot
+
+    __device__ __forceinline__ BucketBinner(BucketShared& s, int tiles_x_, unsigned int* g, unsigned long long* k, unsigned int cap)
+        : sh(s), tiles_x(tiles_x_), gcount(g), keys(k), bcap(cap) {}
+    __device__ __forceinline__ static unsigned int hslot(int tx, int ty) { return (unsigned int)(((ty & (HASH_DIM - 1)) << HASH_BITS) | ((tx + 17 * ty) & (HASH_DIM - 1))); }
+    __device__ __forceinline__ void put(unsigned int tile, unsigned int slot, unsigned long long k) const {
         if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
-    };
-    auto hslot = [](int tx, int ty) -> unsigned int { return (unsigned int)(((ty & 63) << 6) | ((tx + 17 * ty) & 63)); };
-    const int w = tx1 - tx0 + 1, ntiles = vis ? w * (ty1 - ty0 + 1) : 0;
-    const bool small = vis && ntiles <= AGG_MAX_TILES, big = vis && !small;
-    constexpr int LANE_T = 9;
-    auto each_tile = [&](auto f) {          // see bin_block
+    }
+    // f(tx, ty, key) for every tile of the thread's aggregated rectangle (see bin_block's each_tile)
+    template <typename F>
+    __device__ __forceinline__ void each_tile(unsigned long long key, F f) const {
+        const unsigned int lane = threadIdx.x & 63u;
         if (small && ntiles <= LANE_T)
             for (int ty = ty0; ty <= ty1; ++ty)
                 for (int tx = tx0; tx <= tx1; ++tx) f(tx, ty, key);
@@ -360,57 +393,78 @@ __device__ __forceinline__ void bin_bucket(BinShared& sh, bool vis, bool singula
                 f(X0 + dx, Y0 + dy, ((unsigned long long)khi << 32) | klo);
             }
         }
-    };
-    {   // block statistics and bounding box of the aggregated rectangles: wave reduce, LDS atomics by lane 0
-        const unsigned int nv = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vis));
-        const unsigned int ns = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(singular));
-        int a = small ? tx0 : 0x7fffffff, b = small ? ty0 : 0x7fffffff, c = small ? tx1 : -1, d = small ? ty1 : -1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            a = min(a, __shfl_xor(a, o)); b = min(b, __shfl_xor(b, o));
-            c = max(c, __shfl_xor(c, o)); d = max(d, __shfl_xor(d, o));
-        }
-        if (lane == 0) {
-            if (nv) atomicAdd(&sh.nvis, nv);
-            if (ns) atomicAdd(&sh.nsing, ns);
-            if (c >= 0) { atomicMin(&sh.box[0], a); atomicMin(&sh.box[1], b); atomicMax(&sh.box[2], c); atomicMax(&sh.box[3], d); }
-        }
     }
-    each_tile([&](int tx, int ty, unsigned long long) { atomicAdd(&sh.table[hslot(tx, ty)], 1u); });
-    __syncthreads();
-    const int bx0 = sh.box[0], by0 = sh.box[1];
-    const bool any = sh.box[2] >= 0;
-    const bool hashed = any && (sh.box[2] - bx0) < 64 && (sh.box[3] - by0) < 64;
-    // block statistics as a plain store (summed on the host when statistics are asked for): 5860
-    // atomics per frame on one counter are not free on the memory-side atomic unit the reservations use
-    if (tid == 0) blockinfo[blockIdx.x] = sh.nvis | (sh.nsing << 9);
-    if (hashed) {
-        // reserve every touched tile's run in its bucket: one returning global atomic per (block, tile)
-        for (int e = (int)tid; e < AGG_CAP; e += 256) {
-            const unsigned int c = sh.table[e];
-            if (c) {
-                const int ty = by0 + (((e >> 6) - by0) & 63);
-                const int tx = bx0 + (((e & 63) - 17 * ty - bx0) & 63);
-                sh.table[e] = atomicAdd(&gcount[(unsigned int)(ty * tiles_x + tx)], c);
+    __device__ __forceinline__ void reserve(bool vis, bool singular, int tx0_, int tx1_, int ty0_, int ty1_,
+                                            unsigned int* __restrict__ blockinfo) {
+        const unsigned int tid = threadIdx.x, lane = tid & 63u;
+        tx0 = tx0_; tx1 = tx1_; ty0 = ty0_; ty1 = ty1_;
+        w = tx1 - tx0 + 1; ntiles = vis ? w * (ty1 - ty0 + 1) : 0;
+        small = vis && ntiles <= AGG_MAX_TILES; big = vis && !small;
+        {   // block statistics and bounding box of the aggregated rectangles: wave reduce, LDS atomics by lane 0
+            const unsigned int nv = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vis));
+            const unsigned int ns = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(singular));
+            int a = small ? tx0 : 0x7fffffff, b = small ? ty0 : 0x7fffffff, c = small ? tx1 : -1, d = small ? ty1 : -1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a = min(a, __shfl_xor(a, o)); b = min(b, __shfl_xor(b, o));
+                c = max(c, __shfl_xor(c, o)); d = max(d, __shfl_xor(d, o));
+            }
+            if (lane == 0) {
+                if (nv) atomicAdd(&sh.nvis, nv);
+                if (ns) atomicAdd(&sh.nsing, ns);
+                if (c >= 0) { atomicMin(&sh.box[0], a); atomicMin(&sh.box[1], b); atomicMax(&sh.box[2], c); atomicMax(&sh.box[3], d); }
             }
         }
+        each_tile(0ull, [&](int tx, int ty, unsigned long long) { atomicAdd(&sh.table[hslot(tx, ty)], 1u); });
         __syncthreads();
-        each_tile([&](int tx, int ty, unsigned long long k) {
-            const unsigned int slot = atomicAdd(&sh.table[hslot(tx, ty)], 1u);
-            put((unsigned int)(ty * tiles_x + tx), slot, k);
-        });
-    } else if (any) {
-        each_tile([&](int tx, int ty, unsigned long long k) {
-            const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
-            put(tile, atomicAdd(&gcount[tile], 1u), k);
-        });
+        bx0 = sh.box[0]; by0 = sh.box[1];
+        any = sh.box[2] >= 0;
+        hashed = any && (sh.box[2] - bx0) < HASH_DIM && (sh.box[3] - by0) < HASH_DIM;
+        // block statistics as a plain store (summed on the host when statistics are asked for): 5860
+        // atomics per frame on one counter are not free on the memory-side atomic unit the reservations use
+        if (tid == 0) blockinfo[blockIdx.x] = sh.nvis | (sh.nsing << 9);
+#pragma unroll
+        for (int q = 0; q < NRES; ++q) res[q] = 0xffffffffu;
+        if (hashed) {
+            // reserve every touched tile's run in its bucket: one returning global atomic per (block, tile)
+#pragma unroll
+            for (int q = 0; q < NRES; ++q) {
+                const int e = (int)tid + 256 * q;
+                const unsigned int c = sh.table[e];
+                if (c) {
+                    const int ty = by0 + (((e >> HASH_BITS) - by0) & (HASH_DIM - 1));
+                    const int tx = bx0 + (((e & (HASH_DIM - 1)) - 17 * ty - bx0) & (HASH_DIM - 1));
+                    res[q] = atomicAdd(&gcount[(unsigned int)(ty * tiles_x + tx)], c);
+                }
+            }
+        }
     }
-    // close-ups (more than AGG_MAX_TILES tiles): the whole block takes the tiles of each, one per thread
-    if (__syncthreads_or(big ? 1 : 0) == 0) return;
-    if (big) add_big(sh, tx0, tx1, ty0, ty1, key);
-    __syncthreads();
-    expand_big(sh, tiles_x, [&](unsigned int tile, unsigned long long kk) { put(tile, atomicAdd(&gcount[tile], 1u), kk); });
-}
+    __device__ __forceinline__ void place(unsigned long long key) {
+        const unsigned int tid = threadIdx.x;
+        if (hashed) {
+#pragma unroll
+            for (int q = 0; q < NRES; ++q)
+                if (res[q] != 0xffffffffu) sh.table[(int)tid + 256 * q] = res[q];
+            __syncthreads();
+            each_tile(key, [&](int tx, int ty, unsigned long long k) {
+                const unsigned int slot = atomicAdd(&sh.table[hslot(tx, ty)], 1u);
+                put((unsigned int)(ty * tiles_x + tx), slot, k);
+            });
+        } else if (any) {
+            each_tile(key, [&](int tx, int ty, unsigned long long k) {
+                const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
+                put(tile, atomicAdd(&gcount[tile], 1u), k);
+            });
+        }
+        // close-ups (more than AGG_MAX_TILES tiles): the whole block takes the tiles of each, one per thread
+        if (__syncthreads_or(big ? 1 : 0) == 0) return;
+        if (big) add_big(sh, tx0, tx1, ty0, ty1, key);
+        __syncthreads();
+        expand_big(sh, tiles_x, [&](unsigned int tile, unsigned long long kk) { put(tile, atomicAdd(&gcount[tile], 1u), kk); });
+    }
+};
+
+struct NoBinner { template <typename... A> __device__ __forceinline__ NoBinner(A&&...) {} };   // two-pass binning: K1 only counts
 
 // order-preserving u32 of an f32 (ascending z == far first in a right-handed view)
 __device__ __forceinline__ unsigned int depth_key(float z) {
@@ -485,15 +539,24 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                                          const BlockBounds* __restrict__ bounds,
                                                          unsigned int* __restrict__ blockinfo,
                                                          FrameStatus* __restrict__ status) {
-    __shared__ BinShared sh;
+    __shared__ std::conditional_t<BUCKET, BucketShared, BinShared> sh;
     __shared__ unsigned int swave[4];
-    __shared__ unsigned int sbase;
-    // whole block off this context's slab / target: nothing to read, count or emit
-    // (the flag is a plain store: thousands of culled blocks retire within microseconds, and that
-    // many atomics on one counter took longer than the blocks they counted)
-    if (fc.cull_blocks) {
+    __shared__ unsigned int sbase, sreach;
+    if constexpr (BUCKET) {
+        // Block culling rides on the barrier the table reset needs anyway: wave 0 alone runs the bounds test (a
+        // few hundred instructions that used to be issued by all four waves) while the others clear the table.
+        if (fc.cull_blocks && threadIdx.x < 64u) {
+            const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
+            // (the flag is a plain store: thousands of culled blocks retire within microseconds, and that
+            // many atomics on one counter took longer than the blocks they counted)
+            if (threadIdx.x == 0) { sreach = reach ? 1u : 0u; blockinfo[blockIdx.x] = reach ? 0u : 0x80000000u; }   // (binning overwrites a 0 with its counts)
+        }
+        bin_preinit(sh);
+        __syncthreads();
+        if (fc.cull_blocks && sreach == 0u) return;          // whole block off this context's slab / target: nothing to read
+    } else if (fc.cull_blocks) {
         const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
-        if (threadIdx.x == 0) blockinfo[blockIdx.x] = reach ? 0u : 0x80000000u;     // (one-pass binning overwrites a 0 with its counts)
+        if (threadIdx.x == 0) blockinfo[blockIdx.x] = reach ? 0u : 0x80000000u;
         if (!reach) return;
     }
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -501,7 +564,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
     float F[64];
     float cx = 0, cy = 0, hx = 0, hy = 0, ca = 0, cb = 0, cc = 0, zview = 0;
-    if (BUCKET) { bin_preinit(sh); __syncthreads(); }   // (all four waves are here at once: a cheap barrier)
     if (i < n) {
         // geometry first: position, opacity, cov3d live in planes 0-3 (64 B); the SH planes are
         // only fetched for Gaussians that reach this context's slab
@@ -569,6 +631,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                 : make_ushort4(1, 0, 1, 0);
         }
     }
+    std::conditional_t<BUCKET, BucketBinner, NoBinner> binner(sh, fc.tiles_x, counts, keys, fc.bucket_cap);
+    if constexpr (BUCKET) binner.reserve(in_slab, singular, tx0, tx1, ty0, ty1, blockinfo);     // reservations in flight from here on
     if (in_slab) {
 #pragma unroll
         for (int p = 4; p < LIVE_PLANES; ++p) {
@@ -639,30 +703,28 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         r.c = make_float4(col[0], col[1], col[2], pthr);
         recs[orig[i]] = r;
     }
-    if (BUCKET) {
+    if constexpr (BUCKET) {
         const unsigned long long key = in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)orig[i]) : 0ull;
-        bin_bucket(sh, in_slab, singular, tx0, tx1, ty0, ty1, fc.tiles_x, counts, keys, key, fc.bucket_cap, blockinfo);
-        return;
-    }
-    // compact the slots that reach the slab into vislist (K2 runs over those only)
-    {
-        const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(in_slab);
-        if (lane == 0) swave[wave] = (unsigned int)__builtin_popcountll(m);
-        const int nsing = __syncthreads_count(singular);
-        const unsigned int nvis = swave[0] + swave[1] + swave[2] + swave[3];
-        if (threadIdx.x == 0) {
-            sbase = nvis ? (unsigned int)atomicAdd(&status->n_visible, (unsigned long long)nvis) : 0u;
-            if (nsing) atomicAdd(&status->n_singular, (unsigned long long)nsing);
+        binner.place(key);
+    } else {
+        // compact the slots that reach the slab into vislist (K2 runs over those only)
+        {
+            const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(in_slab);
+            if (lane == 0) swave[wave] = (unsigned int)__builtin_popcountll(m);
+            const int nsing = __syncthreads_count(singular);
+            const unsigned int nvis = swave[0] + swave[1] + swave[2] + swave[3];
+            if (threadIdx.x == 0) {
+                sbase = nvis ? (unsigned int)atomicAdd(&status->n_visible, (unsigned long long)nvis) : 0u;
+                if (nsing) atomicAdd(&status->n_singular, (unsigned long long)nsing);
+            }
+            __syncthreads();
+            if (in_slab) {
+                unsigned int r = sbase + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                for (unsigned int w = 0; w < wave; ++w) r += swave[w];
+                vislist[r] = (unsigned int)i;
+            }
         }
-        __syncthreads();
-        if (in_slab) {
-            unsigned int r = sbase + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-            for (unsigned int w = 0; w < wave; ++w) r += swave[w];
-            vislist[r] = (unsigned int)i;
-        }
-    }
-    {
         const bool v1[1] = {in_slab};
         const int a1[1] = {tx0}, b1[1] = {tx1}, c1[1] = {ty0}, d1[1] = {ty1};
         const unsigned long long k1[1] = {0ull};
@@ -760,7 +822,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int* __restrict__ offsets,
                                                            unsigned int* __restrict__ order, unsigned int* __restrict__ lens,
                                                            FrameStatus* __restrict__ status, unsigned int bucket_cap,
-                                                           unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long) {
+                                                           unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
+                                                           unsigned int cls_in_lds) {
     constexpr int NCLS = 64;
     __shared__ unsigned int row[SCAN_NT / 64][NCLS];
     __shared__ unsigned int start[NCLS];
@@ -777,14 +840,29 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
     __syncthreads();
     unsigned long long sum = 0;
     unsigned int mx = 0;
-    for (unsigned int k = tid; k < m; k += SCAN_NT) {
-        const unsigned int c = counts[k];
-        counts[k] = 0;
-        const unsigned int len = min(c, bucket_cap);
-        lens[k] = len;
-        offsets[k] = k * bucket_cap;
-        sum += c; mx = max(mx, c);
-        atomicAdd(&row[wave][cls_of(len)], 1u);
+    // The kernel is a latency chain on the frame's critical path (K1 -> scan -> sort): a thread's counts are
+    // fetched eight at a time (eight loads in flight instead of one dependent round trip per tile), and the
+    // length class of every tile is parked in LDS for the second pass instead of being read back from memory.
+    extern __shared__ unsigned char cls_lds[];            // m bytes when the launch provides them (cls_in_lds)
+    constexpr unsigned int U = 8;
+    for (unsigned int base = 0; base < m; base += U * SCAN_NT) {
+        unsigned int c[U];
+#pragma unroll
+        for (unsigned int u = 0; u < U; ++u) { const unsigned int k = base + u * SCAN_NT + tid; c[u] = (k < m) ? counts[k] : 0u; }
+#pragma unroll
+        for (unsigned int u = 0; u < U; ++u) {
+            const unsigned int k = base + u * SCAN_NT + tid;
+            if (k < m) {
+                counts[k] = 0;
+                const unsigned int len = min(c[u], bucket_cap);
+                lens[k] = len;
+                offsets[k] = k * bucket_cap;
+                sum += c[u]; mx = max(mx, c[u]);
+                const unsigned int cls = cls_of(len);
+                if (cls_in_lds) cls_lds[k] = (unsigned char)cls;
+                atomicAdd(&row[wave][cls], 1u);
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -819,9 +897,16 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         status->overflow = (mx > bucket_cap) ? 2u : ((ge[1] > grid_big || ge[2] > grid_mid || ge[0] > grid_long) ? 3u : 0u);
     }
     __syncthreads();
-    for (unsigned int k = tid; k < m; k += SCAN_NT) {
-        const unsigned int cls = cls_of(lens[k]);       // (written by this very thread)
-        order[start[cls] + atomicAdd(&row[wave][cls], 1u)] = k;
+    // second pass: thread t keeps the same tiles, so its wave's row offsets are its own
+    for (unsigned int base = 0; base < m; base += U * SCAN_NT) {
+#pragma unroll
+        for (unsigned int u = 0; u < U; ++u) {
+            const unsigned int k = base + u * SCAN_NT + tid;
+            if (k < m) {
+                const unsigned int cls = cls_in_lds ? (unsigned int)cls_lds[k] : cls_of(lens[k]);    // (written by this very thread)
+                order[start[cls] + atomicAdd(&row[wave][cls], 1u)] = k;
+            }
+        }
     }
 }
 
@@ -1682,15 +1767,18 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         static const char* env = std::getenv("SPLAT_SCAN_THREADS");
         // small grids: 256 threads start at once beside a busy compositor; 4K-sized ones need the width
         const int nt = env ? std::atoi(env) : (m > 12000u ? 1024 : 256);
+        // one byte of LDS per tile for the length classes (up to 48 KB: a 6-megapixel target), else they are re-read
+        const unsigned int cls_bytes = (m + 15u) & ~15u, in_lds = cls_bytes <= 49152u ? 1u : 0u;
+        const unsigned int dyn = in_lds ? cls_bytes : 0u;
         if (nt == 256)
-            hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(1), dim3(256), 0, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long);
+            hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(1), dim3(256), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
+                               grid_big, grid_mid, grid_long, in_lds);
         else if (nt == 512)
-            hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(1), dim3(512), 0, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long);
+            hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(1), dim3(512), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
+                               grid_big, grid_mid, grid_long, in_lds);
         else
-            hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(1), dim3(1024), 0, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long);
+            hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(1), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
+                               grid_big, grid_mid, grid_long, in_lds);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
