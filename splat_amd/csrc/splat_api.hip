@@ -430,7 +430,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         iters = c->d_iters;
         c->iters_valid = true;
     }
-    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->fused_sort_max, iters);
+    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->fused_sort_max, iters, want_iters);
     HIP_TRY(c, mark(6, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));

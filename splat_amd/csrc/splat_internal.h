@@ -89,7 +89,9 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max = 0,
-                      uint2* iters = nullptr /* per wave (scan, blend) iteration counts, statistics frames only */);
+                      uint2* iters = nullptr /* per wave (scan, blend) iteration counts, statistics frames only */,
+                      bool keep_keys = true /* lists sorted inside the compositor are also written back to the bucket
+                                               (the debug getters read them there); off on ordinary frames */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 // ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)

@@ -118,7 +118,11 @@ __device__ __forceinline__ bool covered_interval(float c, float h, float off, in
     if (!(fhi >= (float)lo_lim - 2.0f) || !(flo <= (float)hi_lim + 2.0f)) return false;
     int a = (int)fmaxf(floorf(flo) - 1.0f, (float)lo_lim);
     int b = (int)fminf(ceilf(fhi) + 1.0f, (float)hi_lim);
+    // (the candidates start at most a few pixels outside the interval: two or three trips each.  Left to itself the
+    // compiler vectorises these search loops eight candidates wide -- ~150 instructions per loop, a quarter of K1)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     while (a <= b && !(fabsf(((float)a + off) - c) <= h)) ++a;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     while (b >= a && !(fabsf(((float)b + off) - c) <= h)) --b;
     if (a > b) return false;
     *lo = a; *hi = b;
@@ -1195,9 +1199,13 @@ constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 51
 
 // Sort one list of n <= CAP keys (global, at g) through this workgroup's LDS (smem: sort_lds_bytes<NT, CAP>()),
 // in place.  Used by sort_tiles_kernel and, for short lists, by the compositor's workgroup itself.
+// idx_out != nullptr (the compositor's own sort): the sorted ORDER -- the keys' index halves -- is left in LDS at
+// idx_out (which may overlap the workspace) for the workgroup that is about to walk the list; the keys go back to
+// global memory only if write_back is set (statistics / debug frames read the lists from there).
 template <int NT, int CAP>
 __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned long long* __restrict__ g, unsigned int n,
-                                                 unsigned int radix_min, FrameStatus* __restrict__ status) {
+                                                 unsigned int radix_min, FrameStatus* __restrict__ status,
+                                                 unsigned int* idx_out = nullptr, bool write_back = true) {
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
     // histograms live right behind the keys in use: a list that leaves room gets 512 bins
     constexpr unsigned int NW = NT / 64;
@@ -1224,7 +1232,21 @@ __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned l
         const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, false, lb);   // (its barriers publish s[])
         sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl);
     }
-    for (unsigned int t = threadIdx.x; t < n; t += NT) g[t] = s[t];
+    if (idx_out == nullptr) {
+        for (unsigned int t = threadIdx.x; t < n; t += NT) g[t] = s[t];
+        return;
+    }
+    constexpr unsigned int E = CAP / NT;
+    unsigned long long k[E];
+#pragma unroll
+    for (unsigned int u = 0; u < E; ++u) { const unsigned int t = threadIdx.x + u * NT; k[u] = (t < n) ? s[t] : 0ull; }
+    if (write_back) {
+#pragma unroll
+        for (unsigned int u = 0; u < E; ++u) { const unsigned int t = threadIdx.x + u * NT; if (t < n) g[t] = k[u]; }
+    }
+    __syncthreads();                       // every key has been read: the index area may overlap them
+#pragma unroll
+    for (unsigned int u = 0; u < E; ++u) { const unsigned int t = threadIdx.x + u * NT; if (t < n) idx_out[t] = (unsigned int)k[u]; }
 }
 
 // One workgroup per tile; a launch handles the lists with lo < n <= CAP (three size classes, so
@@ -1440,7 +1462,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                                                const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
                                                const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                FrameStatus* __restrict__ status, unsigned int fused_sort_max,
-                                               unsigned int radix_min, uint2* __restrict__ iters) {
+                                               unsigned int radix_min, uint2* __restrict__ iters, unsigned int keep_keys) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -1453,9 +1475,14 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     const unsigned int beg = __builtin_amdgcn_readfirstlane(offsets[tile]);
     const unsigned int end = beg + __builtin_amdgcn_readfirstlane(lens[tile]);
     if (beg == end) return;
-    if (end - beg >= 2u && end - beg <= fused_sort_max) {
-        sort_list_in_lds<256, 2048>(smem, keys + beg, end - beg, radix_min, status);
-        __syncthreads();          // the sorted list is in global memory, the LDS is free for the batches
+    // A list this workgroup sorts itself never travels back to memory: the order (2048 x 4 B) stays in LDS behind
+    // the waves' record batches, and the walks below read their indices from there instead of from the bucket.
+    unsigned int* const lds_idx = reinterpret_cast<unsigned int*>(smem + sizeof(WaveLds) * 4);
+    static_assert(sizeof(WaveLds) * 4 + 2048 * 4 <= sort_lds_bytes<256, 2048>(), "the order fits behind the batches");
+    const bool own_order = end - beg >= 2u && end - beg <= fused_sort_max;
+    if (own_order) {
+        sort_list_in_lds<256, 2048>(smem, keys + beg, end - beg, radix_min, status, lds_idx, keep_keys != 0u);
+        __syncthreads();          // the order is in LDS, the rest of the workspace is free for the batches
     }
     const unsigned int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     // The longest lists are the critical path of the launch: let their waves win VALU arbitration
@@ -1492,7 +1519,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     //        issues one instruction per ~4 cycles whatever its type, so scalar bookkeeping per record
     //        is as expensive as vector work on the launch's critical path.
     auto fetch = [&](unsigned int base, unsigned int cnt, Rec& r) {
-        if (lane < cnt) r = recs[(unsigned int)keys[base + lane]];
+        if (lane < cnt) r = recs[own_order ? lds_idx[base - beg + lane] : (unsigned int)keys[base + lane]];
     };
     // Can ANY sample of the block be accepted?  Upper bound of alpha over the block: the minimum of
     // the conic's quadratic form q = a dx^2 + 2 b dx dy + c dy^2 over the block's sample rectangle
@@ -1711,10 +1738,11 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
                                                               unsigned long long* __restrict__ keys,
                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
-                                                              unsigned int radix_min, uint2* __restrict__ iters) {
+                                                              unsigned int radix_min, uint2* __restrict__ iters,
+                                                              unsigned int keep_keys) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
-    composite_tile(smem, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters);
+    composite_tile(smem, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys);
 }
 
 // ---------------------------------------------------------------------------
@@ -1815,7 +1843,7 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
-                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max, uint2* iters) {
+                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max, uint2* iters, bool keep_keys) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
@@ -1824,7 +1852,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
     static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
     hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status,
-                       fused_sort_max, sort_radix_min(), iters);
+                       fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u);
 }
 
 }  // namespace splat
