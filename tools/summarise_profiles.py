@@ -41,9 +41,17 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     shutil.copy(one(os.path.join(src, "trace", "**", "*_kernel_stats.csv")), os.path.join(dst, tag + "_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
+    iso = glob.glob(os.path.join(src, "trace_isolated", "**", "*_kernel_stats.csv"), recursive=True)
+    if iso:
+        shutil.copy(iso[0], os.path.join(dst, tag + "_kernel_stats_isolated.csv"))
     per = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
-        agg = pmc_avg(one(os.path.join(src, "pmc_" + c, "**", "*_counter_collection.csv")))
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):
+        found = glob.glob(os.path.join(src, "pmc_" + c, "**", "*_counter_collection.csv"), recursive=True)
+        if not found:
+            if c == "SQ2":
+                continue
+            raise SystemExit("missing counter pass " + c)
+        agg = pmc_avg(found[0])
         with open(os.path.join(dst, "%s_pmc_%s.csv" % (tag, c)), "w") as f:
             f.write("Kernel,Counter,Dispatches,Average\n")
             for (k, cn), v in sorted(agg.items()):

@@ -73,6 +73,57 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters,
             REP8(asm volatile("v_mul_f32 %0, %0, %8 clamp\n v_mul_f32 %1, %1, %8 clamp\n v_mul_f32 %2, %2, %8 clamp\n v_mul_f32 %3, %3, %8 clamp\n"
                               "v_mul_f32 %4, %4, %8 clamp\n v_mul_f32 %5, %5, %8 clamp\n v_mul_f32 %6, %6, %8 clamp\n v_mul_f32 %7, %7, %8 clamp\n"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 12) {   // v_cmp_le_f32_e64 sgpr dst
+            REP8(asm volatile("v_cmp_le_f32_e64 s[20:21], %0, %8\n v_cmp_le_f32_e64 s[22:23], %1, %8\n v_cmp_le_f32_e64 s[24:25], %2, %8\n v_cmp_le_f32_e64 s[26:27], %3, %8\n v_cmp_le_f32_e64 s[28:29], %4, %8\n v_cmp_le_f32_e64 s[30:31], %5, %8\n v_cmp_le_f32_e64 s[32:33], %6, %8\n v_cmp_le_f32_e64 s[34:35], %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","s30","s31","s32","s33","s34","s35");)
+        } else if (KIND == 13) {   // v_cmp_le_f32_e32 vcc
+            REP8(asm volatile("v_cmp_le_f32_e32 vcc, %0, %8\n v_cmp_le_f32_e32 vcc, %1, %8\n v_cmp_le_f32_e32 vcc, %2, %8\n v_cmp_le_f32_e32 vcc, %3, %8\n v_cmp_le_f32_e32 vcc, %4, %8\n v_cmp_le_f32_e32 vcc, %5, %8\n v_cmp_le_f32_e32 vcc, %6, %8\n v_cmp_le_f32_e32 vcc, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
+        } else if (KIND == 14) {   // v_cndmask_b32 (vcc fixed)
+            REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 15) {   // v_min_f32
+            REP8(asm volatile("v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 16) {   // v_add_f32 clamp (VOP3)
+            REP8(asm volatile("v_add_f32_e64 %0, %0, %8 clamp\n v_add_f32_e64 %1, %1, %8 clamp\n v_add_f32_e64 %2, %2, %8 clamp\n v_add_f32_e64 %3, %3, %8 clamp\n v_add_f32_e64 %4, %4, %8 clamp\n v_add_f32_e64 %5, %5, %8 clamp\n v_add_f32_e64 %6, %6, %8 clamp\n v_add_f32_e64 %7, %7, %8 clamp\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+        } else if (KIND == 17) {   // v_sub_f32 |abs| (VOP3)
+            REP8(asm volatile("v_sub_f32_e64 %0, |%0|, %8\n v_sub_f32_e64 %1, |%1|, %8\n v_sub_f32_e64 %2, |%2|, %8\n v_sub_f32_e64 %3, |%3|, %8\n v_sub_f32_e64 %4, |%4|, %8\n v_sub_f32_e64 %5, |%5|, %8\n v_sub_f32_e64 %6, |%6|, %8\n v_sub_f32_e64 %7, |%7|, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+        } else if (KIND == 18) {   // v_fmac_f32
+            REP8(asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));)
+        } else if (KIND == 19) {   // v_cvt_f32_ubyte0
+            REP8(asm volatile("v_cvt_f32_ubyte0 %0, %0\n v_cvt_f32_ubyte0 %1, %1\n v_cvt_f32_ubyte0 %2, %2\n v_cvt_f32_ubyte0 %3, %3\n v_cvt_f32_ubyte0 %4, %4\n v_cvt_f32_ubyte0 %5, %5\n v_cvt_f32_ubyte0 %6, %6\n v_cvt_f32_ubyte0 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 20) {   // v_cvt_pk_u8_f32
+            REP8(asm volatile("v_cvt_pk_u8_f32 %0, %8, 0, %0\n v_cvt_pk_u8_f32 %1, %8, 0, %1\n v_cvt_pk_u8_f32 %2, %8, 0, %2\n v_cvt_pk_u8_f32 %3, %8, 0, %3\n v_cvt_pk_u8_f32 %4, %8, 0, %4\n v_cvt_pk_u8_f32 %5, %8, 0, %5\n v_cvt_pk_u8_f32 %6, %8, 0, %6\n v_cvt_pk_u8_f32 %7, %8, 0, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 21) {   // v_cvt_u32_f32
+            REP8(asm volatile("v_cvt_u32_f32 %0, %0\n v_cvt_u32_f32 %1, %1\n v_cvt_u32_f32 %2, %2\n v_cvt_u32_f32 %3, %3\n v_cvt_u32_f32 %4, %4\n v_cvt_u32_f32 %5, %5\n v_cvt_u32_f32 %6, %6\n v_cvt_u32_f32 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 22) {   // v_cvt_f32_u32
+            REP8(asm volatile("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %1, %1\n v_cvt_f32_u32 %2, %2\n v_cvt_f32_u32 %3, %3\n v_cvt_f32_u32 %4, %4\n v_cvt_f32_u32 %5, %5\n v_cvt_f32_u32 %6, %6\n v_cvt_f32_u32 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 23) {   // v_floor_f32
+            REP8(asm volatile("v_floor_f32 %0, %0\n v_floor_f32 %1, %1\n v_floor_f32 %2, %2\n v_floor_f32 %3, %3\n v_floor_f32 %4, %4\n v_floor_f32 %5, %5\n v_floor_f32 %6, %6\n v_floor_f32 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 24) {   // v_and_b32
+            REP8(asm volatile("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 25) {   // v_mad_u32_u24
+            REP8(asm volatile("v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n v_mad_u32_u24 %4, %4, %8, %9\n v_mad_u32_u24 %5, %5, %8, %9\n v_mad_u32_u24 %6, %6, %8, %9\n v_mad_u32_u24 %7, %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));)
+        } else if (KIND == 26) {   // v_rcp_f32
+            REP8(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 27) {   // v_mul_f32 by SGPR
+            REP8(asm volatile("v_mul_f32 %0, s40, %0\n v_mul_f32 %1, s40, %1\n v_mul_f32 %2, s40, %2\n v_mul_f32 %3, s40, %3\n v_mul_f32 %4, s40, %4\n v_mul_f32 %5, s40, %5\n v_mul_f32 %6, s40, %6\n v_mul_f32 %7, s40, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "s40");)
+        } else if (KIND == 28) {   // v_mul_f32 by literal
+            REP8(asm volatile("v_mul_f32 %0, 0x3f7fbe77, %0\n v_mul_f32 %1, 0x3f7fbe77, %1\n v_mul_f32 %2, 0x3f7fbe77, %2\n v_mul_f32 %3, 0x3f7fbe77, %3\n v_mul_f32 %4, 0x3f7fbe77, %4\n v_mul_f32 %5, 0x3f7fbe77, %5\n v_mul_f32 %6, 0x3f7fbe77, %6\n v_mul_f32 %7, 0x3f7fbe77, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -86,7 +137,7 @@ static void run(const char* name, int per_iter) {
     const int iters = 2000;
     unsigned long long* d = nullptr;
     hipMalloc(&d, sizeof(unsigned long long) * 4 * 4096);
-    for (int blocks_per_cu : {1, 2, 4, 8}) {
+    for (int blocks_per_cu : {1, 8}) {
         const int grid = 256 * blocks_per_cu;
         hipLaunchKernelGGL(probe<KIND>, dim3(grid), dim3(256), 0, 0, d, 10, 1.0f);      // warm-up
         hipEvent_t e0, e1;
@@ -125,5 +176,22 @@ int main() {
     run<9>("v_pk_mul_f32 dependent", 64);
     run<10>("v_cmp+v_cndmask (pairs)", 64);
     run<11>("v_mul_f32 clamp x8", 64);
+    run<12>("v_cmp_le_f32_e64 sgpr dst", 64);
+    run<13>("v_cmp_le_f32_e32 vcc", 64);
+    run<14>("v_cndmask_b32 (vcc fixed)", 64);
+    run<15>("v_min_f32", 64);
+    run<16>("v_add_f32 clamp (VOP3)", 64);
+    run<17>("v_sub_f32 |abs| (VOP3)", 64);
+    run<18>("v_fmac_f32", 64);
+    run<19>("v_cvt_f32_ubyte0", 64);
+    run<20>("v_cvt_pk_u8_f32", 64);
+    run<21>("v_cvt_u32_f32", 64);
+    run<22>("v_cvt_f32_u32", 64);
+    run<23>("v_floor_f32", 64);
+    run<24>("v_and_b32", 64);
+    run<25>("v_mad_u32_u24", 64);
+    run<26>("v_rcp_f32", 64);
+    run<27>("v_mul_f32 by SGPR", 64);
+    run<28>("v_mul_f32 by literal", 64);
     return 0;
 }
