@@ -411,7 +411,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
         launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
     HIP_TRY(c, mark(3, ss));
-    launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status, c->fused_sort_max);
+    launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
     if (c->pipeline) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
@@ -430,7 +430,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         iters = c->d_iters;
         c->iters_valid = true;
     }
-    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->fused_sort_max, iters, want_iters);
+    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->orig, c->fused_sort_max, iters, want_iters);
     HIP_TRY(c, mark(6, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
@@ -1039,12 +1039,12 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     }
     HIP_TRY(c, hipMemcpy(d.data(), s.depth, sizeof(float) * n, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(q.data(), s.rect, sizeof(ushort4) * n, hipMemcpyDeviceToHost));
-    for (uint64_t j = 0; j < n; ++j) {          // depth/rect live in slot order, records in original order
+    for (uint64_t j = 0; j < n; ++j) {          // everything lives in slot order; the caller gets original order
         const uint64_t i = c->h_orig[j];
         splat_record& o = out[i];
-        o.cx = r[i].a.x; o.cy = r[i].a.y; o.hx = r[i].a.z; o.hy = r[i].a.w;
-        o.conic_a = r[i].b.x; o.conic_b = c->fc.y_up ? r[i].b.y : -r[i].b.y; o.conic_c = r[i].b.z; o.opacity = r[i].b.w;
-        o.r = r[i].c.x; o.g = r[i].c.y; o.b = r[i].c.z; o.depth = d[j];
+        o.cx = r[j].a.x; o.cy = r[j].a.y; o.hx = r[j].a.z; o.hy = r[j].a.w;
+        o.conic_a = r[j].b.x; o.conic_b = c->fc.y_up ? r[j].b.y : -r[j].b.y; o.conic_c = r[j].b.z; o.opacity = r[j].b.w;
+        o.r = r[j].c.x; o.g = r[j].c.y; o.b = r[j].c.z; o.depth = d[j];
         o.px0 = q[j].x; o.px1 = q[j].y; o.py0 = q[j].z; o.py1 = q[j].w;
     }
     return SPLAT_OK;
@@ -1081,7 +1081,7 @@ int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offset
                     HIP_TRY(c, hipMemcpy(k.data() + tile_offsets[t], s.keys + beg[t], sizeof(unsigned long long) * len[t],
                                          hipMemcpyDeviceToHost));
         }
-        for (uint64_t i = 0; i < n_order; ++i) order[i] = (uint32_t)k[i];
+        for (uint64_t i = 0; i < n_order; ++i) order[i] = c->h_orig[(uint32_t)k[i]];      // keys carry slots
     }
     return SPLAT_OK;
 }

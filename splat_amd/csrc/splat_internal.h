@@ -59,7 +59,8 @@ struct FrameStatus {
     unsigned long long n_blocks_culled; // K1 blocks skipped by the bounds test (filled on the host from the block flags)
 };
 
-// 48-byte projected record (3 x float4), gathered by the compositor.
+// 48-byte projected record (3 x float4), stored in SLOT order (the Morton order of the scene planes: K1 writes them
+// coalesced, the compositor's gathers are local) and gathered by the compositor through the keys' slot halves.
 struct Rec {
     float4 a;   // cx, cy, hx, hy
     float4 b;   // conic a, b, c, opacity
@@ -83,12 +84,13 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
 // sort launches cover; the scan validates them against the frame's actual list lengths.
 void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
-                 FrameStatus* status, unsigned int fused_sort_max = 0);
+                 FrameStatus* status, const unsigned int* orig /* slot -> original index: the order among equal depths */,
+                 unsigned int fused_sort_max = 0);
 // fused_sort_max: lists of up to this many keys (<= 2048) are sorted by the compositor's workgroups
 // themselves (launch_sort must be given the same value and then leaves them alone); 0 = off.
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
-                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max = 0,
+                      uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max = 0,
                       uint2* iters = nullptr /* per wave (scan, blend) iteration counts, statistics frames only */,
                       bool keep_keys = true /* lists sorted inside the compositor are also written back to the bucket
                                                (the debug getters read them there); off on ordinary frames */);

@@ -705,10 +705,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         r.a = make_float4(cx, cy, hx, hy);
         r.b = make_float4(ca, fc.y_up ? cb : -cb, cc, opacity);   // cross term carries the y-axis sign (exact)
         r.c = make_float4(col[0], col[1], col[2], pthr);
-        recs[orig[i]] = r;
+        recs[i] = r;                        // slot order: coalesced here, Morton-local for the compositor's gathers
     }
     if constexpr (BUCKET) {
-        const unsigned long long key = in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)orig[i]) : 0ull;
+        const unsigned long long key = in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)(unsigned int)i) : 0ull;
         binner.place(key);
     } else {
         // compact the slots that reach the slab into vislist (K2 runs over those only)
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void emit_kernel(FrameConst fc, const float* _
             ushort4 rc = rect[i];
             int y0 = max((int)rc.z, fc.row_px0), y1 = min((int)rc.w, fc.row_px1 - 1);
             tx0[g] = rc.x >> 4; tx1[g] = rc.y >> 4; ty0[g] = (y0 >> 4) - fc.tile_row0; ty1[g] = (y1 >> 4) - fc.tile_row0;
-            key[g] = ((unsigned long long)depth_key(depth[i]) << 32) | (unsigned long long)orig[i];
+            key[g] = ((unsigned long long)depth_key(depth[i]) << 32) | (unsigned long long)i;
         }
     }
     bin_block<true, EMIT_G>(sh, vis, tx0, tx1, ty0, ty1, fc.tiles_x, cursor, keys, key);
@@ -951,14 +951,22 @@ __global__ __launch_bounds__(256) void emit_kernel(FrameConst fc, const float* _
 // reference's stable ascending-z order).  Bitonic network in its all-ascending "flip" form, so
 // that a list of any length n sorts in place: slots >= n behave as +inf and never move.
 // ---------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void cmp_swap(T* s, unsigned int i, unsigned int p) {
-    T a = s[i], b = s[p];
-    if (a > b) { s[i] = b; s[p] = a; }
+// Order of two keys = (depth_key << 32 | SLOT): ascending depth, and among equal depths ascending ORIGINAL index
+// (the reference's stable sort, src/gaussians.rs:302-303).  The key carries the Morton slot -- records and scene
+// planes live in slot order -- so a tie (exact f32 depth equality: a few per ten thousand keys) looks the original
+// indices up; the branch is taken by the lanes that hold a tie only.
+__device__ __forceinline__ bool key_gt(unsigned long long a, unsigned long long b, const unsigned int* __restrict__ orig) {
+    const unsigned int da = (unsigned int)(a >> 32), db = (unsigned int)(b >> 32);
+    if (da != db) return da > db;
+    return orig[(unsigned int)a] > orig[(unsigned int)b];
+}
+__device__ __forceinline__ void cmp_swap(unsigned long long* s, unsigned int i, unsigned int p, const unsigned int* __restrict__ orig) {
+    unsigned long long a = s[i], b = s[p];
+    if (key_gt(a, b, orig)) { s[i] = b; s[p] = a; }
 }
 
-template <typename T>
-__device__ __forceinline__ void bitonic_sort(T* s, unsigned int n, unsigned int tid, unsigned int nt) {
+__device__ __forceinline__ void bitonic_sort(unsigned long long* s, unsigned int n, unsigned int tid, unsigned int nt,
+                                             const unsigned int* __restrict__ orig) {
     unsigned int P = 1;
     while (P < n) P <<= 1;
     const unsigned int half = P >> 1;
@@ -967,14 +975,14 @@ __device__ __forceinline__ void bitonic_sort(T* s, unsigned int n, unsigned int 
         for (unsigned int t = tid; t < half; t += nt) {
             unsigned int off = t & (hk - 1), base = (t - off) << 1;   // block start = (t / hk) * k
             unsigned int i = base + off, p = base + (k - 1 - off);
-            if (p < n) cmp_swap(s, i, p);
+            if (p < n) cmp_swap(s, i, p, orig);
         }
         __syncthreads();
         for (unsigned int j = k >> 2; j > 0; j >>= 1) {
             for (unsigned int t = tid; t < half; t += nt) {
                 unsigned int lowbits = t & (j - 1);
                 unsigned int i = ((t - lowbits) << 1) | lowbits, p = i + j;
-                if (p < n) cmp_swap(s, i, p);
+                if (p < n) cmp_swap(s, i, p, orig);
             }
             __syncthreads();
         }
@@ -1114,7 +1122,7 @@ __device__ __forceinline__ void radix_sort_depth(unsigned long long* s, unsigned
 template <int NT, int EMAX>
 __device__ __forceinline__ void sort_keys_lds(unsigned long long* s, unsigned int* hist, unsigned int* tot,
                                               unsigned int* dbase, unsigned int n, unsigned int tid,
-                                              FrameStatus* status, const DigitPlan pl) {
+                                              FrameStatus* status, const DigitPlan pl, const unsigned int* __restrict__ orig) {
     radix_sort_depth<NT, EMAX>(s, hist, tot, dbase, n, tid, pl);
     for (int it = 0; it < 6; ++it) {
         bool swapped = false;
@@ -1122,14 +1130,14 @@ __device__ __forceinline__ void sort_keys_lds(unsigned long long* s, unsigned in
         for (unsigned int parity = 0; parity < 2; ++parity) {
             for (unsigned int i = parity + 2u * tid; i + 1 < n; i += 2u * NT) {
                 const unsigned long long x = s[i], y = s[i + 1];
-                if (x > y) { s[i] = y; s[i + 1] = x; swapped = true; }
+                if (key_gt(x, y, orig)) { s[i] = y; s[i + 1] = x; swapped = true; }
             }
             __syncthreads();
         }
         if (!__syncthreads_or(swapped ? 1 : 0)) return;      // a full pass without swaps: sorted
     }
     if (tid == 0) atomicAdd(&status->n_sort_fallback, 1ull);
-    bitonic_sort(s, n, tid, NT);
+    bitonic_sort(s, n, tid, NT, orig);
 }
 
 // The same radix sort for lists that do not fit in LDS: keys stay in global memory (L2-resident),
@@ -1205,6 +1213,7 @@ constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 51
 template <int NT, int CAP>
 __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned long long* __restrict__ g, unsigned int n,
                                                  unsigned int radix_min, FrameStatus* __restrict__ status,
+                                                 const unsigned int* __restrict__ orig,
                                                  unsigned int* idx_out = nullptr, bool write_back = true) {
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
     // histograms live right behind the keys in use: a list that leaves room gets 512 bins
@@ -1227,10 +1236,10 @@ __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned l
     }
     if (n <= radix_min) {
         __syncthreads();
-        bitonic_sort(s, n, threadIdx.x, NT);   // few steps: cheaper than the radix passes
+        bitonic_sort(s, n, threadIdx.x, NT, orig);   // few steps: cheaper than the radix passes
     } else {
         const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, false, lb);   // (its barriers publish s[])
-        sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl);
+        sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl, orig);
     }
     if (idx_out == nullptr) {
         for (unsigned int t = threadIdx.x; t < n; t += NT) g[t] = s[t];
@@ -1262,7 +1271,7 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
                                                          unsigned long long* __restrict__ keys2,
                                                          FrameStatus* __restrict__ status, unsigned int lo,
                                                          unsigned int radix_min, int chunks, unsigned int grid0,
-                                                         unsigned int grid_long) {
+                                                         unsigned int grid_long, const unsigned int* __restrict__ orig) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (status->overflow) return;
     // workgroups [0, grid0) take run 0 of the first grid0 lists; the next 3 * grid_long ones take runs
@@ -1283,7 +1292,7 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
         return;
     }
     if (n <= (unsigned int)CAP) {
-        sort_list_in_lds<NT, CAP>(smem, keys + b, n, radix_min, status);
+        sort_list_in_lds<NT, CAP>(smem, keys + b, n, radix_min, status, orig);
     } else if (chunks) {
         // longer than chunks * CAP: radix passes over the L2-resident bucket, then the same tie fix-up
         unsigned long long* g = keys + b;
@@ -1304,7 +1313,7 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
             for (unsigned int parity = 0; parity < 2; ++parity) {
                 for (unsigned int i = parity + 2u * threadIdx.x; i + 1 < n; i += 2u * NT) {
                     const unsigned long long x = g[i], y = g[i + 1];
-                    if (x > y) { g[i] = y; g[i + 1] = x; swapped = true; }
+                    if (key_gt(x, y, orig)) { g[i] = y; g[i + 1] = x; swapped = true; }
                 }
                 __syncthreads();
             }
@@ -1312,19 +1321,20 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
         }
         if (!sorted) {
             if (threadIdx.x == 0) atomicAdd(&status->n_sort_fallback, 1ull);
-            bitonic_sort(g, n, threadIdx.x, NT);       // exact network, slow: only for long runs of equal depth
+            bitonic_sort(g, n, threadIdx.x, NT, orig);       // exact network, slow: only for long runs of equal depth
         }
     }
 }
 
 // Merge path: how many of the first d outputs of merge(A[0..la), B[0..lb)) come from A.  Keys are
-// unique (the index half), so there are no ties.
+// unique (the slot half) and key_gt is a strict total order, so there are no ties.
 template <typename PA, typename PB>
-__device__ __forceinline__ unsigned int merge_path(unsigned int d, unsigned int la, unsigned int lb, PA A, PB B) {
+__device__ __forceinline__ unsigned int merge_path(unsigned int d, unsigned int la, unsigned int lb, PA A, PB B,
+                                                   const unsigned int* __restrict__ orig) {
     unsigned int lo = d > lb ? d - lb : 0u, hi = min(d, la);
     while (lo < hi) {
         const unsigned int mid = (lo + hi) >> 1;
-        if (A[mid] < B[d - 1u - mid]) lo = mid + 1u; else hi = mid;
+        if (key_gt(B[d - 1u - mid], A[mid], orig)) lo = mid + 1u; else hi = mid;
     }
     return lo;
 }
@@ -1342,7 +1352,8 @@ __global__ __launch_bounds__(NT) void merge_runs_kernel(const unsigned int* __re
                                                          const unsigned int* __restrict__ lens,
                                                          unsigned long long* __restrict__ keys,
                                                          unsigned long long* __restrict__ keys2,
-                                                         const FrameStatus* __restrict__ status) {
+                                                         const FrameStatus* __restrict__ status,
+                                                         const unsigned int* __restrict__ orig) {
     __shared__ unsigned long long sm[MERGE_T];
     __shared__ unsigned int split[4 * CAP / MERGE_T + 2];
     if (status->overflow) return;
@@ -1354,7 +1365,7 @@ __global__ __launch_bounds__(NT) void merge_runs_kernel(const unsigned int* __re
     auto merge = [&](const unsigned long long* A, unsigned int la, const unsigned long long* B, unsigned int lb,
                      unsigned long long* dst) {
         const unsigned int total = la + lb, ntile = (total + MERGE_T - 1u) / MERGE_T;
-        if (tid <= ntile) split[tid] = merge_path(min(tid * MERGE_T, total), la, lb, A, B);
+        if (tid <= ntile) split[tid] = merge_path(min(tid * MERGE_T, total), la, lb, A, B, orig);
         __syncthreads();
         for (unsigned int k = 0; k < ntile; ++k) {
             const unsigned int k0 = k * MERGE_T, k1 = min(k0 + MERGE_T, total);
@@ -1367,11 +1378,11 @@ __global__ __launch_bounds__(NT) void merge_runs_kernel(const unsigned int* __re
             if (q0 < k1 - k0) {
                 const unsigned long long* sA = sm;
                 const unsigned long long* sB = sm + na;
-                unsigned int ia = merge_path(q0, na, nb, sA, sB), ib = q0 - ia;
+                unsigned int ia = merge_path(q0, na, nb, sA, sB, orig), ib = q0 - ia;
 #pragma unroll
                 for (unsigned int e = 0; e < E; ++e) {
                     if (q0 + e < k1 - k0) {
-                        const bool take_a = (ib >= nb) || (ia < na && sA[ia] < sB[ib]);
+                        const bool take_a = (ib >= nb) || (ia < na && key_gt(sB[ib], sA[ia], orig));
                         dst[k0 + q0 + e] = take_a ? sA[ia] : sB[ib];
                         ia += take_a ? 1u : 0u; ib += take_a ? 0u : 1u;
                     }
@@ -1462,7 +1473,8 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                                                const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
                                                const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                FrameStatus* __restrict__ status, unsigned int fused_sort_max,
-                                               unsigned int radix_min, uint2* __restrict__ iters, unsigned int keep_keys) {
+                                               unsigned int radix_min, uint2* __restrict__ iters, unsigned int keep_keys,
+                                               const unsigned int* __restrict__ orig) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -1481,7 +1493,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     static_assert(sizeof(WaveLds) * 4 + 2048 * 4 <= sort_lds_bytes<256, 2048>(), "the order fits behind the batches");
     const bool own_order = end - beg >= 2u && end - beg <= fused_sort_max;
     if (own_order) {
-        sort_list_in_lds<256, 2048>(smem, keys + beg, end - beg, radix_min, status, lds_idx, keep_keys != 0u);
+        sort_list_in_lds<256, 2048>(smem, keys + beg, end - beg, radix_min, status, orig, lds_idx, keep_keys != 0u);
         __syncthreads();          // the order is in LDS, the rest of the workspace is free for the batches
     }
     const unsigned int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
@@ -1739,10 +1751,10 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
                                                               unsigned int radix_min, uint2* __restrict__ iters,
-                                                              unsigned int keep_keys) {
+                                                              unsigned int keep_keys, const unsigned int* __restrict__ orig) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
-    composite_tile(smem, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys);
+    composite_tile(smem, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig);
 }
 
 // ---------------------------------------------------------------------------
@@ -1819,7 +1831,7 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
 }
 void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
-                 FrameStatus* status, unsigned int fused_sort_max) {
+                 FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max) {
     if (!n_tiles) return;
     const unsigned int radix_min = sort_radix_min();
     // longest class first (the tiles are ordered longest-first too)
@@ -1829,21 +1841,22 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
         // (two-pass binning only: one-pass buckets hold at most 16384 keys and there is no keys2)
         grid_long = keys2 ? std::min(grid_long, grid_big) : 0u;
         hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(grid_big + 3u * grid_long), dim3(1024), (sort_lds_bytes<1024, 16384>()), s,
-                           offsets, order, lens, keys, keys2, status, 8192u, radix_min, keys2 ? 4 : 1, grid_big, std::max(grid_long, 1u));
+                           offsets, order, lens, keys, keys2, status, 8192u, radix_min, keys2 ? 4 : 1, grid_big, std::max(grid_long, 1u), orig);
         if (grid_long)
             hipLaunchKernelGGL((merge_runs_kernel<1024, 16384>), dim3(grid_long), dim3(1024), 0, s, offsets, order, lens, keys, keys2,
-                               status);
+                               status, orig);
     }
     if (grid_mid)
     hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(grid_mid), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
-                       lens, keys, keys2, status, 2048u, radix_min, 0, 0u, 1u);
+                       lens, keys, keys2, status, 2048u, radix_min, 0, 0u, 1u, orig);
     if (fused_sort_max < 2048u)      // (lists up to fused_sort_max are sorted by the compositor's own workgroups)
         hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
-                           lens, keys, keys2, status, fused_sort_max, radix_min, 0, 0u, 1u);
+                           lens, keys, keys2, status, fused_sort_max, radix_min, 0, 0u, 1u, orig);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
-                      uint32_t* argb, FrameStatus* status, unsigned int fused_sort_max, uint2* iters, bool keep_keys) {
+                      uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
+                      bool keep_keys) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
@@ -1852,7 +1865,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
     static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
     hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status,
-                       fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u);
+                       fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
 }
 
 }  // namespace splat
