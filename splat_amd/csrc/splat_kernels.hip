@@ -1202,8 +1202,12 @@ __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src,
     }
 }
 
+// keys + one 256-bin histogram row per wave + one row of per-digit totals, which the digit scan turns into the
+// per-digit bases IN PLACE (every lane reads its totals before it writes its bases).  At <256, 2048> that is
+// 21 504 bytes: seven compositor workgroups leave 9 KB of a CU's LDS free, room for one K1 workgroup (6.2 KB)
+// of the next frame beside them.
 template <int NT, int CAP>
-constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 512) * 4; }
+constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 256) * 4; }
 
 // Sort one list of n <= CAP keys (global, at g) through this workgroup's LDS (smem: sort_lds_bytes<NT, CAP>()),
 // in place.  Used by sort_tiles_kernel and, for short lists, by the compositor's workgroup itself.
@@ -1219,10 +1223,10 @@ __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned l
     // histograms live right behind the keys in use: a list that leaves room gets 512 bins
     constexpr unsigned int NW = NT / 64;
     const unsigned int keys_bytes = ((n * 8u) + 15u) & ~15u;
-    const int lb = (keys_bytes + (NW + 2u) * 512u * 4u <= sort_lds_bytes<NT, CAP>()) ? 9 : 8;
+    const int lb = (keys_bytes + (NW + 1u) * 512u * 4u <= sort_lds_bytes<NT, CAP>()) ? 9 : 8;
     unsigned int* hist = reinterpret_cast<unsigned int*>(smem + keys_bytes);
     unsigned int* tot = hist + (NW << lb);
-    unsigned int* dbase = tot + (1u << lb);
+    unsigned int* dbase = tot;             // in place (see sort_lds_bytes)
     unsigned int mn = 0xffffffffu, mx = 0u;
     for (unsigned int t0 = threadIdx.x; t0 < n; t0 += 8u * NT) {     // eight loads in flight per thread
         unsigned long long k[8];
@@ -1298,7 +1302,7 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
         unsigned long long* g = keys + b;
         unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)CAP * 8);
         unsigned int* tot = hist + (NT / 64) * 256;
-        unsigned int* dbase = tot + 256;
+        unsigned int* dbase = tot;         // in place
         unsigned int mn = 0xffffffffu, mx = 0u;
         for (unsigned int t = threadIdx.x; t < n; t += NT) {
             const unsigned int d = (unsigned int)(g[t] >> 32);
