@@ -115,6 +115,11 @@ struct splat_ctx {
     // sized from the most recent harvested frame (+25 % + slack); the device validates, a miss redoes the frame
     bool sort_hint = false, sort_grid_miss = false;
     unsigned int hint_ge8192 = 0, hint_ge2048 = 0, hint_ge16384 = 0;
+    // which flavour of the exact walk the compositor runs (the pixels are the same): 0 = one record per step, 1 = two
+    // records per step with packed math (fewer issue slots: for frames whose compositor is bound by its longest
+    // list's single wave, not by throughput), -1 = by the last harvested frame's pairs per key of the longest list
+    int pair_mode = -1;                    // SPLAT_PAIR_BLEND
+    uint64_t hint_pairs = 0; unsigned int hint_maxlen = 0;
     unsigned int grid_big = 0, grid_mid = 0, grid_long = 0;      // what the frame being enqueued uses
     FrameStatus last{};
     // frames skipped on the device (their storage outgrown: see finish_frame).  A synchronous call redoes its own
@@ -250,6 +255,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow == 2) { c->bucket_overflow = true; c->bucket_want = std::max(c->bucket_want, st.max_tile_len); }
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
+    if (st.overflow == 0) { c->hint_pairs = st.n_pairs; c->hint_maxlen = st.max_tile_len; }
     s.used = false;
 }
 
@@ -430,7 +436,12 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         iters = c->d_iters;
         c->iters_valid = true;
     }
-    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->orig, c->fused_sort_max, iters, want_iters);
+    // throughput-bound frames (many pairs per key of the longest list: C3 737, C5 3100) keep the one-record walk, the
+    // others (C2 316, an eighth-of-a-frame slab 92, C1 36) take the paired one; measured crossover between 316 and 737
+    const bool pair_walk = c->pair_mode >= 0 ? c->pair_mode != 0
+                                             : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
+    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->orig, c->fused_sort_max, iters, want_iters,
+                     pair_walk);
     HIP_TRY(c, mark(6, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
@@ -623,6 +634,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;
     if (const char* e7 = std::getenv("SPLAT_CULL")) c->cull_blocks = std::atoi(e7) != 0;
     if (const char* e8 = std::getenv("SPLAT_DBG_TIGHT_GRIDS")) c->tight_grids = std::atoi(e8) != 0;
+    if (const char* e10 = std::getenv("SPLAT_PAIR_BLEND")) c->pair_mode = std::atoi(e10) < 0 ? -1 : (std::atoi(e10) != 0 ? 1 : 0);
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);

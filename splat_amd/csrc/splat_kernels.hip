@@ -1455,6 +1455,34 @@ __device__ __forceinline__ float blend_channel(float k, float ia, float ac) {
 
 struct WaveLds { float4 a[64]; float4 b[64]; float4 c[64]; };   // one batch of 64 records, private to a wave
 
+// ---- the exact walk two records at a time (composite_exact_kernel<true>) -----------------------------------
+// fragment() of two consecutive records is evaluated with packed f32 instructions (v_pk_add/mul/fma_f32: the two
+// records side by side in even-aligned register pairs), then blend() runs for the first and for the second, red
+// and green side by side.  Every component goes through the same IEEE operations in the same order as the
+// one-record loop, so the pixels are the same bits.  A packed instruction occupies the SIMD for two issue
+// slots (tools/valu_probe.hip), so this buys little where the compositor is throughput-bound; it is for the
+// waves that are alone on their SIMD -- the densest tile of a multi-GPU slab, the tail of every launch, small
+// frames -- which issue one instruction per ~5 cycles whatever its kind: a third fewer issue slots per record.
+// Measured (same box, frames byte-identical): C2 4291 -> 5126 frames/s, C3 2243 -> 2116 (its compositor is
+// throughput-bound, and the paired loop costs a workgroup of occupancy: 74 VGPRs).  The host picks the kernel
+// per frame from the previous frame's statistics (pairs per key of the longest list; SPLAT_PAIR_BLEND=0/1 forces).
+// The batch is staged pair-interleaved, so that the operands are born in aligned register pairs (no moves):
+//   pair p (records 2p, 2p+1) = 24 floats:  cx0 cx1 cy0 cy1 | hx0 hx1 hy0 hy1 | A0 A1 C0 C1 | B0 B1 op0 op1 |
+//                                            r0 g0 r1 g1 | b0 - b1 -
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_add_clamp(f2 a, f2 b) {      // clamp(a + b, 0, 1) per component: the add's clamp modifier
+    f2 r;                                                      // (NaN -> 0 like the one-record loop's v_add_f32 ... clamp)
+    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// blend() for two channels side by side: see blend_channel
+__device__ __forceinline__ f2 blend_channel2(f2 k, float ia, f2 ac) {
+    const float RH = 0x1.010102p-8f, RL = -0x1.fdfdfep-33f;
+    const f2 f = __builtin_elementwise_fma(k, (f2)(RH), k * RL);       // div255, both channels
+    const f2 y = pk_add_clamp(ia * f, ac) * 255.0f;
+    return (f2){truncf(y.x), truncf(y.y)};
+}
+
 // K4 -- compositor.  One wave = one 8x8 pixel block of a 16x16 tile (4 waves per workgroup, but
 // they never synchronise: each wave streams the tile's list through its own 3 KB of LDS, 64
 // records at a time, fetching the next batch into registers while it walks the current one).
@@ -1472,6 +1500,8 @@ struct WaveLds { float4 a[64]; float4 b[64]; float4 c[64]; };   // one batch of 
 #define SPLAT_COMP_WAVES 1
 #endif
 // One tile (slot `item` of the longest-first tile order) by one workgroup; `smem` = sort_lds_bytes<256, 2048>() bytes.
+// PAIR: the exact walk takes two records per step with packed math (see the note above WaveLds).
+template <bool PAIR>
 __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsigned int item, const FrameConst& fc,
                                                const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
                                                const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
@@ -1567,7 +1597,8 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // scan_layout: the phase-A walk only estimates transmittance, so its records are staged in a
     // form that makes the estimate cheap -- the conic pre-multiplied by -log2(e)/2 and log2(opacity),
     // so that alpha ~ exp2(a' dx^2 + b' dx dy + c' dy^2 + l2o) is six VALU and one v_exp.
-    auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base, bool only_contributing, bool scan_layout = false) -> unsigned int {
+    auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base, bool only_contributing, bool scan_layout = false,
+                     bool pair_layout = false) -> unsigned int {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier LDS reads of this wave are done
         __builtin_amdgcn_wave_barrier();
         bool ov = false;
@@ -1578,7 +1609,13 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         const unsigned long long m = __builtin_amdgcn_ballot_w64(ov);
         if (ov) {
             const unsigned int slot = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            if (scan_layout) {
+            if (pair_layout) {
+                float* P = reinterpret_cast<float*>(&L) + (slot >> 1) * 24u + (slot & 1u);
+                P[0] = r.a.x; P[2] = r.a.y; P[4] = r.a.z; P[6] = r.a.w;
+                P[8] = r.b.x; P[10] = r.b.z; P[12] = r.b.y; P[14] = r.b.w;
+                float* Q = reinterpret_cast<float*>(&L) + (slot >> 1) * 24u + 2u * (slot & 1u);
+                Q[16] = r.c.x; Q[17] = r.c.y; Q[20] = r.c.z;
+            } else if (scan_layout) {
                 const float L2E = 1.4426950408889634f;
                 L.a[slot] = make_float4(r.a.x, r.a.y, __uint_as_float(base + lane), 0.0f);
                 L.b[slot] = make_float4(-0.5f * L2E * r.b.x, -L2E * r.b.y, -0.5f * L2E * r.b.z, __log2f(r.b.w));
@@ -1587,9 +1624,17 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 L.c[slot] = make_float4(r.c.x, r.c.y, r.c.z, __uint_as_float(base + lane));   // .w: list position
             }
         }
+        const unsigned int kk = (unsigned int)__builtin_popcountll(m);
+        if (pair_layout && (kk & 1u) && lane == 0) {
+            // an odd batch is completed by a record that covers nothing (half extents -1: alpha 0, blend is the identity)
+            float* P = reinterpret_cast<float*>(&L) + (kk >> 1) * 24u + 1u;
+            P[0] = 0.0f; P[2] = 0.0f; P[4] = -1.0f; P[6] = -1.0f; P[8] = 0.0f; P[10] = 0.0f; P[12] = 0.0f; P[14] = 0.0f;
+            float* Q = reinterpret_cast<float*>(&L) + (kk >> 1) * 24u + 2u;
+            Q[16] = 0.0f; Q[17] = 0.0f; Q[20] = 0.0f;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        return (unsigned int)__builtin_popcountll(m);
+        return kk;
     };
     // fragment(): src/pipelines.rs:134-143, branch-free.  Returns alpha, forced to 0 where the
     // fragment is rejected or the sample is not covered; `cov` reports coverage.
@@ -1698,6 +1743,42 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
             B2 = blend_channel(B2, ia, ab);
         }
     };
+    // two records per step (see the note above WaveLds); q0..q5 = the pair's 24 staged floats
+    const f2 sxm2 = {sxm, sxm}, sym2 = {sym, sym};
+    auto shade_pair = [&](auto BRt, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
+                          const float4& q5) {
+        constexpr bool BR = decltype(BRt)::value;
+        const f2 cx = {q0.x, q0.y}, cy = {q0.z, q0.w}, A = {q2.x, q2.y}, C = {q2.z, q2.w}, Bc = {q3.x, q3.y}, op = {q3.z, q3.w};
+        const f2 dx = sxm2 - cx, dy = cy - sym2;                     // K1 folded the y-axis sign into the cross term
+        const bool cov0 = (fabsf(dx.x) <= q1.x) & (fabsf(dy.x) <= q1.z), cov1 = (fabsf(dx.y) <= q1.y) & (fabsf(dy.y) <= q1.w);
+        const f2 power = -0.5f * (A * dx * dx + C * dy * dy) - Bc * dx * dy;
+        // exp_neg, both records
+        const float L2E_HI = __uint_as_float(0x3fb8aa3bu), L2E_LO = __uint_as_float(0x32a5705fu), LN2 = 0.6931471805599453f;
+        const f2 ph = power * L2E_HI;
+        f2 pl = __builtin_elementwise_fma(power, (f2)(L2E_HI), -ph);
+        pl = __builtin_elementwise_fma(power, (f2)(L2E_LO), pl);
+        const f2 e = {__builtin_amdgcn_exp2f(ph.x), __builtin_amdgcn_exp2f(ph.y)};
+        const f2 ex = __builtin_elementwise_fma(e * pl, (f2)(LN2), e);
+        const f2 al = op * ex;
+        const float a0 = fminf(0.99f, al.x), a1 = fminf(0.99f, al.y);
+        const float alpha0 = (cov0 & !(power.x > 0.0f) & !(a0 < 1.0f / 255.0f)) ? a0 : 0.0f;
+        const float alpha1 = (cov1 & !(power.y > 0.0f) & !(a1 < 1.0f / 255.0f)) ? a1 : 0.0f;
+        auto blend_one = [&](float alpha, f2 rg, float b) {
+            const float ia = 1.0f - alpha;
+            const f2 arg = alpha * rg;
+            const float ab = alpha * b;
+            f2 s = blend_channel2((f2){R, G}, ia, arg);
+            R = s.x; G = s.y;
+            B = blend_channel(B, ia, ab);
+            if (BR) {
+                s = blend_channel2((f2){R2, G2}, ia, arg);
+                R2 = s.x; G2 = s.y;
+                B2 = blend_channel(B2, ia, ab);
+            }
+        };
+        blend_one(alpha0, (f2){q4.x, q4.y}, q5.x);
+        blend_one(alpha1, (f2){q4.z, q4.w}, q5.z);
+    };
     // Walk batches [start, end).  In bracket mode stop at the first batch boundary where every
     // pixel has lo == hi and return that position; otherwise return `end`.
     auto run = [&](auto BRt, unsigned int start) -> unsigned int {
@@ -1707,10 +1788,16 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         if (cntN) fetch(bsN, cntN, r);
         while (cntN) {
             const unsigned int bs = bsN, cnt = cntN;
-            const unsigned int k = stage(r, cnt, bs, true);
+            const unsigned int k = stage(r, cnt, bs, true, false, PAIR);
             bsN = bs + cnt; cntN = min(64u, end - bsN);
             if (cntN) fetch(bsN, cntN, r);                  // prefetch the next (nearer) batch
-            for (unsigned int j = 0; j < k; ++j) shade(BRt, L.a[j], L.b[j], L.c[j]);
+            if constexpr (PAIR) {
+                const float4* P4 = reinterpret_cast<const float4*>(&L);
+                for (unsigned int j = 0; j < (k + 1u) / 2u; ++j)
+                    shade_pair(BRt, P4[6 * j], P4[6 * j + 1], P4[6 * j + 2], P4[6 * j + 3], P4[6 * j + 4], P4[6 * j + 5]);
+            } else {
+                for (unsigned int j = 0; j < k; ++j) shade(BRt, L.a[j], L.b[j], L.c[j]);
+            }
             itB += k;
             if (BR && __builtin_amdgcn_ballot_w64(inside & ((R != R2) | (G != G2) | (B != B2))) == 0ull) return bsN;
         }
@@ -1748,6 +1835,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 // The launch: one workgroup per tile, slot blockIdx.x of the longest-first order.  (A persistent grid pulling
 // slots from a ticket counter, and the order composited as consecutive chunk launches, were both measured as
 // ways to cap the compositor's residency beside the next frame's K1: both slower -- DESIGN.md section 3.)
+template <bool PAIR>
 __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned int* __restrict__ lens,
@@ -1758,7 +1846,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
                                                               unsigned int keep_keys, const unsigned int* __restrict__ orig) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
-    composite_tile(smem, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig);
+    composite_tile<PAIR>(smem, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig);
 }
 
 // ---------------------------------------------------------------------------
@@ -1860,7 +1948,7 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
-                      bool keep_keys) {
+                      bool keep_keys, bool pair_walk) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
@@ -1868,8 +1956,12 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
     static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
     static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
-    hipLaunchKernelGGL(composite_exact_kernel, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status,
-                       fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
+    if (pair_walk)
+        hipLaunchKernelGGL(composite_exact_kernel<true>, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
+                           status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
+    else
+        hipLaunchKernelGGL(composite_exact_kernel<false>, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
+                           status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
 }
 
 }  // namespace splat

@@ -617,3 +617,52 @@ def test_bench_multirank_path_on_shared_gpu():
         assert d["n_gpus"] == n and d["scaling"] == "strong"
         assert d["multi_gpu_frame_equals_single_gpu_frame"] is True
         assert d["config"]["n_pairs"] == 946132          # the slabs partition the frame's pairs exactly
+
+
+def test_paired_walk_gives_the_same_bytes():
+    """The compositor has two flavours of the exact walk -- one record per step, and two records per step with packed
+    f32 math (fewer issue slots for latency-bound waves; chosen per frame by the host) -- which must be the same
+    function: every component goes through the same IEEE operations in the same order.  Frames are compared byte for
+    byte over short lists, long lists (early-out, bracket, retries), odd and even batch sizes, a non-zero image to
+    blend onto and non-finite colours; and both against the oracle."""
+    import os
+    rng = np.random.default_rng(12)
+    cases = []
+    g1 = splat_amd.synthetic_scene(40000, 51)
+    cases.append((g1, make_camera(200, 296), 0.01))
+    g2 = splat_amd.synthetic_scene(90000, 52)
+    g2.positions[:, :3] *= 0.25                                  # dense: lists of thousands of keys
+    g2.sh[::97, 1] = np.inf
+    g2.sh[5::89, 2] = np.nan
+    cases.append((g2, make_camera(160, 224, (0.0, 0.1, 3.0), yaw=0.4), 0.3))
+    frames = {}
+    saved = os.environ.get("SPLAT_PAIR_BLEND")
+    try:
+        for mode in ("0", "1"):
+            os.environ["SPLAT_PAIR_BLEND"] = mode
+            r = splat_amd.Renderer()
+            try:
+                for ci, (g, cam, lp) in enumerate(cases):
+                    if not g.cov3d.any():
+                        g.compute_cov3d(r)
+                    r.upload(g)
+                    h, w = int(cam.h), int(cam.w)
+                    init = np.random.default_rng(ci).integers(0, 2**32, (h, w), dtype=np.uint64).astype(np.uint32)
+                    for variant, start in (("clear", np.zeros((h, w), np.uint32)), ("onto", init)):
+                        img = start.copy()
+                        st = r.render(cam.to_c(lp), img)
+                        frames[(mode, ci, variant)] = (img, st.n_pairs, st.max_tile_len)
+            finally:
+                r.close()
+    finally:
+        os.environ.pop("SPLAT_PAIR_BLEND", None)
+        if saved is not None:
+            os.environ["SPLAT_PAIR_BLEND"] = saved
+    for ci, (g, cam, lp) in enumerate(cases):
+        for variant in ("clear", "onto"):
+            a, b = frames[("0", ci, variant)], frames[("1", ci, variant)]
+            assert np.array_equal(a[0], b[0]), (ci, variant, int((a[0] != b[0]).sum()))
+        assert frames[("0", ci, "clear")][0].any()
+    assert frames[("0", 1, "clear")][2] > 2048                  # the dense case does exercise the long-list paths
+    ref, ost = O.render(scene_dict(cases[1][0]), oracle_camera(cases[1][1], 0.3), nthreads=8)
+    assert image_diff(frames[("1", 1, "clear")][0], ref)[0] <= TOL_LSB
