@@ -168,7 +168,7 @@ int splat_get_tile_lists(splat_ctx* ctx, uint32_t* tile_offsets, uint64_t n_offs
  * two-pass binning (count, scan, emit into exactly sized lists), < 0 without a frame.  One-pass
  * is the default (buckets of up to 16384 keys, grown to at most 65536 when a frame needs it);
  * SPLAT_BUCKETS=0, a caller-fixed pair_capacity, buckets that would not fit SPLAT_BUCKET_BYTES
- * (default 48 GiB for all frame slots together) or a tile list longer than 65536 select two-pass. */
+ * (default 128 GiB for all frame slots together) or a tile list longer than 65536 select two-pass. */
 int64_t splat_binning_mode(splat_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------

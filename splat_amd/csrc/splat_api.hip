@@ -1,14 +1,15 @@
 // splat_api.hip -- C ABI (include/splat_hip.h) over the gfx950 kernels.  Host side only:
 // buffer ownership, per-frame constants, launch sequence, HIP-event timing, error reporting.
 //
-// Frames overlap on the device (SPLAT_PIPELINE = frames in flight, default 2): per-frame buffers live
-// in SLOTS used in rotation; preprocess + scan + sort of frame N+1 run on an internal high-priority
-// stream into the next slot while frame N composites on the caller's stream (fork/join = two events
-// per frame; nothing is skipped or reused between frames).  K1 and the sort are latency chains
-// (36 % / < 21 % VALU), the compositor is VALU bound (78 %): side by side they take 0.57 ms per frame
-// instead of 0.63 (C3; +10 %, C2 +35 %, C1 +47 %).  SPLAT_PIPELINE=3 also moves the sort to its own
-// stream (K1 of N+2 | sort of N+1 | compositor of N): the 147-KB-LDS sort workgroups then starve
-// beside the other two (+3 % only) -- kept as an option.  SPLAT_PIPELINE=1: one stream, no overlap.
+// Frames overlap on the device (SPLAT_PIPELINE): per-frame buffers live in SLOTS used in rotation; preprocess +
+// scan + sort of later frames run on internal high-priority streams into the next slots while frame N composites
+// on the caller's stream (fork/join = two events per frame; nothing is skipped or reused between frames).
+//   1  one stream, no overlap
+//   2  the chain (K1, scan, sort) of frame N+1 on the bin stream under the compositor of frame N
+//   3  the sort on a stream of its own (it starves beside the other two: no gain)
+//   4, 5  three / four slots on the two streams of mode 2 (+0..2 %)
+//   6  (default) four slots, the chains of consecutive frames on alternating streams: with one chain at a time the
+//      frame time is the chain's length under contention; with two the compositor is the bound (C3 +4 %, C1 +10 %)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -78,7 +79,7 @@ struct splat_ctx {
     // the buckets would not fit bucket_bytes, or a tile outgrew the largest LDS-sortable bucket
     bool use_buckets = true;
     bool bucket_failed = false;            // sticky until the scene / target geometry changes
-    uint64_t bucket_bytes = 48ull << 30;   // SPLAT_BUCKET_BYTES: all key buffers of all slots together
+    uint64_t bucket_bytes = 128ull << 30;  // SPLAT_BUCKET_BYTES: all key buffers of all slots together (288 GB of HBM per GPU)
     unsigned int bucket_min = 0;           // a tile outgrew a smaller bucket: buckets of at least this many keys
     unsigned int bucket_want = 0;          // longest list of a harvested frame that overflowed its bucket
     unsigned int bucket_m = 0;             // tile count bucket_failed refers to
@@ -136,7 +137,7 @@ struct splat_ctx {
     int prio_len = 0x3fffffff;             // SPLAT_PRIO_LEN
     unsigned int fused_sort_max = 2048;    // SPLAT_FUSED_SORT: lists up to this length are sorted inside the compositor (0: off)
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
-    int pipeline = 2;                      // frames in flight on the device (SPLAT_PIPELINE = 1 | 2 | 3, see enqueue_frame)
+    int pipeline = 6;                      // frames in flight on the device (SPLAT_PIPELINE = 1..6, see enqueue_frame)
     splat::CommState* comm = nullptr;      // multi-GPU: RCCL communicator + partition (splat_multi.hip)
     std::string err;
 };
@@ -381,8 +382,11 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // frame N+1 on the sort stream, compositor of frame N on the caller's stream -- the bin chain is
     // the longest of the three under contention, so splitting it raises the frame rate.
     hipStream_t bs = c->pipeline ? c->bin_stream : c->stream;
-    // 6: the bin + sort chains of consecutive frames alternate between two streams, so the chain of frame N+2
-    // (a latency chain: K1 -> scan -> sort) runs beside the chain of frame N+1 and the compositor of frame N
+    // 6 (default): four slots, and the bin + sort chains of consecutive frames alternate between two streams, so
+    // the chain of frame N+2 (a latency chain: K1 -> scan -> sort) runs beside the chain of frame N+1 and the
+    // compositor of frame N.  With one chain at a time the frame time IS the chain's length under contention
+    // (C3: 0.28 + 0.03 + 0.11 = 0.42 ms against a compositor of 0.37); two in flight leave the compositor as the
+    // bound: C3 2241 -> 2334 fps, C1 17.4 k -> 19.2 k, C5 +1 %, C2 -1 %
     if (c->pipeline >= 6 && (c->frame_idx & 1ull)) bs = c->sort_stream;
     hipStream_t ss = c->pipeline == 3 ? c->sort_stream : bs;     // (4, 5: three / four slots on two streams)
     const unsigned int m = c->n_tiles;
