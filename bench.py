@@ -329,8 +329,11 @@ def main():
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                traffic = tj.get(args.workload, {}).get("composite_exact_kernel")
-                valu_util = tj.get(args.workload, {}).get("composite_exact_kernel:detail", {}).get("valu_issue_util")
+                wl = tj.get(args.workload, {})
+                kname = next((k for k in ("composite_exact_kernel<false>", "composite_exact_kernel<true>", "composite_exact_kernel")
+                              if k in wl), None)
+                traffic = wl.get(kname) if kname else None
+                valu_util = wl.get(kname + ":detail", {}).get("valu_issue_util") if kname else None
                 prof_src = tj.get(args.workload + ":source")
             except Exception:
                 traffic = None

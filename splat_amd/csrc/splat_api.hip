@@ -649,11 +649,14 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if ((e = init_device_kernels()) != hipSuccess) return bail("hipFuncSetAttribute", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->own_stream = true;
-    {   // the binning stream gets the highest priority: a separate hardware queue from the caller's
-        // stream, and its short streaming kernels should not queue behind a frame-long compositor
+    {   // The binning streams are separate hardware queues from the caller's stream.  With ONE chain in flight
+        // (SPLAT_PIPELINE <= 5) they get the highest priority: the chain is the frame's critical path and its
+        // short kernels should not queue behind a frame-long compositor (normal priority: 2174 -> 1969 fps).
+        // With TWO chains in flight (6, the default) the compositor is the critical path and the chains run at
+        // its priority (2349 -> 2384 fps on C3, C5 +1 %, C2 unchanged).
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        int prio = hi;
+        int prio = c->pipeline >= 6 ? (lo + hi) / 2 : hi;
         if (const char* ep = std::getenv("SPLAT_BIN_PRIO")) prio = std::atoi(ep) > 0 ? hi : (std::atoi(ep) < 0 ? lo : (lo + hi) / 2);
         if ((e = hipStreamCreateWithPriority(&c->bin_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
         if ((e = hipStreamCreateWithPriority(&c->sort_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
