@@ -408,6 +408,33 @@ def main():
                                         "SURVEY appendix B's recollection of CoordinateMode::VULKAN = y down), pixel-centre "
                                         "samples, z-clip [0,1], inclusive rectangle -- euc@290e14c is not in the image"}
             parity_ok = out["parity"]["max_channel_diff_lsb"] <= 1 and out["parity"]["pairs_equal"]
+            # the verification mode: fragment()'s exp computed as the host libm does -> the oracle's frame bit for bit
+            R.close()
+            R2 = splat_amd.Renderer(device=local, mode=splat_amd.MODE_LIBM_EXP)
+            R2.upload(g)
+            R2.set_stream(stream.cuda_stream)
+            with torch.cuda.stream(stream):
+                image.zero_()
+                R2.render_device(last_pose, image.data_ptr(), sync=True)
+            torch.cuda.synchronize()
+            exact_img = image.cpu().numpy().view(np.uint32)
+            for _ in range(5):
+                with torch.cuda.stream(stream):
+                    image.zero_(); R2.render_device(last_pose, image.data_ptr())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(60):
+                with torch.cuda.stream(stream):
+                    image.zero_(); R2.render_device(last_pose, image.data_ptr())
+            torch.cuda.synchronize()
+            out["parity"]["libm_exp_mode"] = {"pixels_differing": int((exact_img != ref).sum()),
+                                              "frames_per_sec": 60 / (time.perf_counter() - t1),
+                                              "what": "SPLAT_MODE_LIBM_EXP: exp as glibc computes it (double, table + cubic); every "
+                                                      "other operation is already the reference's, so the frame must be the "
+                                                      "oracle's bit for bit -- the default mode's differing pixels are the "
+                                                      "exponential's last place and nothing else"}
+            parity_ok = parity_ok and out["parity"]["libm_exp_mode"]["pixels_differing"] == 0
+            R2.close()
         print(json.dumps(out))
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY MISS against the oracle: %s\n" % json.dumps(out["parity"]))

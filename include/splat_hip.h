@@ -32,12 +32,16 @@ extern "C" {
 
 #define SPLAT_TILE 16            /* 16x16 pixel tiles                                     */
 
-/* composite modes */
-#define SPLAT_MODE_EXACT 0       /* back-to-front, 8-bit truncation per splat: bit-faithful to blend() */
+/* modes: bit flags, 0 = the default */
+#define SPLAT_MODE_EXACT 0       /* back-to-front, 8-bit truncation per splat as blend() does it; the exponential of
+                                    fragment() is the device's (~1.5 ulp): within 1 LSB of libm's on ~1e-5 of the pixels */
 #define SPLAT_MODE_CORRECTED_PROJECTION 1 /* same compositing, but cov2d = J W S W^T J^T with the perspective-shear
                                     terms of J (3DGS paper) that the reference drops (its Matrix3::new is
                                     row-major, src/gaussians.rs:141-151).  NOT parity with the reference:
                                     SURVEY section 8(f) rank 2, off by default.                                  */
+#define SPLAT_MODE_LIBM_EXP 2    /* fragment()'s exp computed exactly as glibc's expf does (in double, table + cubic):
+                                    the frame is then the CPU restatement's frame bit for bit.  A verification mode:
+                                    ~1.5x the compositor's time.  May be combined with the flag above.               */
 
 typedef struct splat_ctx splat_ctx;
 

@@ -13,3 +13,4 @@ from .multi import MultiRenderer, slab_partition_native  # noqa: F401
 
 MODE_EXACT = 0                  # SPLAT_MODE_EXACT: the reference's arithmetic
 MODE_CORRECTED_PROJECTION = 1   # SPLAT_MODE_CORRECTED_PROJECTION: EWA Jacobian with its shear terms (not the reference)
+MODE_LIBM_EXP = 2               # SPLAT_MODE_LIBM_EXP: fragment()'s exp as glibc's expf computes it (bit-exact frames, slower)

@@ -348,7 +348,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->early_eps = c->early_eps; fc->early_min = c->early_min; fc->prio_len = c->prio_len;
     fc->early_scan8 = c->early_scan8;
     fc->bucket_cap = 0;
-    fc->corrected = (c->cfg.mode == SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
+    fc->corrected = (c->cfg.mode & SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
     // (a singular cov2d needs lowpass == 0 or a non-PSD cov3d; with lowpass == 0 every Gaussian is
     // looked at so that n_singular stays what the reference would have panicked on)
     fc->cull_blocks = (c->cull_blocks && c->bounds && cam->lowpass > 0.0f) ? 1 : 0;
@@ -445,7 +445,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const bool pair_walk = c->pair_mode >= 0 ? c->pair_mode != 0
                                              : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
     launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->orig, c->fused_sort_max, iters, want_iters,
-                     pair_walk);
+                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0);
     HIP_TRY(c, mark(6, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
@@ -618,7 +618,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     splat_config def;
     splat_default_config(&def);
     if (!cfg) cfg = &def;
-    if (cfg->mode != SPLAT_MODE_EXACT && cfg->mode != SPLAT_MODE_CORRECTED_PROJECTION)
+    if (cfg->mode & ~(SPLAT_MODE_CORRECTED_PROJECTION | SPLAT_MODE_LIBM_EXP))
         return fail(nullptr, SPLAT_ERR_INVALID, "unknown mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

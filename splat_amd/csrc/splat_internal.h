@@ -94,7 +94,8 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       uint2* iters = nullptr /* per wave (scan, blend) iteration counts, statistics frames only */,
                       bool keep_keys = true /* lists sorted inside the compositor are also written back to the bucket
                                                (the debug getters read them there); off on ordinary frames */,
-                      bool pair_walk = false /* the two-records-per-step flavour of the exact walk (same pixels) */);
+                      bool pair_walk = false /* the two-records-per-step flavour of the exact walk (same pixels) */,
+                      bool libm_exp = false /* SPLAT_MODE_LIBM_EXP: expf as the host libm computes it */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 // ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)

@@ -1436,6 +1436,42 @@ __device__ __forceinline__ float exp_neg(float x) {
     return fmaf(e * pl, LN2, e);
 }
 
+// expf as glibc computes it (sysdeps/ieee754/flt-32/e_expf.c since 2.27: the ARM optimized-routines algorithm,
+// restated from its published description): x N/ln2 = k + r with N = 32, 2^(k/N) from a 32-entry table of doubles,
+// 2^(r/N) as a cubic, all in double, one rounding to float at the end.  Bit-identical to the host libm's expf --
+// which is what the oracle (and, through Rust's f32::exp, the reference on a glibc host) calls -- on every input
+// that can reach it here (checked against libm on random arguments by tests/test_host.py through the same
+// constants).  SPLAT_MODE_LIBM_EXP selects it: the frame is then the oracle's frame BIT FOR BIT, which shows that
+// the exponential's last place is the only thing the default build rounds differently.  It costs ~18 double
+// instructions per fragment, so it is a verification mode, not the default.
+__constant__ const unsigned long long EXP2F_TAB[32] = {      // tab[i] = bits(2^(i/32)) - (i << 47)
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+__device__ __forceinline__ float exp_libm(float x, const unsigned long long* __restrict__ tab /* LDS copy of EXP2F_TAB */) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0, C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    // below -87 expf is < 2e-38 and the fragment is rejected whatever its opacity; the clamp keeps k in the table's
+    // range without libm's underflow branches.  NaN stays NaN.
+    const double xd = (double)((x != x) ? x : fmaxf(x, -87.0f));
+    const double z = InvLn2N * xd;
+    double kd = z + SHIFT;                                     // round to nearest integer, in the low mantissa bits
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= SHIFT;
+    const double r = z - kd;
+    const double sc = __longlong_as_double((long long)(tab[ki & 31ull] + (ki << 47)));
+    const double zz = C0 * r + C1;
+    const double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * sc;
+    return (float)y;
+}
+
 // k / 255.0f (IEEE) for every integer k in [0,255] in two instructions: 1/255 split into
 // hi + lo floats, fma(k, hi, k*lo) rounds once (checked exhaustively in tests/test_host.py).
 __device__ __forceinline__ float div255(float k) {
@@ -1501,8 +1537,8 @@ __device__ __forceinline__ f2 blend_channel2(f2 k, float ia, f2 ac) {
 #endif
 // One tile (slot `item` of the longest-first tile order) by one workgroup; `smem` = sort_lds_bytes<256, 2048>() bytes.
 // PAIR: the exact walk takes two records per step with packed math (see the note above WaveLds).
-template <bool PAIR>
-__device__ __forceinline__ void composite_tile(unsigned char* smem, const unsigned int item, const FrameConst& fc,
+template <bool PAIR, bool LIBM>
+__device__ __forceinline__ void composite_tile(unsigned char* smem, const unsigned long long* exptab, const unsigned int item, const FrameConst& fc,
                                                const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
                                                const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
                                                const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
@@ -1638,7 +1674,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     };
     // fragment(): src/pipelines.rs:134-143, branch-free.  Returns alpha, forced to 0 where the
     // fragment is rejected or the sample is not covered; `cov` reports coverage.
-    auto frag_alpha = [&](const float4& a, const float4& b, float e_of_power(float), bool& cov) -> float {
+    auto expv = [&](float x) -> float {
+        if constexpr (LIBM) return exp_libm(x, exptab);
+        else return exp_neg(x);
+    };
+    auto frag_alpha = [&](const float4& a, const float4& b, auto e_of_power, bool& cov) -> float {
         float dx = sxm - a.x, dy = a.y - sym;          // K1 folded the y-axis sign into b.y
         cov = (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
         float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
@@ -1678,7 +1718,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 const unsigned int jr = (jsel != 0xffffffffu) ? jsel : 0u;
                 const float4 a = L.a[jr], b = L.b[jr];
                 bool cov;
-                const float alpha = frag_alpha(a, b, exp_neg, cov);      // exact, 0 when rejected
+                const float alpha = frag_alpha(a, b, expv, cov);      // exact, 0 when rejected
                 alast = (jsel != 0xffffffffu) ? alpha : alast;
             }
             if (__builtin_amdgcn_ballot_w64(!found) == 0ull || bs == beg) break;
@@ -1731,7 +1771,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     auto shade = [&](auto BRt, const float4& a, const float4& b, const float4& c) {
         constexpr bool BR = decltype(BRt)::value;
         bool cov;
-        const float alpha = frag_alpha(a, b, exp_neg, cov);
+        const float alpha = frag_alpha(a, b, expv, cov);
         const float ia = 1.0f - alpha;
         const float ar = alpha * c.x, ag = alpha * c.y, ab = alpha * c.z;
         R = blend_channel(R, ia, ar);
@@ -1835,7 +1875,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 // The launch: one workgroup per tile, slot blockIdx.x of the longest-first order.  (A persistent grid pulling
 // slots from a ticket counter, and the order composited as consecutive chunk launches, were both measured as
 // ways to cap the compositor's residency beside the next frame's K1: both slower -- DESIGN.md section 3.)
-template <bool PAIR>
+template <bool PAIR, bool LIBM>
 __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned int* __restrict__ lens,
@@ -1845,8 +1885,14 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
                                                               unsigned int radix_min, uint2* __restrict__ iters,
                                                               unsigned int keep_keys, const unsigned int* __restrict__ orig) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
+    __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
-    composite_tile<PAIR>(smem, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig);
+    if constexpr (LIBM) {
+        static_assert(!PAIR, "the libm exponential is built for the one-record walk only");
+        if (threadIdx.x < 32) exptab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+        __syncthreads();
+    }
+    composite_tile<PAIR, LIBM>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig);
 }
 
 // ---------------------------------------------------------------------------
@@ -1948,7 +1994,7 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
-                      bool keep_keys, bool pair_walk) {
+                      bool keep_keys, bool pair_walk, bool libm_exp) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
@@ -1956,11 +2002,14 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
     static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
     static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
-    if (pair_walk)
-        hipLaunchKernelGGL(composite_exact_kernel<true>, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
+    if (libm_exp)
+        hipLaunchKernelGGL((composite_exact_kernel<false, true>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs,
+                           argb, status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
+    else if (pair_walk)
+        hipLaunchKernelGGL((composite_exact_kernel<true, false>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
                            status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
     else
-        hipLaunchKernelGGL(composite_exact_kernel<false>, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
+        hipLaunchKernelGGL((composite_exact_kernel<false, false>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
                            status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
 }
 

@@ -77,3 +77,21 @@ def test_fullsize_frame_matches_oracle(wl, pose):
     assert st.n_sort_fallback == 0, st.n_sort_fallback
     assert img.any()
     R.sync()
+
+
+def test_fullsize_c3_libm_exp_mode_is_bit_exact():
+    """C3 at the bench pose with SPLAT_MODE_LIBM_EXP: 2 073 600 pixels, 849 M fragments in the oracle -- identical."""
+    n, W, H, seed = WORKLOADS["C3"]
+    c = workload("C3")
+    R = splat_amd.Renderer(mode=splat_amd.MODE_LIBM_EXP)
+    try:
+        R.upload(c["g"])
+        cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0))
+        cam.update_camera_pose()
+        img = np.zeros((H, W), np.uint32)
+        st = R.render(cam.to_c(0.01, 15), img)
+        ref, ost = O.render(c["sd"], oracle_camera(cam, 0.01), nthreads=os.cpu_count() or 8)
+        assert st.n_pairs == ost.n_tile_pairs
+        assert np.array_equal(img, ref), image_diff(img, ref)
+    finally:
+        R.close()

@@ -666,3 +666,25 @@ def test_paired_walk_gives_the_same_bytes():
     assert frames[("0", 1, "clear")][2] > 2048                  # the dense case does exercise the long-list paths
     ref, ost = O.render(scene_dict(cases[1][0]), oracle_camera(cases[1][1], 0.3), nthreads=8)
     assert image_diff(frames[("1", 1, "clear")][0], ref)[0] <= TOL_LSB
+
+
+def test_libm_exp_mode_is_the_oracle_bit_for_bit():
+    """SPLAT_MODE_LIBM_EXP: with fragment()'s exponential computed the way the host libm computes it, the HIP frame
+    must be the oracle's frame EXACTLY -- every other operation of the path is already the reference's f32
+    arithmetic in the reference's order.  This is the evidence behind the 1-LSB budget of the default mode: the
+    exponential's last place is the only thing it rounds differently."""
+    r = splat_amd.Renderer(mode=splat_amd.MODE_LIBM_EXP)
+    try:
+        cases = [(40000, 61, make_camera(200, 296), 0.01), (40000, 61, make_camera(200, 296, (0.3, 0.1, 2.0), yaw=0.8, pitch=0.2), 0.3),
+                 (90000, 62, make_camera(160, 224, (0.0, 0.1, 3.0)), 0.01)]
+        for n, seed, cam, lp in cases:
+            g = splat_amd.synthetic_scene(n, seed)
+            if seed == 62:
+                g.positions[:, :3] *= 0.25                      # dense: long lists, early-out and bracket paths
+            g.compute_cov3d(r)
+            init = np.random.default_rng(seed).integers(0, 2**32, (int(cam.h), int(cam.w)), dtype=np.uint64).astype(np.uint32)
+            img, st, ref, ost = render_both(r, g, cam, lp, init=init)
+            assert st.n_pairs == ost.n_tile_pairs
+            assert np.array_equal(img, ref), (n, seed, image_diff(img, ref))
+    finally:
+        r.close()

@@ -207,3 +207,45 @@ def test_threaded_loader_is_independent_of_the_thread_count(tmp_path):
     n = C.c_longlong()
     for threads in (1, 3, 0):
         assert L.splat_host_time_load(p.encode(), threads, C.byref(n), None, 0) > 0 and n.value == 20000
+
+
+def test_libm_exp_restatement_constants_and_algorithm():
+    """SPLAT_MODE_LIBM_EXP: the kernel's table is 2^(i/32) as glibc tabulates it, and the algorithm with exactly those
+    constants reproduces the host libm's expf bit for bit (this container's glibc = the GPU box's: same image)."""
+    import ctypes
+    import re
+    import struct
+    from decimal import Decimal, getcontext
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "splat_amd", "csrc", "splat_kernels.hip")).read()
+    body = src[src.index("EXP2F_TAB[32] = {"):]
+    body = body[:body.index("};")]
+    tab = [int(h, 16) for h in re.findall(r"0x([0-9a-f]{16})ull", body)]
+    assert len(tab) == 32
+    getcontext().prec = 60
+    ln2 = Decimal(2).ln()
+    for i in range(32):
+        want = struct.unpack("<Q", struct.pack("<d", float((ln2 * i / 32).exp())))[0] - (i << 47)
+        assert tab[i] == want, i
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    N = 32
+    inv = float.fromhex("0x1.71547652b82fep+0") * N
+    shift = float.fromhex("0x1.8p+52")
+    c0 = float.fromhex("0x1.c6af84b912394p-5") / N / N / N
+    c1 = float.fromhex("0x1.ebfce50fac4f3p-3") / N / N
+    c2 = float.fromhex("0x1.62e42ff0c52d6p-1") / N
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([-rng.random(60000) * 12.0, -rng.random(20000) * 87.0, -rng.random(2000) * 1e-3, [0.0, -0.0, -87.0]]).astype(np.float32)
+    x = xs.astype(np.float64)
+    z = inv * x
+    kd = z + shift
+    ki = kd.view(np.uint64)
+    kd = kd - shift
+    r = z - kd
+    t = (np.array(tab, np.uint64)[(ki & np.uint64(31)).astype(np.int64)] + (ki << np.uint64(47)))
+    s = t.view(np.float64)
+    zz = c0 * r + c1
+    y = ((zz * (r * r) + (c2 * r + 1.0)) * s).astype(np.float32)
+    ref = np.array([libm.expf(float(v)) for v in xs], np.float32)
+    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), int((y != ref).sum())
