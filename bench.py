@@ -3,7 +3,8 @@
 
 A step = one frame: clear the device image + render_to_buffer's whole path (preprocess, binning,
 per-tile sort, exact compositing) with scene and image resident in HBM -- the region
-src/main.rs:71-75 times.  N=1 workload: C3, the 1.5M-Gaussian 'truck' stand-in at 1920x1080
+src/main.rs:71-75 times (splat_render_frame_device: the clear is fused into the compositor, which then does
+not read the old pixels and zeroes the tiles nothing covers).  N=1 workload: C3, the 1.5M-Gaussian 'truck' stand-in at 1920x1080
 (synthetic, seed 3: no real PLY ships with the reference).
 
 N>1 ("scaling": "strong"): the same frame split into load-balanced tile-row slabs, one per GPU, with ONE
@@ -212,8 +213,8 @@ def main():
         pose = poses[frame_no[0] % len(poses)]
         frame_no[0] += 1
         with torch.cuda.stream(stream):
-            image.zero_()                                        # color = Buffer2d::fill([W,H], 0)
-            R.render_device(pose, image.data_ptr())              # enqueue only
+            # color.clear(0) + render_to_buffer (src/main.rs:73-74): one call, the clear fused into the compositor
+            R.render_frame_device(pose, image.data_ptr())        # enqueue only
             if gather_kind == "native":
                 R.comm_gather(image.data_ptr(), W, H, 0)         # grouped ncclSend / ncclRecv on the same stream
             elif world > 1:
@@ -258,13 +259,11 @@ def main():
             # (1) the 36-pose yaw orbit of src/main.rs:53-60, device resident like `value`
             if not args.orbit:
                 for k in range(4):
-                    with torch.cuda.stream(stream):
-                        image.zero_(); R.render_device(orbit[k], image.data_ptr())
+                    R.render_frame_device(orbit[k], image.data_ptr())
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for k in range(K):
-                    with torch.cuda.stream(stream):
-                        image.zero_(); R.render_device(orbit[k % 36], image.data_ptr())
+                    R.render_frame_device(orbit[k % 36], image.data_ptr())
                 torch.cuda.synchronize()
                 legs["orbit_36_poses_device_resident_fps"] = K / (time.perf_counter() - t1)
             # (2) host-visible: the literal render_to_buffer -- host image in and out, synchronous (src/main.rs:71-75)
@@ -419,13 +418,11 @@ def main():
             torch.cuda.synchronize()
             exact_img = image.cpu().numpy().view(np.uint32)
             for _ in range(5):
-                with torch.cuda.stream(stream):
-                    image.zero_(); R2.render_device(last_pose, image.data_ptr())
+                R2.render_frame_device(last_pose, image.data_ptr())
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(60):
-                with torch.cuda.stream(stream):
-                    image.zero_(); R2.render_device(last_pose, image.data_ptr())
+                R2.render_frame_device(last_pose, image.data_ptr())
             torch.cuda.synchronize()
             out["parity"]["libm_exp_mode"] = {"pixels_differing": int((exact_img != ref).sum()),
                                               "frames_per_sec": 60 / (time.perf_counter() - t1),

@@ -151,6 +151,11 @@ int splat_render_device(splat_ctx* ctx, const splat_camera* cam, void* d_argb, i
  * the storage has been grown: render it again.  Reported once.  A synchronous render redoes its OWN frame
  * internally and never returns this code for a frame that composited. */
 int splat_sync(splat_ctx* ctx);
+/* The viewer loop's frame on a device image: `color.clear(0); render_to_buffer(&mut color)` (src/main.rs:73-74) in one
+ * call -- the clear is fused into the compositor (old pixels are not read; tiles nothing covers are zeroed), so the
+ * frame costs no separate pass over the image.  Same result, byte for byte, as a memset followed by
+ * splat_render_device.  With a slab set, only the slab's rows are cleared and rendered. */
+int splat_render_frame_device(splat_ctx* ctx, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats);
 uint64_t splat_frames_dropped(const splat_ctx* ctx);  /* frames skipped on the device since splat_create (redone or reported) */
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */
 /* Run on a caller-owned hipStream_t (e.g. the stream a device image / RCCL gather lives on). */

@@ -53,6 +53,7 @@ SYMBOLS = [
     ("splat_tile_row_loads", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint64), C.c_int32]),
     ("splat_render", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
     ("splat_render_device", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p, C.c_int32, C.POINTER(Stats)]),
+    ("splat_render_frame_device", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     ("splat_sync", C.c_int, [C.c_void_p]),
     ("splat_frames_dropped", C.c_uint64, [C.c_void_p]),
     ("splat_stream", C.c_void_p, [C.c_void_p]),

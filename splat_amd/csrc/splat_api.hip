@@ -86,6 +86,14 @@ struct splat_ctx {
     uint64_t frame_idx = 0;
     int last_slot = -1;                    // buffer slot of the most recent frame (debug getters)
     FrameStatus* h_status = nullptr;       // pinned, one per event-ring entry
+    // Every frame in flight has a device status of its own (one per event-ring entry).  The scan kernel -- where a
+    // frame's pair count, longest list and every overflow verdict are decided -- initialises it and writes the same
+    // words straight into the pinned host copy, so an asynchronous frame needs no read-back and no reset on any
+    // stream: the caller's stream carries nothing but the compositors back to back (a copy and two fills used to sit
+    // between them, ~30 us per frame; a side stream for them shares a hardware queue with a binning stream and
+    // serialises the frames).  Frames rendered with statistics still copy the final status (late counters).
+    FrameStatus* d_status_ring = nullptr;
+    bool clear_first = false;              // the frame being enqueued starts from a cleared image (fused into the compositor)
     // host-image path
     uint32_t* d_img = nullptr;
     size_t img_cap = 0;
@@ -377,6 +385,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     harvest(c, r);
     const int si = (int)(c->frame_idx++ % (uint64_t)slots_in_use(c));
     Slot& s = c->slots[si];
+    FrameStatus* const d_st = c->d_status_ring + r;       // (initialised by this frame's scan)
     // pipeline depth 1: everything on the caller's stream.  2: K1..K3 of frame N+1 on the bin stream
     // under the compositor of frame N.  3: K1 + scan of frame N+2 on the bin stream, K2 + K3 of
     // frame N+1 on the sort stream, compositor of frame N on the caller's stream -- the bin chain is
@@ -396,9 +405,10 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         // for a caller that interleaves uploads), and after the compositor that last used the slot
         if (s.used) HIP_TRY(c, hipStreamWaitEvent(bs, s.ev_free, 0));
     }
+    if (!c->fc.bucket_cap)                                 // two-pass binning: K1 counts visible Gaussians into the status before the scan
+        HIP_TRY(c, hipMemsetAsync(d_st, 0, sizeof(FrameStatus), bs));
     HIP_TRY(c, mark(0, bs));
-    // (the slot's status is zero: cleared behind the read-back of the frame that used it last)
-    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, s.d_status);
+    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, d_st);
     HIP_TRY(c, mark(1, bs));
     if (c->sort_hint && c->tight_grids) {
         c->grid_big = c->hint_ge8192; c->grid_mid = c->hint_ge2048; c->grid_long = c->hint_ge16384;
@@ -411,7 +421,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     } else {
         c->grid_big = m; c->grid_mid = m; c->grid_long = m;
     }
-    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long);
+    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r]);
     HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
         HIP_TRY(c, hipEventRecord(s.ev_binned, bs));
@@ -419,9 +429,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     }
     HIP_TRY(c, mark(8, ss));
     if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
-        launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, s.d_status);
+        launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, d_st);
     HIP_TRY(c, mark(3, ss));
-    launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, s.d_status, c->orig, c->fused_sort_max);
+    launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
     if (c->pipeline) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
@@ -444,13 +454,13 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // others (C2 316, an eighth-of-a-frame slab 92, C1 36) take the paired one; measured crossover between 316 and 737
     const bool pair_walk = c->pair_mode >= 0 ? c->pair_mode != 0
                                              : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
-    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, s.d_status, c->orig, c->fused_sort_max, iters, want_iters,
-                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0);
+    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
+                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first);
     HIP_TRY(c, mark(6, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], s.d_status, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
+    // the scan has already delivered this frame's status to h_status[r]; a statistics frame refreshes it with the late
+    // counters (compositor retries, sort fallbacks)
+    if (want_iters) HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], d_st, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
-    // zero the status for the slot's next frame here, off the binning stream's critical path
-    HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
     if (c->pipeline) HIP_TRY(c, hipEventRecord(s.ev_free, c->stream));
     HIP_TRY(c, hipGetLastError());
     s.used = true;
@@ -668,6 +678,8 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         if ((e = hipEventCreateWithFlags(&s.ev_binned, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
+    if ((e = hipMalloc(&c->d_status_ring, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMalloc(status ring)", e);
+    if ((e = hipMemset(c->d_status_ring, 0, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMemset(status ring)", e);
     if ((e = hipHostMalloc(&c->h_status, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipHostMalloc(status)", e);
     std::memset(c->h_status, 0, sizeof(FrameStatus) * EV_RING);
     for (auto& s : c->ring)
@@ -699,6 +711,7 @@ void splat_destroy(splat_ctx* c) {
     }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_status) (void)hipHostFree(c->h_status);
+    dfree(c->d_status_ring);
     for (auto& s : c->ring)
         for (auto& ev : s.e)
             if (ev) (void)hipEventDestroy(ev);
@@ -839,14 +852,40 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     return SPLAT_OK;
 }
 
+}  // extern "C"
+
+namespace {
+int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats, bool clear_first);
+}
+
+extern "C" {
+
 int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats) {
+    return render_device_impl(c, cam, d_argb, sync, stats, false);
+}
+int splat_render_frame_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats) {
+    return render_device_impl(c, cam, d_argb, sync, stats, true);
+}
+
+}  // extern "C"
+
+namespace {
+int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats, bool clear_first) {
     if (!c) return SPLAT_ERR_INVALID;
     if (!d_argb) return fail(c, SPLAT_ERR_INVALID, "d_argb is NULL");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc = SPLAT_OK;
     if (c->n == 0 && !c->planes) {
-        // an empty scene renders nothing (the reference's loop body never runs)
-        if (stats) { c->last = FrameStatus{}; c->last_ring = -1; unsigned int nt; rc = build_frame_const(c, cam, &c->fc, &nt); if (rc) return rc; fill_stats(c, stats); }
+        // an empty scene renders nothing (the reference's loop body never runs); a viewer-loop frame is still cleared
+        unsigned int nt;
+        rc = build_frame_const(c, cam, &c->fc, &nt);
+        if (rc) return rc;
+        if (clear_first && c->fc.row_px1 > c->fc.row_px0) {
+            HIP_TRY(c, hipMemsetAsync((uint32_t*)d_argb + (size_t)c->fc.row_px0 * c->fc.W, 0,
+                                      (size_t)(c->fc.row_px1 - c->fc.row_px0) * c->fc.W * 4, c->stream));
+            if (sync || stats) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        if (stats) { c->last = FrameStatus{}; c->last_ring = -1; fill_stats(c, stats); }
         return SPLAT_OK;
     }
     rc = build_frame_const(c, cam, &c->fc, &c->n_tiles);
@@ -858,7 +897,9 @@ int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int
         rc = prepare_binning(c, c->n_tiles, &c->fc);
         if (rc != SPLAT_OK) return rc;
         const bool timed = stats != nullptr || c->timing_every <= 1 || (c->frame_idx % (uint64_t)c->timing_every) == 0;
+        c->clear_first = clear_first;
         rc = enqueue_frame(c, (uint32_t*)d_argb, timed, stats != nullptr);
+        c->clear_first = false;
         if (rc != SPLAT_OK) return rc;
         if (!sync && !stats) return SPLAT_OK;
         bool skipped = false;
@@ -883,6 +924,9 @@ int splat_render_device(splat_ctx* c, const splat_camera* cam, void* d_argb, int
     if (stats) fill_stats(c, stats);
     return SPLAT_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int splat_render(splat_ctx* c, const splat_camera* cam, uint32_t* argb, splat_stats* stats) {
     if (!c) return SPLAT_ERR_INVALID;
@@ -933,8 +977,7 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
     const int k = (int)(c->s_idx++ & 1u);
     // the image must not be cleared while its previous frame is still crossing PCIe
     if (c->s_used[k]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->s_copied[k], 0));
-    HIP_TRY(c, hipMemsetAsync(c->s_img[k], 0, bytes, c->stream));
-    rc = splat_render_device(c, cam, c->s_img[k], 0, nullptr);
+    rc = splat_render_frame_device(c, cam, c->s_img[k], 0, nullptr);      // clear + render (the clear is fused into the compositor)
     if (rc != SPLAT_OK) return rc;
     c->s_ring[k] = c->last_ring; c->s_cam[k] = *cam;
     HIP_TRY(c, hipEventRecord(c->s_rendered[k], c->stream));
@@ -965,8 +1008,7 @@ int splat_stream_wait(splat_ctx* c, const uint32_t* argb_out) {
             c->deferred_drop = false;
             // (the OTHER image's frame, if it was lost too, is redone by its own wait: its status says so)
             const size_t bytes = (size_t)c->s_cam[k].w * (size_t)c->s_cam[k].h * 4;
-            HIP_TRY(c, hipMemsetAsync(c->s_img[k], 0, bytes, c->stream));
-            rc = splat_render_device(c, &c->s_cam[k], c->s_img[k], 1, nullptr);
+            rc = splat_render_frame_device(c, &c->s_cam[k], c->s_img[k], 1, nullptr);
             if (rc != SPLAT_OK) return rc;
             c->s_ring[k] = c->last_ring;
             HIP_TRY(c, hipMemcpyAsync(const_cast<uint32_t*>(argb_out), c->s_img[k], bytes, hipMemcpyDeviceToHost, c->stream));

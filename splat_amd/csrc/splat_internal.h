@@ -77,7 +77,8 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
                        FrameStatus* status);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
-                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long);
+                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
+                 FrameStatus* host_status = nullptr /* pinned, device-visible: the scan also delivers the status there */);
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 // grid_big / grid_mid: how many entries of `order` (longest lists first) the 1024- and 512-thread
@@ -95,7 +96,9 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       bool keep_keys = true /* lists sorted inside the compositor are also written back to the bucket
                                                (the debug getters read them there); off on ordinary frames */,
                       bool pair_walk = false /* the two-records-per-step flavour of the exact walk (same pixels) */,
-                      bool libm_exp = false /* SPLAT_MODE_LIBM_EXP: expf as the host libm computes it */);
+                      bool libm_exp = false /* SPLAT_MODE_LIBM_EXP: expf as the host libm computes it */,
+                      bool clear_first = false /* the frame starts from a cleared image: old pixels are not read, tiles
+                                                  nothing covers are zeroed (color.clear(0) of src/main.rs:73, fused) */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 // ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)

@@ -533,7 +533,10 @@ __device__ __forceinline__ bool block_may_reach_slab(const BlockBounds& bb, cons
 // BUCKET = true  (one-pass binning): every tile owns a fixed-stride bucket of fc.bucket_cap keys;
 //          the slot reservation that counts a (Gaussian, tile) pair also places its key, so there is
 //          no K2 and no second read of the per-Gaussian data.
-template <bool BUCKET>
+// CORRECTED = SPLAT_MODE_CORRECTED_PROJECTION, a compile-time flavour: in the reference's projection the clamped tx/ty
+// and the Jacobian's shear entries only reach the discarded third column of cov (src/gaussians.rs:133-151), so the
+// compiler drops them -- two divisions, the clamps and a third of the products -- when it can see that.
+template <bool BUCKET, bool CORRECTED = false>
 __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes,
                                                          const unsigned int* __restrict__ orig, FrameConst fc,
                                                          Rec* __restrict__ recs, float* __restrict__ depth,
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) M3(Wm, r, c) = fc.view[r * 4 + c];
-        Mat3 T = fc.corrected ? mat3_mul(Wm, mat3_t(J)) : mat3_mul(Wm, J);   // corrected: the shear column reaches the 2x2 block
+        Mat3 T = CORRECTED ? mat3_mul(Wm, mat3_t(J)) : mat3_mul(Wm, J);   // corrected: the shear column reaches the 2x2 block
         Mat3 Sg;
 #pragma unroll
         for (int e = 0; e < 9; ++e) Sg.m[e] = F[4 + e];
@@ -745,7 +748,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
                                                     unsigned int* __restrict__ order, unsigned int* __restrict__ lens,
                                                     FrameStatus* __restrict__ status,
                                                     unsigned long long capacity, unsigned int bucket_cap,
-                                                    unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long) {
+                                                    unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
+                                                    FrameStatus* __restrict__ host_status) {
     constexpr int NCLS = 64;
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int hist[NCLS];
@@ -809,6 +813,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         const unsigned int ge16384 = start[cls_of(16384u)] + hist[cls_of(16384u)];
         status->n_ge8192 = ge8192; status->n_ge2048 = ge2048; status->n_ge16384 = ge16384;
         if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid || ge16384 > grid_long)) status->overflow = 3u;
+        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_iter_scan = 0; status->n_iter_blend = 0;
+        if (host_status) *host_status = *status;      // (n_visible / n_singular: K1's atomics, complete before this kernel)
     }
     __syncthreads();   // lens[] written above by this workgroup are visible to it
     for (unsigned int k = tid; k < m; k += 1024) order[atomicAdd(&start[cls_of(lens[k])], 1u)] = k;
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int* __restrict__ order, unsigned int* __restrict__ lens,
                                                            FrameStatus* __restrict__ status, unsigned int bucket_cap,
                                                            unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
-                                                           unsigned int cls_in_lds) {
+                                                           unsigned int cls_in_lds, FrameStatus* __restrict__ host_status) {
     constexpr int NCLS = 64;
     __shared__ unsigned int row[SCAN_NT / 64][NCLS];
     __shared__ unsigned int start[NCLS];
@@ -899,6 +905,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         status->max_tile_len = mx;
         status->n_ge16384 = ge[0]; status->n_ge8192 = ge[1]; status->n_ge2048 = ge[2];
         status->overflow = (mx > bucket_cap) ? 2u : ((ge[1] > grid_big || ge[2] > grid_mid || ge[0] > grid_long) ? 3u : 0u);
+        // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
+        status->n_visible = 0; status->n_singular = 0;
+        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_iter_scan = 0; status->n_iter_blend = 0;
+        status->pad_ = 0; status->n_blocks_culled = 0;
+        // ... and delivers it to the host: everything an asynchronous frame reports is decided here
+        if (host_status) *host_status = *status;
     }
     __syncthreads();
     // second pass: thread t keeps the same tiles, so its wave's row offsets are its own
@@ -1544,7 +1556,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                                                const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                FrameStatus* __restrict__ status, unsigned int fused_sort_max,
                                                unsigned int radix_min, uint2* __restrict__ iters, unsigned int keep_keys,
-                                               const unsigned int* __restrict__ orig) {
+                                               const unsigned int* __restrict__ orig, const unsigned int clear_first) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -1556,7 +1568,16 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     const unsigned int tid = threadIdx.x;
     const unsigned int beg = __builtin_amdgcn_readfirstlane(offsets[tile]);
     const unsigned int end = beg + __builtin_amdgcn_readfirstlane(lens[tile]);
-    if (beg == end) return;
+    if (beg == end) {
+        // nothing covers this tile.  A frame that starts from a cleared image (clear_first: the viewer loop's
+        // color.clear(0), src/main.rs:73, fused into this kernel) still owes the tile its zeros.
+        if (clear_first) {
+            const int txx0 = (int)(tile % (unsigned int)fc.tiles_x), tyy0 = (int)(tile / (unsigned int)fc.tiles_x) + fc.tile_row0;
+            const int px0 = txx0 * TILE + (int)(tid & 15u), py0 = tyy0 * TILE + (int)(tid >> 4);
+            if (px0 < fc.W && py0 < fc.H && py0 >= fc.row_px0 && py0 < fc.row_px1) argb[(size_t)py0 * fc.W + px0] = 0u;
+        }
+        return;
+    }
     // A list this workgroup sorts itself never travels back to memory: the order (2048 x 4 B) stays in LDS behind
     // the waves' record batches, and the walks below read their indices from there instead of from the bucket.
     unsigned int* const lds_idx = reinterpret_cast<unsigned int*>(smem + sizeof(WaveLds) * 4);
@@ -1590,7 +1611,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     const float xlo = (float)bx0 + off, xhi = (float)x1w + off;
     const float ylo = (float)y0w + off, yhi = (float)y1w + off;
     const float sx = (float)px + off, sy = (float)py + off;
-    const uint32_t old = inside ? argb[(size_t)py * fc.W + px] : 0u;
+    const uint32_t old = (inside && !clear_first) ? argb[(size_t)py * fc.W + px] : 0u;
 
     // Pixels outside the target never pass the coverage test: NaN sample coordinates.
     const float sxm = inside ? sx : __uint_as_float(0x7fc00000u), sym = inside ? sy : __uint_as_float(0x7fc00000u);
@@ -1883,7 +1904,8 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
                                                               unsigned int radix_min, uint2* __restrict__ iters,
-                                                              unsigned int keep_keys, const unsigned int* __restrict__ orig) {
+                                                              unsigned int keep_keys, const unsigned int* __restrict__ orig,
+                                                              unsigned int clear_first) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
@@ -1892,7 +1914,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         if (threadIdx.x < 32) exptab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
         __syncthreads();
     }
-    composite_tile<PAIR, LIBM>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig);
+    composite_tile<PAIR, LIBM>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig, clear_first);
 }
 
 // ---------------------------------------------------------------------------
@@ -1930,16 +1952,20 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
     if (!n) return;
     if (!bounds || !blockinfo) fc.cull_blocks = 0;
     if (!blockinfo) fc.bucket_cap = 0;
-    if (fc.bucket_cap)
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth,
-                           rect, counts, vislist, keys, bounds, blockinfo, status);
+    const dim3 grid(blocks_for(n, 256)), block(256);
+    if (fc.bucket_cap && fc.corrected)
+        hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
+    else if (fc.bucket_cap)
+        hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
+    else if (fc.corrected)
+        hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
     else
-        hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, planes, orig, fc, recs, depth,
-                           rect, counts, vislist, keys, bounds, blockinfo, status);
+        hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
-                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long) {
+                 unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
+                 FrameStatus* host_status) {
     if (bucket_cap)
     {
         static const char* env = std::getenv("SPLAT_SCAN_THREADS");
@@ -1950,17 +1976,17 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         const unsigned int dyn = in_lds ? cls_bytes : 0u;
         if (nt == 256)
             hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(1), dim3(256), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long, in_lds);
+                               grid_big, grid_mid, grid_long, in_lds, host_status);
         else if (nt == 512)
             hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(1), dim3(512), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long, in_lds);
+                               grid_big, grid_mid, grid_long, in_lds, host_status);
         else
             hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(1), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long, in_lds);
+                               grid_big, grid_mid, grid_long, in_lds, host_status);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
-                           bucket_cap, grid_big, grid_mid, grid_long);
+                           bucket_cap, grid_big, grid_mid, grid_long, host_status);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
@@ -1994,7 +2020,7 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
-                      bool keep_keys, bool pair_walk, bool libm_exp) {
+                      bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
@@ -2004,13 +2030,13 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
     if (libm_exp)
         hipLaunchKernelGGL((composite_exact_kernel<false, true>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs,
-                           argb, status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
+                           argb, status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u);
     else if (pair_walk)
         hipLaunchKernelGGL((composite_exact_kernel<true, false>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
-                           status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
+                           status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u);
     else
         hipLaunchKernelGGL((composite_exact_kernel<false, false>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
-                           status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig);
+                           status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u);
 }
 
 }  // namespace splat

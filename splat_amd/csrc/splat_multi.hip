@@ -370,9 +370,9 @@ void worker_main(splat_multi* m, Worker* me) {
                 if (!ensure_image(w, h)) break;
                 int a, b;
                 slab_px(&m->slabs[2 * me->rank], h, &a, &b);
-                // color.clear(0) of src/main.rs:73, on this rank's rows only
-                if (b > a) { hipError_t e = hipMemsetAsync(me->img + (size_t)a * w, 0, (size_t)(b - a) * w * 4, st); if (e != hipSuccess) { note(SPLAT_ERR_HIP, "hipMemsetAsync"); break; } }
-                if (!check(splat_render_device(me->ctx, &c.cam, me->img, 0, nullptr), "splat_render_device")) break;
+                // color.clear(0) + render_to_buffer of src/main.rs:73-74, on this rank's rows only (the clear is fused
+                // into the compositor)
+                if (!check(splat_render_frame_device(me->ctx, &c.cam, me->img, 0, nullptr), "splat_render_frame_device")) break;
                 gather(w, h);
                 break;
             }

@@ -146,6 +146,14 @@ class Renderer:
     def device_free(self, d_ptr):
         self._L.splat_device_free(self._h, C.c_void_p(d_ptr))
 
+    def render_frame_device(self, cam_c, d_ptr, sync=False, want_stats=False):
+        """the viewer loop's frame (clear + render_to_buffer, src/main.rs:73-74) on a device image; the clear is fused
+        into the compositor"""
+        st = _lib.Stats() if want_stats else None
+        self._check(self._L.splat_render_frame_device(self._h, C.byref(cam_c), C.c_void_p(d_ptr), 1 if sync else 0,
+                                                      C.byref(st) if want_stats else None))
+        return st
+
     def sync(self):
         """Wait for everything enqueued.  Raises SplatError(ERR_CAPACITY) once if an ASYNCHRONOUS frame was
         skipped on the device (storage has been grown: render it again)."""

@@ -688,3 +688,39 @@ def test_libm_exp_mode_is_the_oracle_bit_for_bit():
             assert np.array_equal(img, ref), (n, seed, image_diff(img, ref))
     finally:
         r.close()
+
+
+def test_frame_with_fused_clear_equals_clear_then_render(R):
+    """splat_render_frame_device (the viewer loop's clear + render_to_buffer, src/main.rs:73-74, the clear fused into the
+    compositor) must give the bytes of a memset followed by splat_render_device: whole frame, a slab (rows outside it
+    untouched), a camera that leaves most tiles empty, and an empty scene."""
+    g = gpu_scene(R, 30000, 44)
+    R.upload(g)
+    rng = np.random.default_rng(8)
+    h, w = 200, 312
+    garbage = rng.integers(0, 2**32, (h, w), dtype=np.uint64).astype(np.uint32)
+    for cam, slab in ((make_camera(h, w), None), (make_camera(h, w, (4.0, 0.0, 5.0), yaw=0.2), None), (make_camera(h, w), (3, 9))):
+        cam_c = cam.to_c(0.01)
+        if slab:
+            R.set_slab(*slab)
+        want = np.zeros((h, w), np.uint32)
+        if slab:
+            want[:] = garbage
+            want[slab[0] * 16:min(slab[1] * 16, h)] = 0
+        d = R.device_image(want)
+        R.render_device(cam_c, d, sync=True)
+        want = R.device_download(d, h, w)
+        d2 = R.device_image(garbage)
+        R.render_frame_device(cam_c, d2, sync=True)
+        got = R.device_download(d2, h, w)
+        R.set_slab(0, -1)
+        assert np.array_equal(got, want), (slab, int((got != want).sum()))
+        assert want.any()
+        for p in (d, d2):
+            R.device_free(p)
+    empty = splat_amd.GaussianList(np.zeros((0, 4)), np.zeros((0, 3)), np.zeros(0), np.zeros((0, 4)), np.zeros((0, 48)))
+    R.upload(empty)
+    d = R.device_image(garbage)
+    R.render_frame_device(make_camera(h, w).to_c(0.01), d, sync=True)
+    assert not R.device_download(d, h, w).any()
+    R.device_free(d)
