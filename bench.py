@@ -329,8 +329,7 @@ def main():
             try:
                 tj = json.load(open(tp))
                 wl = tj.get(args.workload, {})
-                kname = next((k for k in ("composite_exact_kernel<false>", "composite_exact_kernel<true>", "composite_exact_kernel")
-                              if k in wl), None)
+                kname = next((k for k in sorted(wl) if k.startswith("composite_exact_kernel") and not k.endswith(":detail")), None)
                 traffic = wl.get(kname) if kname else None
                 valu_util = wl.get(kname + ":detail", {}).get("valu_issue_util") if kname else None
                 prof_src = tj.get(args.workload + ":source")
