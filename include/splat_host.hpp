@@ -99,6 +99,9 @@ public:
     // public `gaussians` field on every render_to_buffer, src/pipelines.rs:67-79).  After mutating
     // `gaussians` (edits, compute_cov3d after the first frame, ...) call this: the next frame uploads again.
     void invalidate_scene() { uploaded_ = nullptr; }
+    // SPLAT_MODE_* flags (include/splat_hip.h) for this pipeline's GPU context; the reference has no such switch and
+    // the default (0) is its arithmetic.  Must be called before the first frame (the context is created there).
+    void set_mode(int mode);
     static uint32_t* alloc_frame(size_t pixels);
     static void free_frame(uint32_t* p);
 protected:
@@ -108,6 +111,7 @@ protected:
     void ensure(const GaussianList& g);
     splat_ctx* ctx_ = nullptr;
     const void* uploaded_ = nullptr;
+    int mode_ = 0;
 };
 }  // namespace detail
 

@@ -13,4 +13,5 @@ from .multi import MultiRenderer, slab_partition_native  # noqa: F401
 
 MODE_EXACT = 0                  # SPLAT_MODE_EXACT: the reference's arithmetic
 MODE_CORRECTED_PROJECTION = 1   # SPLAT_MODE_CORRECTED_PROJECTION: EWA Jacobian with its shear terms (not the reference)
+MODE_FAST = 4                   # SPLAT_MODE_FAST: every colour byte within 1 of the exact frame's, by construction; ~1/3 less compositor work
 MODE_LIBM_EXP = 2               # SPLAT_MODE_LIBM_EXP: fragment()'s exp as glibc's expf computes it (bit-exact frames, slower)

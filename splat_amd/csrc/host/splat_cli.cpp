@@ -12,14 +12,15 @@
 int main(int argc, char** argv) {
     const char* ply = nullptr; const char* out = nullptr;
     int W = 800, H = 600, frames = 36;
-    bool streaming = false;
+    bool streaming = false, fast = false;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--ply") && i + 1 < argc) ply = argv[++i];
         else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
         else if (!std::strcmp(argv[i], "--size") && i + 2 < argc) { W = std::atoi(argv[++i]); H = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--stream")) streaming = true;
-        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--stream] [--out frame.ppm]\n"); return 2; }
+        else if (!std::strcmp(argv[i], "--fast")) fast = true;      // SPLAT_MODE_FAST: every colour byte within 1 of the exact frame
+        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--stream] [--fast] [--out frame.ppm]\n"); return 2; }
     }
     try {
         std::printf("Loading gaussians from %s\n", ply ? ply : "naive_gaussians()");
@@ -28,6 +29,7 @@ int main(int argc, char** argv) {
         for (auto& x : g) x.compute_cov3d();
         splat::Vec3 pos{0.0f, 0.0f, 5.0f};                    // CAMERA_POSITION, src/main.rs:13
         splat::GaussianSplatPipeline01 pipeline(g, splat::Camera((float)H, (float)W, &pos));
+        if (fast) pipeline.set_mode(SPLAT_MODE_FAST);
         std::vector<uint32_t> color((size_t)W * H, 0u);
         if (streaming) {
             // the same loop with the present step decoupled: two pinned frames in flight, frame f is

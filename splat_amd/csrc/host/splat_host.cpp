@@ -342,9 +342,16 @@ void GaussianList::compute_cov3d(splat_ctx* gpu) {
 // ---------------------------------------------------------------- pipelines (src/pipelines.rs)
 namespace detail {
 PipelineBase::~PipelineBase() { if (ctx_) splat_destroy(ctx_); }
+void PipelineBase::set_mode(int mode) {
+    if (ctx_) throw std::logic_error("set_mode: the GPU context already exists (call before the first frame)");
+    mode_ = mode;
+}
 void PipelineBase::ensure(const GaussianList& g) {
     if (!ctx_) {
-        if (splat_create(nullptr, &ctx_) != SPLAT_OK) throw std::runtime_error(std::string("splat_create: ") + splat_last_error(nullptr));
+        splat_config cfg;
+        splat_default_config(&cfg);
+        cfg.mode = mode_;
+        if (splat_create(&cfg, &ctx_) != SPLAT_OK) throw std::runtime_error(std::string("splat_create: ") + splat_last_error(nullptr));
     }
     if (uploaded_ != (const void*)&g) {        // lazily, once per scene object
         check(splat_upload_scene(ctx_, g.num_gaussians, g.positions.data(), g.cov3d.data(), g.opacities.data(), g.sh.data()),

@@ -139,6 +139,7 @@ struct splat_ctx {
     uint2* d_iters = nullptr;              // per compositor wave: (scan, blend) iterations of a frame rendered with stats
     unsigned int iters_alloc = 0;
     bool iters_valid = false;
+    float fast_width = 2.0f;               // SPLAT_MODE_FAST: bracket width that counts as closed (SPLAT_FAST_WIDTH: 1 or 2)
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
     int early_min = 768;                   // SPLAT_EARLY_MIN
     int early_scan8 = 4;                   // SPLAT_EARLY_SCAN8
@@ -354,6 +355,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->y_up = c->cfg.y_up; fc->sample_half = c->cfg.sample_half; fc->zclip = c->cfg.zclip;
     fc->zmin = c->cfg.zmin; fc->zmax = c->cfg.zmax;
     fc->early_eps = c->early_eps; fc->early_min = c->early_min; fc->prio_len = c->prio_len;
+    fc->close_width = (c->cfg.mode & SPLAT_MODE_FAST) ? c->fast_width : 0.0f;
     fc->early_scan8 = c->early_scan8;
     fc->bucket_cap = 0;
     fc->corrected = (c->cfg.mode & SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
@@ -628,7 +630,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     splat_config def;
     splat_default_config(&def);
     if (!cfg) cfg = &def;
-    if (cfg->mode & ~(SPLAT_MODE_CORRECTED_PROJECTION | SPLAT_MODE_LIBM_EXP))
+    if (cfg->mode & ~(SPLAT_MODE_CORRECTED_PROJECTION | SPLAT_MODE_LIBM_EXP | SPLAT_MODE_FAST))
         return fail(nullptr, SPLAT_ERR_INVALID, "unknown mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -638,6 +640,8 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     splat_ctx* c = new (std::nothrow) splat_ctx();
     if (!c) return fail(nullptr, SPLAT_ERR_INVALID, "out of host memory");
     c->cfg = *cfg;
+    if (cfg->mode & SPLAT_MODE_FAST) c->early_eps = 2e-3f;      // hi - lo <= 2 needs a contraction of ~1/128, not of ~1e-5
+    if (const char* e0 = std::getenv("SPLAT_FAST_WIDTH")) c->fast_width = std::atoi(e0) <= 1 ? 1.0f : 2.0f;
     if (const char* e1 = std::getenv("SPLAT_EARLY_EPS")) c->early_eps = (float)std::atof(e1);
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
     if (const char* e11 = std::getenv("SPLAT_EARLY_SCAN8")) c->early_scan8 = std::min(8, std::max(1, std::atoi(e11)));

@@ -30,6 +30,8 @@ struct FrameConst {
     int n_tile_rows;       // slab: tile rows in this context
     int row_px0, row_px1;  // slab pixel rows [row_px0, row_px1)
     float early_eps;       // compositor early-out: transmittance below which a pixel stops needing layers; 0 = off
+    float close_width;     // the skipped layers' [lo,hi] bracket counts as closed when hi - lo <= this on every channel:
+                           // 0 = the exact frame, 2 = SPLAT_MODE_FAST (the walk continues from the bracket's middle: within 1 of exact)
     int early_min;         // shortest list the early-out is tried on
     int early_scan8;       // the transmittance scan gives up after this many eighths of the list
     int prio_len;          // lists >= prio_len / 2x / 4x run at wave priority 1 / 2 / 3

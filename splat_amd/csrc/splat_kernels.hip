@@ -1790,6 +1790,13 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     }
 
     // ---------------- phase B: exact compositing from the start layer ----------------
+    // The bracket is closed when hi - lo <= cw on every channel of every pixel.  cw = 0: lo == hi, the exact frame.
+    // cw = 2 (SPLAT_MODE_FAST): blend() is monotone in the state and never expands a difference of integer states
+    // (|blend(x) - blend(y)| <= |x - y|: the real difference is (1 - alpha) |x - y|, not an integer unless alpha = 0,
+    // where blend is the identity), so a state within 1 of the exact one stays within 1 to the nearest record.  The
+    // middle of a bracket of width <= 2 is such a state: the walk continues with it alone, every channel ends within
+    // 1 of the exact frame, and the walk may start where the transmittance is ~1e-3 instead of ~1e-6.
+    const float cw = fc.close_width;
     float R = (float)((old >> 16) & 0xffu), G = (float)((old >> 8) & 0xffu), B = (float)(old & 0xffu);
     float R2 = 255.0f, G2 = 255.0f, B2 = 255.0f;  // upper end of the bracket
     // blend(): src/pipelines.rs:147-167.  With alpha == 0 it is the identity on the 8-bit state
@@ -1869,7 +1876,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 #ifdef SPLAT_STAT_BRACKET
             if (BR) itA += k;
 #endif
-            if (BR && __builtin_amdgcn_ballot_w64(inside & ((R != R2) | (G != G2) | (B != B2))) == 0ull) return bsN;
+            if (BR && __builtin_amdgcn_ballot_w64(inside & ((R2 - R > cw) | (G2 - G > cw) | (B2 - B > cw))) == 0ull) return bsN;
         }
         return end;
     };
@@ -1883,9 +1890,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         // skipped layers [beg, start): bracket them
         R = G = B = 0.0f; R2 = G2 = B2 = 255.0f;
         const unsigned int pos = run(std::true_type{}, start);
-        const bool open = __builtin_amdgcn_ballot_w64(inside & ((R != R2) | (G != G2) | (B != B2))) != 0ull;
+        const bool open = __builtin_amdgcn_ballot_w64(inside & ((R2 - R > cw) | (G2 - G > cw) | (B2 - B > cw))) != 0ull;
         if (!open) {
-            if (pos < end) run(std::false_type{}, pos);    // closed: continue single-state
+            // closed: continue single-state from the middle of the bracket (lo itself when lo == hi, the exact mode)
+            R = truncf((R + R2) * 0.5f); G = truncf((G + G2) * 0.5f); B = truncf((B + B2) * 0.5f);
+            if (pos < end) run(std::false_type{}, pos);
             break;
         }
         // lo != hi somewhere at the end of the list: not proven.  Retry from twice the depth

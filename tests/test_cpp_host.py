@@ -141,6 +141,19 @@ def test_cli_streaming_loop_gives_the_same_last_frame(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_fast_mode_frame_is_within_one_count(tmp_path):
+    """--fast = PipelineBase::set_mode(SPLAT_MODE_FAST): every colour byte of the last frame within 1 of the default's"""
+    outs = []
+    for extra in ([], ["--fast"]):
+        out = str(tmp_path / ("f%d.ppm" % len(outs)))
+        r = subprocess.run([os.path.join(ROOT, "splat_amd", "splat_cli"), "--frames", "2", "--size", "320", "240", "--out", out] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.frombuffer(open(out, "rb").read()[len("P6\n320 240\n255\n"):], np.uint8).astype(np.int16))
+    assert outs[0].any() and np.abs(outs[0] - outs[1]).max() <= 1
+
+
+@pytest.mark.gpu
 def test_plain_c_client(tmp_path):
     """examples/render_c.c: a C99 program against include/splat_hip.h only"""
     out = str(tmp_path / "c.ppm")

@@ -95,3 +95,45 @@ def test_fullsize_c3_libm_exp_mode_is_bit_exact():
         assert np.array_equal(img, ref), image_diff(img, ref)
     finally:
         R.close()
+
+
+def test_fullsize_c3_fast_mode_is_within_one_count():
+    """C3 with SPLAT_MODE_FAST: every colour byte within 1 of the exact frame's (bench pose and from inside the cloud),
+    alpha bytes equal; with the libm exponential on top, within 1 of the ORACLE's on all 2 073 600 pixels."""
+    n, W, H, seed = WORKLOADS["C3"]
+    c = workload("C3")
+
+    def chans(a):
+        return np.stack([(a >> s) & 0xff for s in (24, 16, 8, 0)]).astype(np.int16)
+
+    cams = []
+    for pos, yaw, pitch in (POSES["bench"], POSES["inside"]):
+        cam = splat_amd.Camera(H, W, pos)
+        if yaw:
+            cam.update_yaw_angle(yaw)
+        if pitch:
+            cam.update_pitch_angle(pitch)
+        cam.update_camera_pose()
+        cams.append(cam)
+    exact = []
+    for cam in cams:
+        img = np.zeros((H, W), np.uint32)
+        c["R"].render(cam.to_c(0.01, 15), img)
+        exact.append(img)
+    for mode in (splat_amd.MODE_FAST, splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP):
+        R = splat_amd.Renderer(mode=mode)
+        try:
+            R.upload(c["g"])
+            for k, cam in enumerate(cams):
+                img = np.zeros((H, W), np.uint32)
+                R.render(cam.to_c(0.01, 15), img)
+                if mode == splat_amd.MODE_FAST:
+                    d = np.abs(chans(img) - chans(exact[k]))
+                    assert d[0].max() == 0 and d[1:].max() <= 1, (k, int(d.max()))
+                    assert (d.max(0) > 0).any()                 # the shortcut was taken
+                elif k == 0:
+                    ref, ost = O.render(c["sd"], oracle_camera(cam, 0.01), nthreads=os.cpu_count() or 8)
+                    d = np.abs(chans(img) - chans(ref))
+                    assert d.max() <= 1 and d[0].max() == 0, int(d.max())
+        finally:
+            R.close()

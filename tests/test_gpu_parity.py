@@ -724,3 +724,72 @@ def test_frame_with_fused_clear_equals_clear_then_render(R):
     R.render_frame_device(make_camera(h, w).to_c(0.01), d, sync=True)
     assert not R.device_download(d, h, w).any()
     R.device_free(d)
+
+
+def _channels(a):
+    return np.stack([(a >> s) & 0xff for s in (24, 16, 8, 0)]).astype(np.int32)
+
+
+def test_fast_mode_is_within_one_count_of_the_exact_frame():
+    """SPLAT_MODE_FAST closes the early-out's bracket at hi - lo <= 2 and continues from its middle; blend() never
+    expands a difference of states, so every R, G, B byte must end within 1 of the exact frame's and the alpha byte
+    must be the same -- on short lists, dense scenes (thousands of keys per tile), a non-zero
+    image to blend onto, both walks (one and two records per step), both bracket widths, and reckless start thresholds
+    that make most brackets fail and retry.  With the libm exponential on top the bound holds against the ORACLE."""
+    import os
+    cases = []
+    g1 = splat_amd.synthetic_scene(40000, 71)
+    cases.append((g1, make_camera(200, 296), 0.01))
+    g2 = splat_amd.synthetic_scene(120000, 72)
+    g2.positions[:, :3] *= 0.3                                   # dense: hundreds of layers per pixel
+    g2.sh[::101, 1] = np.inf
+    cases.append((g2, make_camera(192, 256, (0.0, 0.1, 3.0), yaw=0.3), 0.3))
+    keys = ("SPLAT_EARLY_EPS", "SPLAT_FAST_WIDTH", "SPLAT_PAIR_BLEND")
+    saved = {k: os.environ.get(k) for k in keys}
+
+    def frames(mode, env):
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        r = splat_amd.Renderer(mode=mode)
+        out = []
+        try:
+            for ci, (g, cam, lp) in enumerate(cases):
+                if not g.cov3d.any():
+                    g.compute_cov3d(r)
+                r.upload(g)
+                h, w = int(cam.h), int(cam.w)
+                init = np.random.default_rng(ci).integers(0, 2**32, (h, w), dtype=np.uint64).astype(np.uint32)
+                for start in (np.zeros((h, w), np.uint32), init):
+                    img = start.copy()
+                    st = r.render(cam.to_c(lp), img)
+                    out.append((img, st))
+        finally:
+            r.close()
+        return out
+
+    try:
+        exact = frames(splat_amd.MODE_EXACT, {})
+        assert exact[2][1].max_tile_len > 2048
+        differing = 0
+        for env in ({}, {"SPLAT_FAST_WIDTH": "1"}, {"SPLAT_PAIR_BLEND": "1"}, {"SPLAT_PAIR_BLEND": "0"},
+                    {"SPLAT_EARLY_EPS": "0.05"}, {"SPLAT_EARLY_EPS": "0.5", "SPLAT_PAIR_BLEND": "1"}, {"SPLAT_EARLY_EPS": "1e-5"}):
+            fast = frames(splat_amd.MODE_FAST, env)
+            for k, ((a, sa), (b, sb)) in enumerate(zip(exact, fast)):
+                d = np.abs(_channels(a) - _channels(b))
+                assert d[0].max() == 0, (env, k)                   # the alpha byte: the nearest covering record's, exact
+                assert d[1:].max() <= 1, (env, k, int(d[1:].max()))
+                assert sa.n_pairs == sb.n_pairs
+                differing += int((d.max(0) > 0).sum())
+        assert differing > 0                                        # the dense case does take the shortcut
+        # ... and against the oracle, with the exponential that makes the exact mode bit-identical to it
+        fast = frames(splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP, {})
+        for ci, (g, cam, lp) in enumerate(cases):
+            ref, ost = O.render(scene_dict(g), oracle_camera(cam, lp), nthreads=8)
+            d = np.abs(_channels(fast[2 * ci][0]) - _channels(ref))
+            assert d.max() <= 1 and d[0].max() == 0, (ci, int(d.max()))
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
