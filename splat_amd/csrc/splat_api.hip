@@ -139,6 +139,11 @@ struct splat_ctx {
     uint2* d_iters = nullptr;              // per compositor wave: (scan, blend) iterations of a frame rendered with stats
     unsigned int iters_alloc = 0;
     bool iters_valid = false;
+    // Who sorts the lists of more than 2048 keys: 0 = the sort launches (74 / 147 KB workgroups, starved beside a compositor
+    // in flight, but the cheaper code), 1 = the tile's own compositor workgroup (no launches, no starvation, more
+    // work), -1 = by the previous frame: the compositor when the AVERAGE list is longer than 2048 keys, i.e. when
+    // the sort launches would carry most of the frame's keys (C5: +7 %; C3 -5 %, C2 -13 % if forced).  SPLAT_SORT_IN_COMP.
+    int sort_in_comp = -1;
     float fast_width = 2.0f;               // SPLAT_MODE_FAST: bracket width that counts as closed (SPLAT_FAST_WIDTH: 1 or 2)
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
     int early_min = 768;                   // SPLAT_EARLY_MIN
@@ -327,6 +332,10 @@ uint64_t default_pair_capacity(const splat_ctx* c) {
 // through a second key buffer (buckets of that size only once a frame needed them); all buffers
 // of all slots must fit the byte budget, and list positions 32 bits.
 constexpr unsigned int BUCKET_MAX = 65536;
+bool compositor_sorts_long_lists(const splat_ctx* c, unsigned int m) {
+    if (c->fused_sort_max < 2048u) return false;
+    return c->sort_in_comp > 0 || (c->sort_in_comp < 0 && c->hint_pairs > 2048ull * (uint64_t)m);
+}
 unsigned int choose_bucket_cap(splat_ctx* c, unsigned int m, bool* need_keys2) {
     *need_keys2 = false;
     if (!c->use_buckets || c->cfg.pair_capacity || m == 0) return 0;
@@ -335,7 +344,7 @@ unsigned int choose_bucket_cap(splat_ctx* c, unsigned int m, bool* need_keys2) {
     while (cap < 16384 && cap < c->n) cap <<= 1;
     cap = std::max<uint64_t>(cap, c->bucket_min);
     if (cap > BUCKET_MAX) return 0;
-    *need_keys2 = cap > 16384;
+    *need_keys2 = cap > 16384 || compositor_sorts_long_lists(c, m);
     const uint64_t bytes = (uint64_t)m * cap * 8ull * (*need_keys2 ? 2u : 1u) * (uint64_t)slots_in_use(c);
     if (bytes > c->bucket_bytes || (uint64_t)m * cap >= 0xFFFFFFF0ull) return 0;
     return (unsigned int)cap;
@@ -412,7 +421,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     HIP_TRY(c, mark(0, bs));
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, d_st);
     HIP_TRY(c, mark(1, bs));
-    if (c->sort_hint && c->tight_grids) {
+    if (compositor_sorts_long_lists(c, m) && s.keys2 != nullptr) {
+        c->grid_big = m; c->grid_mid = m; c->grid_long = m;        // no sort launches to size: the scan has nothing to validate
+    } else if (c->sort_hint && c->tight_grids) {
         c->grid_big = c->hint_ge8192; c->grid_mid = c->hint_ge2048; c->grid_long = c->hint_ge16384;
     } else if (c->sort_hint) {
         // generous: an asynchronous frame that misses is lost (reported at the next sync), idle extra
@@ -433,7 +444,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
         launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, d_st);
     HIP_TRY(c, mark(3, ss));
-    launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
+    const bool comp_sorts = compositor_sorts_long_lists(c, m) && s.keys2 != nullptr;
+    if (!comp_sorts)
+        launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
     if (c->pipeline) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
@@ -457,7 +470,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const bool pair_walk = c->pair_mode >= 0 ? c->pair_mode != 0
                                              : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
     launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
-                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first);
+                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr);
     HIP_TRY(c, mark(6, c->stream));
     // the scan has already delivered this frame's status to h_status[r]; a statistics frame refreshes it with the late
     // counters (compositor retries, sort fallbacks)
@@ -641,6 +654,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (!c) return fail(nullptr, SPLAT_ERR_INVALID, "out of host memory");
     c->cfg = *cfg;
     if (cfg->mode & SPLAT_MODE_FAST) c->early_eps = 2e-3f;      // hi - lo <= 2 needs a contraction of ~1/128, not of ~1e-5
+    if (const char* es = std::getenv("SPLAT_SORT_IN_COMP")) c->sort_in_comp = std::atoi(es) < 0 ? -1 : (std::atoi(es) != 0 ? 1 : 0);
     if (const char* e0 = std::getenv("SPLAT_FAST_WIDTH")) c->fast_width = std::atoi(e0) <= 1 ? 1.0f : 2.0f;
     if (const char* e1 = std::getenv("SPLAT_EARLY_EPS")) c->early_eps = (float)std::atof(e1);
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);

@@ -100,7 +100,9 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       bool pair_walk = false /* the two-records-per-step flavour of the exact walk (same pixels) */,
                       bool libm_exp = false /* SPLAT_MODE_LIBM_EXP: expf as the host libm computes it */,
                       bool clear_first = false /* the frame starts from a cleared image: old pixels are not read, tiles
-                                                  nothing covers are zeroed (color.clear(0) of src/main.rs:73, fused) */);
+                                                  nothing covers are zeroed (color.clear(0) of src/main.rs:73, fused) */,
+                      unsigned long long* keys2 = nullptr /* != nullptr: no sort launch ran; lists of more than 2048 keys
+                                                             are sorted by their tile's workgroup through this buffer */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 // ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)

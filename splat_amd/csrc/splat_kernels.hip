@@ -1225,21 +1225,22 @@ __device__ __forceinline__ void radix_sort_depth_global(unsigned long long* src,
 template <int NT, int CAP>
 constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 256) * 4; }
 
-// Sort one list of n <= CAP keys (global, at g) through this workgroup's LDS (smem: sort_lds_bytes<NT, CAP>()),
-// in place.  Used by sort_tiles_kernel and, for short lists, by the compositor's workgroup itself.
-// idx_out != nullptr (the compositor's own sort): the sorted ORDER -- the keys' index halves -- is left in LDS at
-// idx_out (which may overlap the workspace) for the workgroup that is about to walk the list; the keys go back to
-// global memory only if write_back is set (statistics / debug frames read the lists from there).
+// Sort one list of n <= CAP keys (global, at gin) through this workgroup's LDS (smem: sort_lds_bytes<NT, CAP>(), of
+// which the last `reserve` bytes are left alone), into gout (which may be gin).  Used by sort_tiles_kernel and, for
+// the lists of its own tile, by the compositor's workgroup.
+// idx_out != nullptr (the compositor's own short list): the sorted ORDER -- the keys' index halves -- is left in LDS
+// at idx_out (which may overlap the workspace) for the workgroup that is about to walk the list; the keys go back
+// to global memory only if write_back is set (statistics / debug frames read the lists from there).
 template <int NT, int CAP>
-__device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned long long* __restrict__ g, unsigned int n,
-                                                 unsigned int radix_min, FrameStatus* __restrict__ status,
+__device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, const unsigned long long* gin, unsigned long long* gout,
+                                                 unsigned int n, unsigned int radix_min, FrameStatus* __restrict__ status,
                                                  const unsigned int* __restrict__ orig,
-                                                 unsigned int* idx_out = nullptr, bool write_back = true) {
+                                                 unsigned int* idx_out = nullptr, bool write_back = true, unsigned int reserve = 0u) {
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
     // histograms live right behind the keys in use: a list that leaves room gets 512 bins
     constexpr unsigned int NW = NT / 64;
     const unsigned int keys_bytes = ((n * 8u) + 15u) & ~15u;
-    const int lb = (keys_bytes + (NW + 1u) * 512u * 4u <= sort_lds_bytes<NT, CAP>()) ? 9 : 8;
+    const int lb = (keys_bytes + (NW + 1u) * 512u * 4u + reserve <= sort_lds_bytes<NT, CAP>()) ? 9 : 8;
     unsigned int* hist = reinterpret_cast<unsigned int*>(smem + keys_bytes);
     unsigned int* tot = hist + (NW << lb);
     unsigned int* dbase = tot;             // in place (see sort_lds_bytes)
@@ -1247,7 +1248,7 @@ __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned l
     for (unsigned int t0 = threadIdx.x; t0 < n; t0 += 8u * NT) {     // eight loads in flight per thread
         unsigned long long k[8];
 #pragma unroll
-        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; k[u] = (t < n) ? g[t] : 0ull; }
+        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; k[u] = (t < n) ? gin[t] : 0ull; }
 #pragma unroll
         for (unsigned int u = 0; u < 8; ++u) {
             const unsigned int t = t0 + u * NT;
@@ -1262,7 +1263,7 @@ __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned l
         sort_keys_lds<NT, CAP / NT>(s, hist, tot, dbase, n, threadIdx.x, status, pl, orig);
     }
     if (idx_out == nullptr) {
-        for (unsigned int t = threadIdx.x; t < n; t += NT) g[t] = s[t];
+        for (unsigned int t = threadIdx.x; t < n; t += NT) gout[t] = s[t];
         return;
     }
     constexpr unsigned int E = CAP / NT;
@@ -1271,11 +1272,151 @@ __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, unsigned l
     for (unsigned int u = 0; u < E; ++u) { const unsigned int t = threadIdx.x + u * NT; k[u] = (t < n) ? s[t] : 0ull; }
     if (write_back) {
 #pragma unroll
-        for (unsigned int u = 0; u < E; ++u) { const unsigned int t = threadIdx.x + u * NT; if (t < n) g[t] = k[u]; }
+        for (unsigned int u = 0; u < E; ++u) { const unsigned int t = threadIdx.x + u * NT; if (t < n) gout[t] = k[u]; }
     }
     __syncthreads();                       // every key has been read: the index area may overlap them
 #pragma unroll
     for (unsigned int u = 0; u < E; ++u) { const unsigned int t = threadIdx.x + u * NT; if (t < n) idx_out[t] = (unsigned int)k[u]; }
+}
+
+// A list of any length through global memory (L2-resident): LSD radix passes by depth from g to h and back (an even
+// number of them), then the tie fix-up and, for long runs of one depth, the exact network -- both on global memory.
+// Slow (one workgroup, every pass a round trip): the route of last resort.  smem: (NT / 64 + 1) * 256 words.
+template <int NT>
+__device__ __forceinline__ void sort_list_global(unsigned char* smem, unsigned long long* g, unsigned long long* h, unsigned int n,
+                                                 FrameStatus* __restrict__ status, const unsigned int* __restrict__ orig) {
+    unsigned int* hist = reinterpret_cast<unsigned int*>(smem);
+    unsigned int* tot = hist + (NT / 64) * 256;
+    unsigned int* dbase = tot;         // in place
+    unsigned int mn = 0xffffffffu, mx = 0u;
+    for (unsigned int t = threadIdx.x; t < n; t += NT) {
+        const unsigned int d = (unsigned int)(g[t] >> 32);
+        mn = min(mn, d); mx = max(mx, d);
+    }
+    const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, true, 8);
+    radix_sort_depth_global<NT>(g, h, hist, tot, dbase, n, threadIdx.x, pl);
+    bool sorted = false;
+    for (int it = 0; it < 6 && !sorted; ++it) {
+        bool swapped = false;
+#pragma unroll
+        for (unsigned int parity = 0; parity < 2; ++parity) {
+            for (unsigned int i = parity + 2u * threadIdx.x; i + 1 < n; i += 2u * NT) {
+                const unsigned long long x = g[i], y = g[i + 1];
+                if (key_gt(x, y, orig)) { g[i] = y; g[i + 1] = x; swapped = true; }
+            }
+            __syncthreads();
+        }
+        sorted = !__syncthreads_or(swapped ? 1 : 0);
+    }
+    if (!sorted) {
+        if (threadIdx.x == 0) atomicAdd(&status->n_sort_fallback, 1ull);
+        bitonic_sort(g, n, threadIdx.x, NT, orig);       // exact network, slow: only for long runs of equal depth
+    }
+}
+
+// A list LONGER than the 2048 keys a compositor workgroup sorts in its LDS, sorted by that same workgroup (NT = 256
+// threads, the compositor's sort_lds_bytes<NT, 2048>() of LDS) before it composites the tile -- so that no frame
+// waits for sort launches whose big workgroups (74 / 147 KB of LDS) only find room on a chip full of compositor
+// workgroups once those have drained:
+//   1  depth range of the list; 1024 bins of (depth - min) >> shift
+//   2  histogram (LDS atomics), exclusive scan -> every bin's place in the output
+//   3  scatter g -> h (the second key buffer): the list is now grouped by bin, bins in depth order
+//   4  consecutive bins are grouped into PARTS of fewer than 1792 keys (a part begins at the first bin whose place
+//      crosses a multiple of 1280; no bin holds more than 512 keys) and every part is sorted through LDS, h -> g,
+//      by the code that sorts the short lists.
+// A bin of more than 512 keys (hundreds of Gaussians at one depth), or more than 63 parts, goes the global route.
+// partition_long_list does 1-3 and returns the number of parts (their bounds in `pstart`, LDS, the last
+// LONG_SORT_RESERVE bytes of the workspace), or 0 if the list went the global route and is already sorted in g; the
+// caller runs the parts through sort_list_in_lds (the compositor has ONE inlined copy of that code for its short and
+// its long lists: a second one cost 24 VGPRs, two workgroups per CU).
+constexpr unsigned int LONG_SORT_RESERVE = 256u;
+template <int NT>
+__device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem, unsigned long long* g, unsigned long long* h,
+                                                            unsigned int n, FrameStatus* __restrict__ status,
+                                                            const unsigned int* __restrict__ orig) {
+    constexpr unsigned int NB = 1024u, PART_T = 1280u, BIN_MAX = 512u, PMAX = 63u, RESERVE = LONG_SORT_RESERVE;
+    static_assert(NT == 256, "four bins per thread");
+    unsigned int* bins = reinterpret_cast<unsigned int*>(smem);             // counts, then exclusive starts
+    unsigned int* cur = bins + NB;                                          // scatter cursors
+    unsigned int* misc = cur + NB;                                          // 0 min, 1 max, 2 largest bin, 3 last part, 4.. wave sums
+    unsigned int* pstart = reinterpret_cast<unsigned int*>(smem + sort_lds_bytes<NT, 2048>() - RESERVE);   // [64]
+    const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (unsigned int q = tid; q < NB; q += NT) { bins[q] = 0u; cur[q] = 0u; }
+    if (tid < 64u) pstart[tid] = 0xffffffffu;
+    if (tid == 0u) { misc[0] = 0xffffffffu; misc[1] = 0u; misc[2] = 0u; misc[3] = 0u; }
+    unsigned int mn = 0xffffffffu, mx = 0u;
+    for (unsigned int t = tid; t < n; t += NT) {
+        const unsigned int d = (unsigned int)(g[t] >> 32);
+        mn = min(mn, d); mx = max(mx, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (unsigned int)__shfl_xor((int)mn, o));
+        mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+    }
+    __syncthreads();
+    if (lane == 0u) { atomicMin(&misc[0], mn); atomicMax(&misc[1], mx); }
+    __syncthreads();
+    const unsigned int dmin = misc[0], range = misc[1] - dmin;
+    const unsigned int sh = range >= NB ? (unsigned int)(32 - __clz((int)range)) - 10u : 0u;      // (range >> sh) < 1024
+    for (unsigned int t = tid; t < n; t += NT) atomicAdd(&bins[((unsigned int)(g[t] >> 32) - dmin) >> sh], 1u);
+    __syncthreads();
+    {   // exclusive scan, four consecutive bins per thread
+        unsigned int c[4], sum = 0u, big = 0u;
+#pragma unroll
+        for (unsigned int j = 0; j < 4; ++j) { c[j] = bins[4u * tid + j]; sum += c[j]; big = max(big, c[j]); }
+        unsigned int v = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int u = (unsigned int)__shfl_up((int)v, o);
+            if ((int)lane >= o) v += u;
+        }
+        if (lane == 63u) misc[4u + wave] = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned int)__shfl_xor((int)big, o));
+        if (lane == 0u) atomicMax(&misc[2], big);
+        __syncthreads();
+        unsigned int ex = v - sum;
+        for (unsigned int w = 0; w < wave; ++w) ex += misc[4u + w];
+#pragma unroll
+        for (unsigned int j = 0; j < 4; ++j) {
+            bins[4u * tid + j] = ex;
+            if (c[j]) {                                 // a part begins at the first (non-empty) bin placed in its interval
+                const unsigned int p = ex / PART_T;
+                if (p <= PMAX) atomicMin(&pstart[p], ex);
+                atomicMax(&misc[3], p);
+            }
+            ex += c[j];
+        }
+    }
+    __syncthreads();
+    const unsigned int P = misc[3] + 1u;
+    if (misc[2] > BIN_MAX || P > PMAX) {
+        __syncthreads();                               // (misc is about to be overwritten)
+        sort_list_global<NT>(smem, g, h, n, status, orig);
+        return 0u;
+    }
+    for (unsigned int t = tid; t < n; t += NT) {
+        const unsigned long long key = g[t];
+        const unsigned int b = ((unsigned int)(key >> 32) - dmin) >> sh;
+        h[bins[b] + atomicAdd(&cur[b], 1u)] = key;
+    }
+    if (tid == 0u) pstart[P] = n;
+    __syncthreads();                                   // h is complete (this workgroup's own global writes) and bins / cur are free
+    return P;
+}
+
+// The whole of it, for the compositor's workgroup.
+__device__ __forceinline__ void sort_long_list(unsigned char* smem, unsigned long long* g, unsigned long long* h, unsigned int n,
+                                               unsigned int radix_min, FrameStatus* status, const unsigned int* orig) {
+    const unsigned int parts = partition_long_list<256>(smem, g, h, n, status, orig);
+    const unsigned int* const pstart = reinterpret_cast<const unsigned int*>(smem + sort_lds_bytes<256, 2048>() - LONG_SORT_RESERVE);
+    for (unsigned int p = 0; p < parts; ++p) {
+        const unsigned int a = (unsigned int)__builtin_amdgcn_readfirstlane((int)pstart[p]);
+        const unsigned int b = (unsigned int)__builtin_amdgcn_readfirstlane((int)pstart[p + 1u]);
+        sort_list_in_lds<256, 2048>(smem, h + a, g + a, b - a, radix_min, status, orig, nullptr, true, LONG_SORT_RESERVE);
+        __syncthreads();                               // the workspace is the next part's
+    }
 }
 
 // One workgroup per tile; a launch handles the lists with lo < n <= CAP (three size classes, so
@@ -1312,37 +1453,10 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
         return;
     }
     if (n <= (unsigned int)CAP) {
-        sort_list_in_lds<NT, CAP>(smem, keys + b, n, radix_min, status, orig);
+        sort_list_in_lds<NT, CAP>(smem, keys + b, keys + b, n, radix_min, status, orig);
     } else if (chunks) {
         // longer than chunks * CAP: radix passes over the L2-resident bucket, then the same tie fix-up
-        unsigned long long* g = keys + b;
-        unsigned int* hist = reinterpret_cast<unsigned int*>(smem + (size_t)CAP * 8);
-        unsigned int* tot = hist + (NT / 64) * 256;
-        unsigned int* dbase = tot;         // in place
-        unsigned int mn = 0xffffffffu, mx = 0u;
-        for (unsigned int t = threadIdx.x; t < n; t += NT) {
-            const unsigned int d = (unsigned int)(g[t] >> 32);
-            mn = min(mn, d); mx = max(mx, d);
-        }
-        const DigitPlan pl = block_digit_plan(mn, mx, tot, threadIdx.x, true, 8);
-        radix_sort_depth_global<NT>(g, keys2 + b, hist, tot, dbase, n, threadIdx.x, pl);
-        bool sorted = false;
-        for (int it = 0; it < 6 && !sorted; ++it) {
-            bool swapped = false;
-#pragma unroll
-            for (unsigned int parity = 0; parity < 2; ++parity) {
-                for (unsigned int i = parity + 2u * threadIdx.x; i + 1 < n; i += 2u * NT) {
-                    const unsigned long long x = g[i], y = g[i + 1];
-                    if (key_gt(x, y, orig)) { g[i] = y; g[i + 1] = x; swapped = true; }
-                }
-                __syncthreads();
-            }
-            sorted = !__syncthreads_or(swapped ? 1 : 0);
-        }
-        if (!sorted) {
-            if (threadIdx.x == 0) atomicAdd(&status->n_sort_fallback, 1ull);
-            bitonic_sort(g, n, threadIdx.x, NT, orig);       // exact network, slow: only for long runs of equal depth
-        }
+        sort_list_global<NT>(smem + (size_t)CAP * 8, keys + b, keys2 + b, n, status, orig);
     }
 }
 
@@ -1553,14 +1667,16 @@ __device__ __forceinline__ f2 blend_channel2(f2 k, float ia, f2 ac) {
 #endif
 // One tile (slot `item` of the longest-first tile order) by one workgroup; `smem` = sort_lds_bytes<256, 2048>() bytes.
 // PAIR: the exact walk takes two records per step with packed math (see the note above WaveLds).
-template <bool PAIR, bool LIBM>
+// LONG: lists of more than 2048 keys are sorted by this workgroup as well (sort_long_list), no sort launch needed.
+template <bool PAIR, bool LIBM, bool LONG>
 __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsigned long long* exptab, const unsigned int item, const FrameConst& fc,
                                                const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
                                                const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
                                                const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
                                                FrameStatus* __restrict__ status, unsigned int fused_sort_max,
                                                unsigned int radix_min, uint2* __restrict__ iters, unsigned int keep_keys,
-                                               const unsigned int* __restrict__ orig, const unsigned int clear_first) {
+                                               const unsigned int* __restrict__ orig, const unsigned int clear_first,
+                                               unsigned long long* __restrict__ keys2) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -1586,9 +1702,23 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // the waves' record batches, and the walks below read their indices from there instead of from the bucket.
     unsigned int* const lds_idx = reinterpret_cast<unsigned int*>(smem + sizeof(WaveLds) * 4);
     static_assert(sizeof(WaveLds) * 4 + 2048 * 4 <= sort_lds_bytes<256, 2048>(), "the order fits behind the batches");
+    // ... and behind the order, 32 x 8 B per wave: which records of a 64-record batch the transmittance scan staged
+    // (see `stage`), so that the exact walk over the same batches does not test them again.
+    static_assert(sizeof(WaveLds) * 4 + 2048 * 4 + 4 * 32 * 8 <= sort_lds_bytes<256, 2048>(), "the batch masks fit too");
+    unsigned long long* const wmask = reinterpret_cast<unsigned long long*>(smem + sizeof(WaveLds) * 4 + 2048 * 4) + (tid >> 6) * 32u;
     const bool own_order = end - beg >= 2u && end - beg <= fused_sort_max;
+    // A list of more than 2048 keys, when no sort launch ran in front of this kernel (keys2 != nullptr says so), is
+    // ordered here too: partitioned by depth into parts of fewer than 1792 keys through the second key buffer
+    // (partition_long_list), every part sorted through LDS back into the bucket, and then read from memory like a
+    // list a sort launch had left.
+    if constexpr (LONG) {
+        if (end - beg > 2048u) {
+            sort_long_list(smem, keys + beg, keys2 + beg, end - beg, radix_min, status, orig);
+            __syncthreads();
+        }
+    }
     if (own_order) {
-        sort_list_in_lds<256, 2048>(smem, keys + beg, end - beg, radix_min, status, orig, lds_idx, keep_keys != 0u);
+        sort_list_in_lds<256, 2048>(smem, keys + beg, keys + beg, end - beg, radix_min, status, orig, lds_idx, keep_keys != 0u);
         __syncthreads();          // the order is in LDS, the rest of the workspace is free for the batches
     }
     const unsigned int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
@@ -1658,16 +1788,23 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // scan_layout: the phase-A walk only estimates transmittance, so its records are staged in a
     // form that makes the estimate cheap -- the conic pre-multiplied by -log2(e)/2 and log2(opacity),
     // so that alpha ~ exp2(a' dx^2 + b' dx dy + c' dy^2 + l2o) is six VALU and one v_exp.
+    // Batches are aligned to the END of the list (batch k = records [end - 64 (k + 1), end - 64 k), clipped at beg) in
+    // every pass, so the verdicts of one pass serve the next: the scan saves its ballot (save_k), the exact walk
+    // takes it (reuse_k; reuse_shift = records of the batch below the walk's start) instead of running the two
+    // coverage tests and the contribution bound again -- 60 of the 76 instructions of a staging.
     auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base, bool only_contributing, bool scan_layout = false,
-                     bool pair_layout = false) -> unsigned int {
+                     bool pair_layout = false, int reuse_k = -1, unsigned int reuse_shift = 0u, int save_k = -1) -> unsigned int {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier LDS reads of this wave are done
         __builtin_amdgcn_wave_barrier();
         bool ov = false;
-        if (lane < cnt) {
+        if (reuse_k >= 0) {
+            ov = (((wmask[reuse_k] >> reuse_shift) >> lane) & 1ull) != 0ull;
+        } else if (lane < cnt) {
             ov = any_sample_covered(r.a.x, r.a.z, xlo, xhi, off) && any_sample_covered(r.a.y, r.a.w, ylo, yhi, off);
             if (ov && only_contributing) ov = may_contribute(r);
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(ov);
+        if (save_k >= 0 && lane == 0u) wmask[save_k] = m;
         if (ov) {
             const unsigned int slot = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
             if (pair_layout) {
@@ -1751,6 +1888,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     }
     // ---------------- phase A: where must the exact walk start? ----------------
     unsigned int ws = beg;                       // this wave's start position (uniform)
+    unsigned int nA = 0;                         // batches (from the end of the list) whose staging verdicts the scan saved
     if (fc.early_eps > 0.0f && end - beg >= (unsigned int)fc.early_min) {
         float T = 1.0f;
         unsigned int sp = inside ? beg : 0xffffffffu;    // per lane: first layer the lane needs
@@ -1762,7 +1900,8 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         fetch(bsN, cntN, r);
         while (true) {
             const unsigned int bs = bsN, cnt = cntN;
-            const unsigned int k = stage(r, cnt, bs, true, true);
+            const unsigned int k = stage(r, cnt, bs, true, true, false, -1, 0u, nA < 32u ? (int)nA : -1);
+            nA += nA < 32u ? 1u : 0u;
             if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }   // prefetch farther batch
             for (unsigned int j = k; j-- > 0;) {                  // nearest first
                 const float4 a = L.a[j], b = L.b[j];
@@ -1858,12 +1997,16 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     auto run = [&](auto BRt, unsigned int start) -> unsigned int {
         constexpr bool BR = decltype(BRt)::value;
         Rec r;
-        unsigned int bsN = start, cntN = min(64u, end - start);
+        // the first batch ends where the scan's batch that contains `start` ends; the others are the scan's batches
+        unsigned int kb = start < end ? (end - 1u - start) >> 6 : 0u;
+        unsigned int bsN = start, cntN = start < end ? (end - (kb << 6)) - start : 0u;
         if (cntN) fetch(bsN, cntN, r);
         while (cntN) {
             const unsigned int bs = bsN, cnt = cntN;
-            const unsigned int k = stage(r, cnt, bs, true, false, PAIR);
-            bsN = bs + cnt; cntN = min(64u, end - bsN);
+            const bool reuse = kb < nA;
+            const unsigned int abase = (end - beg >= ((kb + 1u) << 6)) ? end - ((kb + 1u) << 6) : beg;   // where the scan's batch began
+            const unsigned int k = stage(r, cnt, bs, true, false, PAIR, reuse ? (int)kb : -1, bs - abase);
+            bsN = bs + cnt; cntN = min(64u, end - bsN); kb -= cntN ? 1u : 0u;
             if (cntN) fetch(bsN, cntN, r);                  // prefetch the next (nearer) batch
             if constexpr (PAIR) {
                 const float4* P4 = reinterpret_cast<const float4*>(&L);
@@ -1914,8 +2057,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 // The launch: one workgroup per tile, slot blockIdx.x of the longest-first order.  (A persistent grid pulling
 // slots from a ticket counter, and the order composited as consecutive chunk launches, were both measured as
 // ways to cap the compositor's residency beside the next frame's K1: both slower -- DESIGN.md section 3.)
-template <bool PAIR, bool LIBM>
-__global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+// LONG = true: seven waves per SIMD = seven workgroups per CU, which is also what the 21.5 KB of LDS allow: at most 72
+// VGPRs.  The walks need 64; the long-list sort in front of them would take 88, and under this bound spills nine
+// registers around its loop over the parts instead -- outside every hot loop (checked in the ISA).
+template <bool PAIR, bool LIBM, bool LONG>
+__global__ __launch_bounds__(256, LONG ? 7 : SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned int* __restrict__ lens,
                                                               unsigned long long* __restrict__ keys,
@@ -1923,7 +2069,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
                                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
                                                               unsigned int radix_min, uint2* __restrict__ iters,
                                                               unsigned int keep_keys, const unsigned int* __restrict__ orig,
-                                                              unsigned int clear_first) {
+                                                              unsigned int clear_first, unsigned long long* __restrict__ keys2) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
@@ -1932,7 +2078,7 @@ __global__ __launch_bounds__(256, SPLAT_COMP_WAVES) void composite_exact_kernel(
         if (threadIdx.x < 32) exptab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
         __syncthreads();
     }
-    composite_tile<PAIR, LIBM>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig, clear_first);
+    composite_tile<PAIR, LIBM, LONG>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig, clear_first, keys2);
 }
 
 // ---------------------------------------------------------------------------
@@ -2038,7 +2184,7 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
-                      bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first) {
+                      bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2) {
     if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
@@ -2046,15 +2192,19 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
     static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
     static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
-    if (libm_exp)
-        hipLaunchKernelGGL((composite_exact_kernel<false, true>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs,
-                           argb, status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u);
-    else if (pair_walk)
-        hipLaunchKernelGGL((composite_exact_kernel<true, false>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
-                           status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u);
-    else
-        hipLaunchKernelGGL((composite_exact_kernel<false, false>), dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb,
-                           status, fused_sort_max, sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
+                           sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u, keys2);
+    };
+    if (keys2 != nullptr) {
+        if (libm_exp) go(composite_exact_kernel<false, true, true>);
+        else if (pair_walk) go(composite_exact_kernel<true, false, true>);
+        else go(composite_exact_kernel<false, false, true>);
+    } else {
+        if (libm_exp) go(composite_exact_kernel<false, true, false>);
+        else if (pair_walk) go(composite_exact_kernel<true, false, false>);
+        else go(composite_exact_kernel<false, false, false>);
+    }
 }
 
 }  // namespace splat

@@ -793,3 +793,44 @@ def test_fast_mode_is_within_one_count_of_the_exact_frame():
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def test_compositor_sorts_long_lists_itself():
+    """SPLAT_SORT_IN_COMP=1 (chosen automatically when the average list is longer than 2048 keys): lists of more than
+    2048 keys are ordered by their tile's compositor workgroup -- depth partition through the second key buffer, parts
+    sorted through LDS -- instead of by sort launches.  Same lists, same frame: lists of 2049..16384 keys, longer ones,
+    more than 63 parts (the global route), thousands of Gaussians at ONE depth (a bin of more than 512 keys: the global
+    route and its tie fix-up), and one-pass as well as two-pass binning."""
+    import os
+    saved = {k: os.environ.get(k) for k in ("SPLAT_SORT_IN_COMP", "SPLAT_BUCKETS")}
+    try:
+        for buckets in ("1", "0"):
+            os.environ["SPLAT_SORT_IN_COMP"] = "1"
+            os.environ["SPLAT_BUCKETS"] = buckets
+            r = splat_amd.Renderer()
+            try:
+                for n, squeeze, second in ((30000, 0.05, 9000), (60000, 0.02, 8000), (130000, 0.02, 10000)):
+                    g = splat_amd.synthetic_scene(n, 19)
+                    g.positions[:, :3] *= squeeze
+                    g.positions[:second, 0] += 0.35
+                    g.compute_cov3d(r)
+                    cam = make_camera(96, 96)
+                    img, st, ref, ost = render_both(r, g, cam, 0.01)
+                    assert st.max_tile_len > 2048 and st.n_pairs == ost.n_tile_pairs
+                    assert image_diff(img, ref)[0] <= TOL_LSB, (buckets, n)
+                g = splat_amd.synthetic_scene(6000, 31)
+                g.positions[:, 2] = np.float32(0.25)               # one depth for everyone
+                g.positions[:4500, :2] *= 0.02
+                g.compute_cov3d(r)
+                img, st, ref, ost = render_both(r, g, make_camera(128, 128), 0.01)
+                assert st.max_tile_len > 2048 and image_diff(img, ref)[0] <= TOL_LSB
+                off, order = r.tile_lists(64, st.n_pairs)
+                for t in range(64):
+                    assert np.all(np.diff(order[off[t]:off[t + 1]].astype(np.int64)) > 0), t
+            finally:
+                r.close()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
