@@ -142,7 +142,8 @@ struct splat_ctx {
     // Who sorts the lists of more than 2048 keys: 0 = the sort launches (74 / 147 KB workgroups, starved beside a compositor
     // in flight, but the cheaper code), 1 = the tile's own compositor workgroup (no launches, no starvation, more
     // work), -1 = by the previous frame: the compositor when the AVERAGE list is longer than 2048 keys, i.e. when
-    // the sort launches would carry most of the frame's keys (C5: +7 %; C3 -5 %, C2 -13 % if forced).  SPLAT_SORT_IN_COMP.
+    // the sort launches would carry most of the frame's keys, and the frame is throughput-bound (C5: +7 %; C3 -5 %, C2 -13 %
+    // if forced).  SPLAT_SORT_IN_COMP.
     int sort_in_comp = -1;
     float fast_width = 2.0f;               // SPLAT_MODE_FAST: bracket width that counts as closed (SPLAT_FAST_WIDTH: 1 or 2)
     float early_eps = 1e-6f;               // SPLAT_EARLY_EPS overrides (0 disables the early-out)
@@ -334,7 +335,12 @@ uint64_t default_pair_capacity(const splat_ctx* c) {
 constexpr unsigned int BUCKET_MAX = 65536;
 bool compositor_sorts_long_lists(const splat_ctx* c, unsigned int m) {
     if (c->fused_sort_max < 2048u) return false;
-    return c->sort_in_comp > 0 || (c->sort_in_comp < 0 && c->hint_pairs > 2048ull * (uint64_t)m);
+    // auto: the average list is longer than 2048 keys (the sort launches would carry most of the frame) AND the frame is
+    // not the chain of its longest list (more than 1500 pairs per key of that list: C5 3100; the four centre tile rows
+    // of C3 as a slab: average 2300 keys but 100 pairs per key of the 10 892-key list, whose sort must not move in
+    // front of its walk -- 0.114 -> 0.225 ms)
+    return c->sort_in_comp > 0 ||
+           (c->sort_in_comp < 0 && c->hint_pairs > 2048ull * (uint64_t)m && c->hint_pairs > 1500ull * (uint64_t)c->hint_maxlen);
 }
 unsigned int choose_bucket_cap(splat_ctx* c, unsigned int m, bool* need_keys2) {
     *need_keys2 = false;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Predict multi-GPU strong scaling on ONE GPU: render every slab of a k-way partition separately and
 take the slowest slab's GPU time (+ nothing for the gather, which is ~20-40 us over xGMI).
-Usage: python tools/slab_scaling.py [workload]"""
+Usage: python tools/slab_scaling.py [workload] [fast]   (fast: SPLAT_MODE_FAST, every colour byte within 1 of the exact frame)"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -12,7 +12,7 @@ from bench import WORKLOADS
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 n, W, H, seed = WORKLOADS[wl]
-R = splat_amd.Renderer()
+R = splat_amd.Renderer(mode=splat_amd.MODE_FAST if (len(sys.argv) > 2 and sys.argv[2] == "fast") else 0)
 g = splat_amd.synthetic_scene(n, seed); g.compute_cov3d(R)
 cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0)); cam.update_camera_pose()
 cam_c = cam.to_c(0.01, 15)
