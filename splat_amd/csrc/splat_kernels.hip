@@ -553,16 +553,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     // throughput-bound waves every one of its instructions queued behind theirs.  One priority step above the
     // compositor's default: K1 0.38 -> 0.32 ms inside the pipeline, +4 % frames/s on C3.
     __builtin_amdgcn_s_setprio(1);
-#ifdef SPLAT_K1_EARLY
-    float4 early[4];
-    {
-        const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i0 < n) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) early[p] = planes[(uint64_t)p * n + i0];
-        }
-    }
-#endif
     if constexpr (BUCKET) {
         // Block culling rides on the barrier the table reset needs anyway: wave 0 alone runs the bounds test (a
         // few hundred instructions that used to be issued by all four waves) while the others clear the table.
@@ -590,11 +580,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         // only fetched for Gaussians that reach this context's slab
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-#ifdef SPLAT_K1_EARLY
-            float4 v = early[p];
-#else
             float4 v = planes[(uint64_t)p * n + i];
-#endif
             F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
         const float px = F[0], py = F[1], pz = F[2];
