@@ -266,6 +266,17 @@ def main():
                     R.render_frame_device(orbit[k % 36], image.data_ptr())
                 torch.cuda.synchronize()
                 legs["orbit_36_poses_device_resident_fps"] = K / (time.perf_counter() - t1)
+            # (1b) a short timed region (the driver's --steps 20) is mostly pipeline fill and a GPU coming out of idle:
+            # the same step, 400 frames back to back, for the steady state
+            if args.steps < 100:
+                for k in range(10):
+                    R.render_frame_device(cam_c, image.data_ptr())
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for k in range(400):
+                    R.render_frame_device(cam_c, image.data_ptr())
+                torch.cuda.synchronize()
+                legs["steady_state_400_frames_device_resident_fps"] = 400 / (time.perf_counter() - t1)
             # (2) host-visible: the literal render_to_buffer -- host image in and out, synchronous (src/main.rs:71-75)
             himg = np.zeros((H, W), np.uint32)
             R.render(cam_c, himg)
