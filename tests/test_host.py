@@ -249,3 +249,29 @@ def test_libm_exp_restatement_constants_and_algorithm():
     y = ((zz * (r * r) + (c2 * r + 1.0)) * s).astype(np.float32)
     ref = np.array([libm.expf(float(v)) for v in xs], np.float32)
     assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), int((y != ref).sum())
+
+
+def test_blend_is_monotone_and_never_expands_a_difference_of_states():
+    """The lemma behind both of the compositor's early-outs, checked on the oracle's blend() (the restatement of
+    src/pipelines.rs:147-167): for a fixed fragment, blend as a map of the 8-bit state is monotone non-decreasing
+    (the [lo, hi] bracket of the exact mode) and maps neighbouring states to equal or neighbouring states
+    (SPLAT_MODE_FAST: a state within 1 of the exact one stays within 1).  All 256 states, every alpha fragment()
+    can return (0, and [1/255, 0.99]) sampled densely at both ends, colours from tame to absurd."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    alphas = np.concatenate([[0.0, 1.0 / 255.0, 0.99], np.nextafter(np.float32(1.0 / 255.0), np.float32(1), dtype=np.float32)[None],
+                             rng.uniform(1.0 / 255.0, 0.99, 150), 1.0 / 255.0 + rng.uniform(0, 1e-3, 40), 0.99 - rng.uniform(0, 1e-3, 40)]).astype(np.float32)
+    colours = np.concatenate([[0.0, 1.0, 0.5, -0.25, 1.75, 1e30, -1e30, np.inf, -np.inf, np.nan], rng.uniform(-0.2, 1.2, 12)]).astype(np.float32)
+    states = np.arange(256, dtype=np.uint32)
+    packed = (states << 16) | (states << 8) | states
+    for a in alphas:
+        for c in colours[rng.permutation(len(colours))[:6]]:
+            with np.errstate(invalid="ignore", over="ignore"):
+                frag = np.array([a * c, a * np.float32(0.3), a * np.float32(c * 0.5), a], np.float32)   # fragment(): colour * alpha, alpha
+            out = np.array([O.blend(int(p), frag) for p in packed], dtype=np.uint32)
+            for sh in (16, 8, 0):
+                ch = ((out >> sh) & 0xff).astype(np.int32)
+                d = np.diff(ch)
+                assert d.min() >= 0 and d.max() <= 1, (float(a), float(c), sh, int(d.min()), int(d.max()))
+            if a == 0.0:
+                assert np.array_equal(out & 0xffffff, packed & 0xffffff)      # a rejected fragment is the identity on RGB
