@@ -285,17 +285,27 @@ def main():
                 himg[:] = 0
                 R.render(cam_c, himg)
             legs["host_visible_splat_render_fps"] = 20 / (time.perf_counter() - t1)
-            # (3) host-visible: the viewer loop (clear, render, present) with two pinned frames in flight
-            bufs = [R.host_image(H, W), R.host_image(H, W)]
-            R.render_stream(cam_c, bufs[0]); R.stream_wait(bufs[0])
-            t1 = time.perf_counter()
-            for k in range(K):
-                R.render_stream(cam_c, bufs[k & 1])
-                if k:
-                    R.stream_wait(bufs[(k - 1) & 1])
-            R.stream_wait(bufs[(K - 1) & 1])
-            legs["host_visible_splat_render_stream_fps"] = K / (time.perf_counter() - t1)
-            legs["host_visible_frames_equal_device_frame"] = bool(np.array_equal(bufs[(K - 1) & 1], himg))
+            # (3) host-visible: the viewer loop (clear, render, present) with pinned frames in flight: frame k is presented
+            # (waited for) while frames k+1.. render and cross PCIe.  Two buffers are what a double-buffered window has;
+            # four keep the device's frame pipeline (two binning chains + a compositor) full
+            for nb in (2, 4):
+                bufs = [R.host_image(H, W) for _ in range(nb)]
+                for k in range(80):                              # the first few dozen frames into fresh pinned buffers run at a
+                    R.render_stream(cam_c, bufs[k % nb])         # third of the rate (one-time mapping of the copy path): warm-up
+                    if k >= nb - 1:
+                        R.stream_wait(bufs[(k - (nb - 1)) % nb])
+                for k in range(80 - (nb - 1), 80):
+                    R.stream_wait(bufs[k % nb])
+                t1 = time.perf_counter()
+                for k in range(K):
+                    R.render_stream(cam_c, bufs[k % nb])
+                    if k >= nb - 1:
+                        R.stream_wait(bufs[(k - (nb - 1)) % nb])
+                for k in range(max(0, K - (nb - 1)), K):
+                    R.stream_wait(bufs[k % nb])
+                legs["host_visible_splat_render_stream_fps" if nb == 2 else "host_visible_splat_render_stream_4_in_flight_fps"] = K / (time.perf_counter() - t1)
+                last_buf = bufs[(K - 1) % nb]
+            legs["host_visible_frames_equal_device_frame"] = bool(np.array_equal(last_buf, himg))
             legs["what"] = ("host-visible = pixels delivered to host memory (PCIe inclusive); never `value`.  %d frames each "
                             "(splat_render: 20)" % K)
             R.timing(reset=True)

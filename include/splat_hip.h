@@ -126,7 +126,8 @@ int splat_tile_row_loads(splat_ctx* ctx, const splat_camera* cam, uint64_t* row_
 /* Viewer-loop variant (src/main.rs:69-78: clear, render, present): the frame is rendered onto a
  * CLEARED device image -- what the loop's `color.clear(0)` + `render_to_buffer` amount to -- and
  * copied to `argb_out` (host, w*h u32) asynchronously; the call returns once the work is queued.
- * Frames alternate between two device images, so frame N+1 renders while frame N crosses PCIe.
+ * Frames rotate through four device images, so up to four may be in flight: frames N+1.. render while frame N
+ * crosses PCIe (two in flight is a double-buffered window; three or more keep the device's frame pipeline full).
  * `argb_out` is complete after splat_stream_wait(ctx, argb_out) (or splat_sync); give each frame
  * in flight its own buffer, ideally pinned (splat_host_alloc) -- a pageable one works but the
  * copy then blocks the calling thread.  A streamed frame that outgrew its storage on the device (tile

@@ -98,15 +98,16 @@ struct splat_ctx {
     uint32_t* d_img = nullptr;
     size_t img_cap = 0;
     // streaming path (splat_render_stream): two device images, a copy stream, per-image events
-    uint32_t* s_img[2] = {nullptr, nullptr};
+    static constexpr int S_IMGS = 4;       // streamed frames in flight (device images): the pipeline wants three (two chains + a compositor)
+    uint32_t* s_img[S_IMGS] = {};
     size_t s_cap = 0;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t s_rendered[2] = {nullptr, nullptr}, s_copied[2] = {nullptr, nullptr};
-    const uint32_t* s_dst[2] = {nullptr, nullptr};
-    bool s_used[2] = {false, false};
+    hipEvent_t s_rendered[S_IMGS] = {}, s_copied[S_IMGS] = {};
+    const uint32_t* s_dst[S_IMGS] = {};
+    bool s_used[S_IMGS] = {};
     uint64_t s_idx = 0;
-    int s_ring[2] = {-1, -1};              // event-ring entry of the frame each streaming image holds
-    splat_camera s_cam[2] = {};            // ... and its camera (a frame skipped on the device is redone by splat_stream_wait)
+    int s_ring[S_IMGS] = {-1, -1, -1, -1}; // event-ring entry of the frame each streaming image holds
+    splat_camera s_cam[S_IMGS] = {};       // ... and its camera (a frame skipped on the device is redone by splat_stream_wait)
     // slab
     int slab0 = 0, slab1 = -1;
     // timing
@@ -728,7 +729,7 @@ void splat_destroy(splat_ctx* c) {
         if (s.ev_free) (void)hipEventDestroy(s.ev_free);
     }
     dfree(c->d_img); dfree(c->d_iters);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < splat_ctx::S_IMGS; ++k) {
         dfree(c->s_img[k]);
         if (c->s_rendered[k]) (void)hipEventDestroy(c->s_rendered[k]);
         if (c->s_copied[k]) (void)hipEventDestroy(c->s_copied[k]);
@@ -984,7 +985,7 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
     const size_t bytes = (size_t)fc.W * fc.H * 4;
     if (!c->copy_stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < splat_ctx::S_IMGS; ++k) {
             HIP_TRY(c, hipEventCreateWithFlags(&c->s_rendered[k], hipEventDisableTiming));
             HIP_TRY(c, hipEventCreateWithFlags(&c->s_copied[k], hipEventDisableTiming));
         }
@@ -992,13 +993,13 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
     if (bytes > c->s_cap) {
         rc = sync_all(c);
         if (rc != SPLAT_OK) return rc;
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < splat_ctx::S_IMGS; ++k) {
             dfree(c->s_img[k]); c->s_used[k] = false;
             HIP_TRY(c, hipMalloc(&c->s_img[k], bytes));
         }
         c->s_cap = bytes;
     }
-    const int k = (int)(c->s_idx++ & 1u);
+    const int k = (int)(c->s_idx++ % (uint64_t)splat_ctx::S_IMGS);
     // the image must not be cleared while its previous frame is still crossing PCIe
     if (c->s_used[k]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->s_copied[k], 0));
     rc = splat_render_frame_device(c, cam, c->s_img[k], 0, nullptr);      // clear + render (the clear is fused into the compositor)
@@ -1016,9 +1017,8 @@ int splat_stream_wait(splat_ctx* c, const uint32_t* argb_out) {
     if (!c) return SPLAT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     // the most recent frame that went to this buffer (the other image may hold an older one)
-    const int newest = (int)((c->s_idx + 1) & 1u);
-    for (int j = 0; j < 2; ++j) {
-        const int k = j == 0 ? newest : newest ^ 1;
+    for (int j = 1; j <= splat_ctx::S_IMGS; ++j) {
+        const int k = (int)((c->s_idx + (uint64_t)(splat_ctx::S_IMGS - j)) % (uint64_t)splat_ctx::S_IMGS);    // newest first
         if (c->s_used[k] && c->s_dst[k] == argb_out) {
             HIP_TRY(c, hipEventSynchronize(c->s_copied[k]));
             // The frame's status arrived before its pixels left.  If it was skipped on the device (it outgrew
