@@ -140,6 +140,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the host-visible and orbit legs")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--scene", default=None,
+                    help="an INRIA 3DGS .ply (e.g. the real 'truck' / 'bicycle' / plush_sledge scene: none is in the repo, "
+                         "src/main.rs:21 loads one): rendered at --workload's resolution and camera instead of the synthetic "
+                         "stand-in of the same size; load_from_ply's activations and recentring included (src/gaussians.rs:375-405)")
     args = ap.parse_args()
 
     import torch
@@ -177,7 +181,13 @@ def main():
     # bubble); a short timed region needs them on every frame to have launches to average over
     os.environ.setdefault("SPLAT_TIMING_EVERY", "8" if args.steps >= 64 else "1")
     R = splat_amd.Renderer(device=local)
-    g = splat_amd.synthetic_scene(n, seed)
+    if args.scene:
+        g = splat_amd.load_from_ply(args.scene)          # the C++ host mirror's loader (mmap + direct decode)
+        n = len(g.opacities)
+        data_kind, scene_name = "ply:" + os.path.basename(args.scene), "%s (%d Gaussians)" % (os.path.basename(args.scene), n)
+    else:
+        g = splat_amd.synthetic_scene(n, seed)
+        data_kind, scene_name = "synthetic", "synthetic seed %d" % seed
     g.compute_cov3d(R)                                   # K0 on the GPU (load-time, not timed)
     cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0))        # src/main.rs:13,29
     cam.update_camera_pose()
@@ -371,9 +381,9 @@ def main():
             "metric": "frames_per_sec", "value": args.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_frames_before_warmup": SETTLE_FRAMES,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d Gaussians @%dx%d, synthetic seed %d, Camera(0,0,5), Pipeline01 "
-                                   "(lowpass 0.01, sh_dim 15), exact mode" % (args.workload, n, W, H, seed),
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": data_kind,
+            "config": {"workload": "%s: %d Gaussians @%dx%d, %s, Camera(0,0,5), Pipeline01 "
+                                   "(lowpass 0.01, sh_dim 15), exact mode" % (args.workload, n, W, H, scene_name),
                        "camera": "36-pose yaw orbit, 10 degrees per frame" if args.orbit else "fixed pose",
                        "partition": ("one rank per GPU, load-balanced tile-row slabs %s, one gather of slab rows per frame: %s"
                                      % ([b - a for a, b in slabs],
