@@ -47,7 +47,7 @@ extern "C" {
                                     mode ([lo,hi] from 0 and from 255, blend() is monotone), but the bracket counts as
                                     closed at hi - lo <= 1, which half the optical depth achieves.  Every R, G, B byte
                                     is within 1 of the SPLAT_MODE_EXACT frame's (the alpha byte is the same); about a
-                                    third fewer compositor instructions.  The north_star's "front-to-back ... early-out
+                                    third less compositor time.  The north_star's "front-to-back ... early-out
                                     on saturated alpha", with the error bound proven instead of hoped for.        */
 
 typedef struct splat_ctx splat_ctx;

@@ -660,7 +660,10 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     splat_ctx* c = new (std::nothrow) splat_ctx();
     if (!c) return fail(nullptr, SPLAT_ERR_INVALID, "out of host memory");
     c->cfg = *cfg;
-    if (cfg->mode & SPLAT_MODE_FAST) c->early_eps = 2e-3f;      // hi - lo <= 2 needs a contraction of ~1/128, not of ~1e-5
+    if (cfg->mode & SPLAT_MODE_FAST) {
+        c->early_eps = 2e-3f;      // hi - lo <= 2 needs a contraction of ~1/128, not of ~1e-5 ...
+        c->early_min = 384;        // ... which lists of a few hundred keys reach too (C3: 2960 -> 3125 frames/s; exact mode: 768 is best)
+    }
     if (const char* es = std::getenv("SPLAT_SORT_IN_COMP")) c->sort_in_comp = std::atoi(es) < 0 ? -1 : (std::atoi(es) != 0 ? 1 : 0);
     if (const char* e0 = std::getenv("SPLAT_FAST_WIDTH")) c->fast_width = std::atoi(e0) <= 1 ? 1.0f : 2.0f;
     if (const char* e1 = std::getenv("SPLAT_EARLY_EPS")) c->early_eps = (float)std::atof(e1);
