@@ -1,6 +1,7 @@
 // splat_cli -- the reference's main loop (src/main.rs:41-80) without the window: load a PLY (or the
 // naive scene), orbit the camera in 10-degree yaw steps, time "pose update + clear + render" exactly
 // like src/main.rs:71-77 and print it; optionally write the last frame as a PPM.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,14 +14,16 @@ int main(int argc, char** argv) {
     const char* ply = nullptr; const char* out = nullptr;
     int W = 800, H = 600, frames = 36;
     bool streaming = false, fast = false;
+    int in_flight = 2;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--ply") && i + 1 < argc) ply = argv[++i];
         else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
         else if (!std::strcmp(argv[i], "--size") && i + 2 < argc) { W = std::atoi(argv[++i]); H = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--stream")) streaming = true;
+        else if (!std::strcmp(argv[i], "--in-flight") && i + 1 < argc) in_flight = std::max(1, std::min(4, std::atoi(argv[++i])));
         else if (!std::strcmp(argv[i], "--fast")) fast = true;      // SPLAT_MODE_FAST: every colour byte within 1 of the exact frame
-        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--stream] [--fast] [--out frame.ppm]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--stream [--in-flight 1..4]] [--fast] [--out frame.ppm]\n"); return 2; }
     }
     try {
         std::printf("Loading gaussians from %s\n", ply ? ply : "naive_gaussians()");
@@ -32,21 +35,22 @@ int main(int argc, char** argv) {
         if (fast) pipeline.set_mode(SPLAT_MODE_FAST);
         std::vector<uint32_t> color((size_t)W * H, 0u);
         if (streaming) {
-            // the same loop with the present step decoupled: two pinned frames in flight, frame f is
-            // "presented" (waited for) while frame f+1 renders and frame f crosses PCIe
-            uint32_t* buf[2] = {splat::GaussianSplatPipeline01::alloc_frame((size_t)W * H),
-                                splat::GaussianSplatPipeline01::alloc_frame((size_t)W * H)};
+            // the same loop with the present step decoupled: `in_flight` pinned frames rotate (2 = a double-buffered window;
+            // the library holds up to four), frame f is "presented" (waited for) while the frames behind it render and
+            // cross PCIe
+            std::vector<uint32_t*> buf;
+            for (int k = 0; k < in_flight; ++k) buf.push_back(splat::GaussianSplatPipeline01::alloc_frame((size_t)W * H));
             auto t0 = std::chrono::steady_clock::now();
             for (int f = 0; f < frames; ++f) {
                 pipeline.camera.update_camera_pose();
-                pipeline.stream_frame(buf[f & 1]);
-                if (f > 0) pipeline.wait_frame(buf[(f - 1) & 1]);
+                pipeline.stream_frame(buf[f % in_flight]);
+                if (f >= in_flight - 1) pipeline.wait_frame(buf[(f - (in_flight - 1)) % in_flight]);
                 pipeline.camera.update_yaw_angle(10.0f * 3.14159265f / 180.0f);
             }
-            pipeline.wait_frame(buf[(frames - 1) & 1]);
+            for (int f = std::max(0, frames - (in_flight - 1)); f < frames; ++f) pipeline.wait_frame(buf[f % in_flight]);
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::printf("Streamed %d frames in %.3f ms: %.3f ms per frame, host-visible\n", frames, ms, ms / frames);
-            std::memcpy(color.data(), buf[(frames - 1) & 1], color.size() * 4);
+            std::memcpy(color.data(), buf[(frames - 1) % in_flight], color.size() * 4);
             for (auto* b : buf) splat::GaussianSplatPipeline01::free_frame(b);
             frames = 0;
         }

@@ -130,14 +130,14 @@ def test_cli_streaming_loop_gives_the_same_last_frame(tmp_path):
     """--stream: the loop with presentation decoupled (two pinned frames in flight) ends on the frame
     the synchronous loop ends on"""
     outs = []
-    for extra in ([], ["--stream"]):
+    for extra in ([], ["--stream"], ["--stream", "--in-flight", "4"]):
         out = str(tmp_path / ("f%d.ppm" % len(outs)))
         r = subprocess.run([os.path.join(ROOT, "splat_amd", "splat_cli"), "--frames", "5", "--size", "160", "120", "--out", out] + extra,
                            capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
         outs.append(open(out, "rb").read())
     assert "Streamed 5 frames" in r.stdout
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
 
 
 @pytest.mark.gpu
