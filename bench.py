@@ -249,7 +249,7 @@ def main():
         st = R.render_device(cam_c, image.data_ptr(), sync=True, want_stats=True)
     # setup, untimed and not counted as warm-up steps: the same frames until the device is out of its idle clocks and
     # every lazily created queue exists (a GPU fresh from idle runs its first few dozen frames ~10 % slower)
-    for _ in range(SETTLE_FRAMES):
+    for _ in range(0 if share else SETTLE_FRAMES):       # (not on the CPU-transport test path: nothing to settle there)
         step()
     fence()
     for _ in range(args.warmup):
