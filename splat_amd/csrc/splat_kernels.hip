@@ -1916,9 +1916,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 sp = now ? __float_as_uint(a.z) : sp;
                 done = done | now;
             }
-#ifndef SPLAT_STAT_BRACKET
             itA += k;
-#endif
             if (__builtin_amdgcn_ballot_w64(!done) == 0ull || bs == beg || bs <= giveup) break;
         }
         unsigned int need = done ? sp : beg;              // lanes that never saturated need the whole list
@@ -2016,9 +2014,6 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 for (unsigned int j = 0; j < k; ++j) shade(BRt, L.a[j], L.b[j], L.c[j]);
             }
             itB += k;
-#ifdef SPLAT_STAT_BRACKET
-            if (BR) itA += k;
-#endif
             if (BR && __builtin_amdgcn_ballot_w64(inside & ((R2 - R > cw) | (G2 - G > cw) | (B2 - B > cw))) == 0ull) return bsN;
         }
         return end;
