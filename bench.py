@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the host-visible and orbit legs")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast"],
+                    help="exact (default, what `value` is quoted on): the reference's frame; fast: SPLAT_MODE_FAST, every colour "
+                         "byte within 1 of the exact frame's by construction")
     ap.add_argument("--scene", default=None,
                     help="an INRIA 3DGS .ply (e.g. the real 'truck' / 'bicycle' / plush_sledge scene: none is in the repo, "
                          "src/main.rs:21 loads one): rendered at --workload's resolution and camera instead of the synthetic "
@@ -180,7 +183,8 @@ def main():
     # per-kernel HIP events ride on every 8th asynchronous frame by default (each record is a queue
     # bubble); a short timed region needs them on every frame to have launches to average over
     os.environ.setdefault("SPLAT_TIMING_EVERY", "8" if args.steps >= 64 else "1")
-    R = splat_amd.Renderer(device=local)
+    main_mode = splat_amd.MODE_FAST if args.mode == "fast" else splat_amd.MODE_EXACT
+    R = splat_amd.Renderer(device=local, mode=main_mode)
     if args.scene:
         g = splat_amd.load_from_ply(args.scene)          # the C++ host mirror's loader (mmap + direct decode)
         n = len(g.opacities)
@@ -383,7 +387,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": data_kind,
             "config": {"workload": "%s: %d Gaussians @%dx%d, %s, Camera(0,0,5), Pipeline01 "
-                                   "(lowpass 0.01, sh_dim 15), exact mode" % (args.workload, n, W, H, scene_name),
+                                   "(lowpass 0.01, sh_dim 15), %s mode" % (args.workload, n, W, H, scene_name, args.mode),
                        "camera": "36-pose yaw orbit, 10 degrees per frame" if args.orbit else "fixed pose",
                        "partition": ("one rank per GPU, load-balanced tile-row slabs %s, one gather of slab rows per frame: %s"
                                      % ([b - a for a, b in slabs],
@@ -442,12 +446,14 @@ def main():
             out["parity"] = {"max_channel_diff_lsb": int(d.max()), "pixels_differing": int((d.max(0) > 0).sum()),
                              "pixels": int(W * H), "fragments": int(ost.n_fragments),
                              "pairs_equal": bool(int(tot[1]) == int(ost.n_tile_pairs) and int(tot[0]) == int(ost.n_visible)),
-                             "tolerance_lsb": 1,
+                             "tolerance_lsb": 1 if args.mode == "exact" else 2,
                              "against": "oracle/ (C++ restatement of src/gaussians.rs + src/pipelines.rs + src/camera.rs); "
                                         "euc conventions ASSUMED, not pinned: y_up=1 from notes/screenshot.png (contradicts "
                                         "SURVEY appendix B's recollection of CoordinateMode::VULKAN = y down), pixel-centre "
                                         "samples, z-clip [0,1], inclusive rectangle -- euc@290e14c is not in the image"}
-            parity_ok = out["parity"]["max_channel_diff_lsb"] <= 1 and out["parity"]["pairs_equal"]
+            # (--mode fast: within 1 of the exact frame by construction -- checked below -- and the exact frame within 1 of the
+            # oracle through the exponential's last place: 2 in principle, 1 in every frame measured)
+            parity_ok = out["parity"]["max_channel_diff_lsb"] <= (1 if args.mode == "exact" else 2) and out["parity"]["pairs_equal"]
             # the verification mode: fragment()'s exp computed as the host libm does -> the oracle's frame bit for bit
             R.close()
             R2 = splat_amd.Renderer(device=local, mode=splat_amd.MODE_LIBM_EXP)
@@ -474,7 +480,8 @@ def main():
             parity_ok = parity_ok and out["parity"]["libm_exp_mode"]["pixels_differing"] == 0
             R2.close()
             # the fast mode: the same frame to within one count per colour byte, by construction (include/splat_hip.h)
-            R3 = splat_amd.Renderer(device=local, mode=splat_amd.MODE_FAST)
+            # (with --mode fast the roles swap: the timed frame is the fast one, this renderer supplies the exact frame)
+            R3 = splat_amd.Renderer(device=local, mode=splat_amd.MODE_EXACT if args.mode == "fast" else splat_amd.MODE_FAST)
             R3.upload(g)
             R3.set_stream(stream.cuda_stream)
             with torch.cuda.stream(stream):
@@ -496,7 +503,7 @@ def main():
             def ch(a):
                 return np.stack([((a >> s) & 255).astype(np.int32) for s in (24, 16, 8, 0)])
             dfe, dfo = np.abs(ch(fast_img) - ch(gpu_img)), np.abs(ch(fast_img) - ch(ref))
-            out["parity"]["fast_mode"] = {"frames_per_sec": fast_fps, "max_channel_diff_vs_exact_frame": int(dfe.max()),
+            out["parity"]["fast_mode" if args.mode == "exact" else "exact_mode"] = {"frames_per_sec": fast_fps, "max_channel_diff_vs_exact_frame": int(dfe.max()),
                                           "alpha_bytes_differing": int((dfe[0] > 0).sum()),
                                           "pixels_differing_vs_exact_frame": int((dfe.max(0) > 0).sum()),
                                           "max_channel_diff_vs_oracle": int(dfo.max()),
