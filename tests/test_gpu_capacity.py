@@ -127,3 +127,15 @@ def test_sort_launch_miss_with_tight_grids():
         assert r.frames_dropped() >= 1, "expected at least one sort-launch miss"
     finally:
         r.close()
+
+
+def test_fuzzed_pose_sequences_through_the_frame_pipeline():
+    """tools/fuzz_async.py, 15 seeds: random pose sequences rendered asynchronously with several frames in flight
+    (storage and launch sizes from earlier frames), slabs against the full frame, streamed frames four in flight --
+    every frame equals its synchronous render unless it was skipped on the device, left untouched and reported."""
+    import subprocess, sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_async.py"), "15", "4242"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "15 cases, 0 failures" in r.stdout

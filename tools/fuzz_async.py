@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Fuzz the frame pipeline: random sequences of poses (near, far, inside, orbit jumps) rendered ASYNCHRONOUSLY, several
+frames in flight with storage and launch sizes derived from EARLIER frames of the sequence, each into its own
+device image; then every image is compared with the same pose rendered synchronously.  A frame may only differ if it
+was skipped on the device (then its image is untouched and splat_frames_dropped() accounts for it); also slabs
+(2..4 tile-row slabs == the full frame) and the streamed path.   usage: python tools/fuzz_async.py [n_cases] [seed]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import splat_amd
+from splat_amd.renderer import SplatError
+from helpers import make_camera
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = 0
+tot_dropped = tot_frames = 0
+t0 = time.time()
+for case in range(ncases):
+    rng = np.random.default_rng(seed0 + case)
+    n = int(rng.choice([3000, 20000, 80000, 200000]))
+    g = splat_amd.synthetic_scene(n, seed0 + case)
+    if rng.integers(0, 3) == 0: g.positions[:, :3] *= rng.choice([0.1, 0.3])
+    H, W = int(rng.choice([96, 160, 240])), int(rng.choice([128, 200, 320]))
+    R = splat_amd.Renderer()
+    g.compute_cov3d(R); R.upload(g)
+    poses = []
+    for k in range(12):
+        pos = [(0, 0, 5.0), (0, 0, 1.5), (0.3, 0.2, 0.4), (0, 0, 25.0), (2.0, -1.0, 3.0), (0, 0, 9.0)][int(rng.integers(0, 6))]
+        poses.append(make_camera(H, W, pos, yaw=float(rng.uniform(0, 6.28)), pitch=float(rng.uniform(-0.5, 0.5))).to_c(float(rng.choice([0.01, 0.3])), 15))
+    garbage = rng.integers(1, 2**32, (H, W), dtype=np.uint64).astype(np.uint32)
+    imgs = [R.device_image(garbage) for _ in poses]
+    d0 = R.frames_dropped()
+    R.render_device(poses[0], imgs[0], sync=True)          # (sizes storage for pose 0 only)
+    R.device_free(imgs[0]); imgs[0] = R.device_image(garbage)
+    for p, im in zip(poses, imgs):
+        R.render_frame_device(p, im)                       # clear + render, asynchronous
+    try:
+        R.sync()
+    except SplatError:
+        pass                                               # some frame outgrew its storage: reported here, counted below
+    dropped = R.frames_dropped() - d0
+    tot_dropped += dropped; tot_frames += len(poses)
+    got = [R.device_download(im, H, W) for im in imgs]
+    wrong = 0
+    for k, p in enumerate(poses):
+        ref = np.zeros((H, W), np.uint32)
+        R.render(p, ref)
+        if not np.array_equal(got[k], ref):
+            if np.array_equal(got[k], garbage): wrong += 1           # skipped: untouched
+            else:
+                bad += 1
+                print("CASE %d seed %d: frame %d differs from its synchronous render (%d px) and is not an untouched skip" % (case, seed0 + case, k, int((got[k] != ref).sum())))
+    if wrong > dropped:
+        bad += 1
+        print("CASE %d seed %d: %d frames untouched but only %d reported dropped" % (case, seed0 + case, wrong, dropped))
+    # slabs == full frame
+    p = poses[int(rng.integers(0, len(poses)))]
+    full = np.zeros((H, W), np.uint32); R.render(p, full)
+    rows = (H + 15) // 16
+    cuts = sorted(set([0, rows] + [int(x) for x in rng.integers(0, rows + 1, int(rng.integers(1, 4)))]))
+    acc = np.zeros((H, W), np.uint32)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        R.set_slab(a, b)
+        part = np.zeros((H, W), np.uint32); R.render(p, part)
+        acc[a * 16:min(b * 16, H)] = part[a * 16:min(b * 16, H)]
+        if part[:a * 16].any() or part[min(b * 16, H):].any():
+            bad += 1; print("CASE %d seed %d: slab (%d,%d) wrote outside its rows" % (case, seed0 + case, a, b))
+    R.set_slab(0, -1)
+    if not np.array_equal(acc, full):
+        bad += 1; print("CASE %d seed %d: slabs %s != full frame (%d px)" % (case, seed0 + case, cuts, int((acc != full).sum())))
+    # streamed frames == synchronous frames, four in flight
+    bufs = [R.host_image(H, W) for _ in range(4)]
+    outs = []
+    for k, p in enumerate(poses[:8]):
+        if k >= 4:
+            R.stream_wait(bufs[k % 4]); outs.append(np.array(bufs[k % 4]).copy())
+        R.render_stream(p, bufs[k % 4])
+    for k in range(4, 8):
+        R.stream_wait(bufs[k % 4]); outs.append(np.array(bufs[k % 4]).copy())
+    for k, p in enumerate(poses[:8]):
+        ref = np.zeros((H, W), np.uint32); R.render(p, ref)
+        if not np.array_equal(outs[k], ref):
+            bad += 1; print("CASE %d seed %d: streamed frame %d differs (%d px)" % (case, seed0 + case, k, int((outs[k] != ref).sum())))
+    for im in imgs: R.device_free(im)
+    R.close()
+print("fuzz_async: %d cases, %d failures, %d of %d asynchronous frames skipped on the device and reported, %.0f s" % (ncases, bad, tot_dropped, tot_frames, time.time() - t0))
+sys.exit(1 if bad else 0)
