@@ -104,12 +104,12 @@ def load_from_ply(filename):
     err = C.create_string_buffer(512)
     n = L.splat_host_load_ply(str(filename).encode(), None, None, None, None, None, err, 512)
     if n < 0:
-        raise ValueError(err.value.decode() or "load_from_ply failed")
+        raise ValueError(err.value.decode("utf-8", "replace") or "load_from_ply failed")
     pos4, sc, op = np.zeros((n, 4), f32), np.zeros((n, 3), f32), np.zeros(n, f32)
     rot, sh = np.zeros((n, 4), f32), np.zeros((n, 48), f32)
     g = lambda a: a.ctypes.data_as(fp)  # noqa: E731
     if L.splat_host_load_ply(str(filename).encode(), g(pos4), g(sc), g(op), g(rot), g(sh), err, 512) != n:
-        raise ValueError(err.value.decode() or "load_from_ply failed")
+        raise ValueError(err.value.decode("utf-8", "replace") or "load_from_ply failed")
     return GaussianList(pos4, sc, op, rot, sh)
 
 

@@ -275,3 +275,38 @@ def test_blend_is_monotone_and_never_expands_a_difference_of_states():
                 assert d.min() >= 0 and d.max() <= 1, (float(a), float(c), sh, int(d.min()), int(d.max()))
             if a == 0.0:
                 assert np.array_equal(out & 0xffffff, packed & 0xffffff)      # a rejected fragment is the identity on RGB
+
+
+def test_ply_loader_survives_malformed_files(tmp_path):
+    """Truncated files, impossible vertex counts, a corrupted header byte, a missing end_header, a payload of random
+    bytes: load_from_ply (the C++ mmap loader) raises ValueError or loads, and never reads past the mapping (each case
+    in a child process, so a crash would show as its exit code)."""
+    import subprocess, sys
+    from splat_amd.gaussians import write_ply, synthetic_raw
+    base = str(tmp_path / "base.ply")
+    write_ply(base, synthetic_raw(50, 3), 50)
+    data = open(base, "rb").read()
+    hdr_end = data.index(b"end_header\n") + len(b"end_header\n")
+    rng = np.random.default_rng(0)
+    child = ("import sys\nsys.path.insert(0, %r)\nimport splat_amd\n"
+             "try:\n    print('ok', len(splat_amd.load_from_ply(sys.argv[1])))\n"
+             "except ValueError as e:\n    print('raised', str(e)[:60])\n") % os.path.join(os.path.dirname(__file__), "..")
+    (tmp_path / "child.py").write_text(child)
+    outcomes = []
+    for k in range(32):
+        kind, d = k % 8, bytearray(data)
+        if kind == 0: d = d[:int(rng.integers(0, len(d)))]
+        elif kind == 1: d = d[:hdr_end + int(rng.integers(0, len(d) - hdr_end))]
+        elif kind == 2: d = d.replace(b"element vertex 50", b"element vertex %d" % int(rng.choice([0, 51, 10**6, 2**31, 2**40, -5])))
+        elif kind == 3: d = d.replace(b"property float x", b"property double x")
+        elif kind == 4: d = d.replace(b"binary_little_endian", bytes(rng.choice([b"binary_big_endian", b"binary_little_endiax"])))
+        elif kind == 5: d[int(rng.integers(0, hdr_end))] = int(rng.integers(0, 256))
+        elif kind == 6: d = d.replace(b"end_header\n", b"")
+        elif kind == 7: d = d[:hdr_end] + bytes(rng.integers(0, 256, len(d) - hdr_end, dtype=np.uint8))
+        f = str(tmp_path / ("c%d.ply" % k))
+        open(f, "wb").write(bytes(d))
+        r = subprocess.run([sys.executable, str(tmp_path / "child.py"), f], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and r.stdout.strip(), (kind, r.returncode, r.stderr[-300:])
+        outcomes.append((kind, r.stdout.split()[0]))
+    assert all(o == "raised" for k, o in outcomes if k in (0, 1, 3, 6))          # truncation / size mismatch / no header end
+    assert all(o == "ok" for k, o in outcomes if k == 7)                         # any payload of the right size loads
