@@ -110,3 +110,15 @@ def test_comm_single_rank_over_rccl():
         R.device_free(d)
     finally:
         R.close()
+
+
+@pytest.mark.gpu
+def test_fuzzed_partitions_and_pose_sequences_equal_the_single_context():
+    """tools/fuzz_multi.py, 12 seeds: random scenes, target sizes, 1..6 ranks sharing this GPU, balanced and equal slabs,
+    host in/out frames onto a random image, viewer-loop frames queued back to back over changing poses (a slab skipped
+    for capacity is reported by the sync and redone), re-balancing: the gathered frame is the single-context frame."""
+    import os, subprocess, sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_multi.py"), "12", "777"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "12 cases, 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
