@@ -840,7 +840,8 @@ def test_fuzzed_scenes_match_the_oracle():
     """tools/fuzz_parity.py's generator (hostile scales, anisotropy, opacities, depth clusters, NaN / inf positions and
     colours, degenerate quaternions, odd target sizes, cameras inside / behind / far, every sorting / binning /
     compositing variant): 60 seeds here, thousands when the tool is run by hand.  HIP == oracle within 1 LSB with equal
-    pair and visible counts; the fast mode within 1 of the exact frame with equal alpha bytes."""
+    pair and visible counts; the fast mode within 1 of the exact frame with equal alpha bytes; the libm-exp mode the
+    oracle's frame bit for bit."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
     import fuzz_parity as F
@@ -852,7 +853,7 @@ def test_fuzzed_scenes_match_the_oracle():
                 os.environ.pop(k, None)
             os.environ.update(variant)
             frames = {}
-            for mode in (0, splat_amd.MODE_FAST):
+            for mode in (0, splat_amd.MODE_FAST, splat_amd.MODE_LIBM_EXP, splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP):
                 r = splat_amd.Renderer(mode=mode)
                 try:
                     if mode == 0:
@@ -873,6 +874,9 @@ def test_fuzzed_scenes_match_the_oracle():
             assert image_diff(img, ref)[0] <= TOL_LSB, desc
             d = np.abs(_channels(frames[splat_amd.MODE_FAST][0]) - _channels(img))
             assert d[0].max() == 0 and d[1:].max() <= 1, desc
+            # the exponential as the host libm computes it: the oracle's frame bit for bit; the fast mode within 1 of it
+            assert np.array_equal(frames[splat_amd.MODE_LIBM_EXP][0], ref), desc
+            assert image_diff(frames[splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP][0], ref)[0] <= 1, desc
     finally:
         for k, v in saved.items():
             os.environ.pop(k, None)

@@ -51,7 +51,7 @@ for case in range(ncases if __name__ == "__main__" else 0):
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(variant)
     frames = {}
-    for mode in (0, splat_amd.MODE_FAST):
+    for mode in (0, splat_amd.MODE_FAST, splat_amd.MODE_LIBM_EXP, splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP):
         R = splat_amd.Renderer(mode=mode)
         try:
             if mode == 0: g.compute_cov3d(R)
@@ -74,6 +74,13 @@ for case in range(ncases if __name__ == "__main__" else 0):
     mx, cnt = image_diff(img, ref)
     d = np.abs(np.stack([((frames[splat_amd.MODE_FAST][0] >> sh) & 255).astype(np.int32) - ((img >> sh) & 255).astype(np.int32) for sh in (24, 16, 8, 0)]))
     ok = st.n_pairs == ost.n_tile_pairs and st.n_visible == ost.n_visible and mx <= 1 and d[0].max() == 0 and d[1:].max() <= 1
+    # with the exponential computed as the host libm does: the oracle's frame bit for bit, and the fast mode within 1 of IT
+    libm_exact = np.array_equal(frames[splat_amd.MODE_LIBM_EXP][0], ref)
+    mx_fl, _ = image_diff(frames[splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP][0], ref)
+    if not libm_exact or mx_fl > 1:
+        ok = False
+        print("   libm-exp frame == oracle: %s (%d px differ); fast + libm-exp max diff vs oracle %d" %
+              (libm_exact, int((frames[splat_amd.MODE_LIBM_EXP][0] != ref).sum()), mx_fl))
     if not ok:
         bad += 1
         print("CASE %d FAILED: %s: pairs %d vs %d, visible %d vs %d, max diff %d (%d px), fast vs exact %d (alpha %d)"
