@@ -1766,7 +1766,12 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // overlaps on C3.  Their only effect, the alpha byte, is resolved by the alpha pass below.
     auto may_contribute = [&](const Rec& r) -> bool {
         const float a = r.b.x, b = r.b.y, c = r.b.z;
-        if (!(a > 0.0f && c > 0.0f && a * c - b * b > 0.0f)) return true;      // not positive definite: keep
+        // not positive definite: keep.  Nearly singular (a needle: b^2 within 0.1 % of a c): keep as well -- the minimum of
+        // q is then the small difference of terms thousands of times its size, and its f32 rounding error would no
+        // longer fit the margin below (found by tools/fuzz_parity.py: 3 of 12 000 hostile scenes lost a fragment of
+        // alpha ~ 1/255 to it, one count in one or two pixels)
+        const float ac = a * c;
+        if (!(a > 0.0f && c > 0.0f && ac - b * b > 1e-3f * ac)) return true;
         const float x0 = xlo - r.a.x, x1 = xhi - r.a.x, y0 = r.a.y - yhi, y1 = r.a.y - ylo;
         // q is convex with its minimum (0) at the centre: over the rectangle the minimum is 0 if the centre
         // is inside, else it lies on an edge that FACES the centre (from any point of a far edge q
@@ -2056,7 +2061,10 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 // VGPRs.  The walks need 64; the long-list sort in front of them would take 88, and under this bound spills nine
 // registers around its loop over the parts instead -- outside every hot loop (checked in the ISA).
 template <bool PAIR, bool LIBM, bool LONG>
-__global__ __launch_bounds__(256, LONG ? 7 : SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+#ifndef SPLAT_PAIR_WAVES
+#define SPLAT_PAIR_WAVES SPLAT_COMP_WAVES
+#endif
+__global__ __launch_bounds__(256, LONG ? 7 : (PAIR ? SPLAT_PAIR_WAVES : SPLAT_COMP_WAVES)) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned int* __restrict__ lens,
                                                               unsigned long long* __restrict__ keys,
