@@ -2061,10 +2061,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 // VGPRs.  The walks need 64; the long-list sort in front of them would take 88, and under this bound spills nine
 // registers around its loop over the parts instead -- outside every hot loop (checked in the ISA).
 template <bool PAIR, bool LIBM, bool LONG>
-#ifndef SPLAT_PAIR_WAVES
-#define SPLAT_PAIR_WAVES SPLAT_COMP_WAVES
-#endif
-__global__ __launch_bounds__(256, LONG ? 7 : (PAIR ? SPLAT_PAIR_WAVES : SPLAT_COMP_WAVES)) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+__global__ __launch_bounds__(256, LONG ? 7 : SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned int* __restrict__ lens,
                                                               unsigned long long* __restrict__ keys,
