@@ -22,7 +22,7 @@ def make_case(seed):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([300, 2000, 8000, 30000, 90000]))
     g = splat_amd.synthetic_scene(n, seed)
-    kind = int(rng.integers(0, 8))
+    kind = int(rng.integers(0, 12))
     if kind == 1: g.positions[:, :3] *= rng.choice([0.02, 0.1, 0.3])                       # dense: long lists
     if kind == 2: g.scales[:] *= rng.choice([0.05, 8.0, 40.0])                             # tiny / huge splats
     if kind == 3: g.scales[:, int(rng.integers(0, 3))] *= 1e-3; g.scales[:, int(rng.integers(0, 3))] *= 30.0   # needles / sheets
@@ -32,10 +32,14 @@ def make_case(seed):
         v = rng.choice([np.nan, np.inf, -np.inf, 1e30]); g.positions[rng.integers(0, n, n // 50), int(rng.integers(0, 3))] = v
         v = rng.choice([np.nan, np.inf, -np.inf, 1e30, -1e30]); g.sh[rng.integers(0, n, n // 40), int(rng.integers(0, 27))] = v
     if kind == 7: g.rotations[rng.integers(0, n, n // 30)] = 0.0                            # degenerate quaternions
+    if kind == 8: g.scales[:, 0] *= 200.0; g.scales[:, 1] *= 1e-4                           # long needles: nearly singular conics
+    if kind == 9: g.opacities[:] = rng.uniform(0.0035, 0.0045, n).astype(np.float32)       # every alpha at the 1/255 threshold
+    if kind == 10: g.opacities[:] = rng.uniform(0.98, 1.0, n).astype(np.float32); g.positions[:, :3] *= 0.2   # the 0.99 cap, dense
+    if kind == 11: g.scales[:] *= 1e-3                                                      # sub-pixel splats: the low-pass term alone
     H, W = int(rng.choice([33, 64, 100, 130, 200])), int(rng.choice([47, 64, 120, 177, 256]))
     pos = [(0, 0, 5.0), (0, 0, 1.0), (0.3, 0.2, 0.4), (0, 0, 30.0), (2.0, -1.0, 3.0), (0, 0, -4.0)][int(rng.integers(0, 6))]
     cam = make_camera(H, W, pos, yaw=float(rng.choice([0.0, 0.7, 2.5])), pitch=float(rng.choice([0.0, 0.3, -0.4])))
-    lp = float(rng.choice([0.01, 0.3]))
+    lp = float(rng.choice([0.01, 0.3, 0.3, 0.01, 0.0]))
     variant = VARIANTS[int(rng.integers(0, len(VARIANTS)))]
     init = rng.integers(0, 2**32, (H, W), dtype=np.uint64).astype(np.uint32) if rng.integers(0, 2) else np.zeros((H, W), np.uint32)
     return g, cam, lp, variant, init, "seed %d n %d kind %d %dx%d pos %s lp %g variant %s" % (seed, n, kind, W, H, pos, lp, variant)
