@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size parity sweep: the HIP frame against the CPU oracle for several camera poses of a
 workload (orbit poses, near and inside the cloud).  Prints one line per pose and a JSON summary.
-usage: python tools/parity_sweep.py [C3] [out.json]"""
+usage: python tools/parity_sweep.py [C3] [out.json] [libm]     (libm: SPLAT_MODE_LIBM_EXP -- the frames must then be the oracle's bit for bit)"""
 import json, math, os, sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -13,7 +13,7 @@ from bench import WORKLOADS
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 out = sys.argv[2] if len(sys.argv) > 2 else None
 n, W, H, seed = WORKLOADS[wl]
-R = splat_amd.Renderer()
+R = splat_amd.Renderer(mode=splat_amd.MODE_LIBM_EXP if (len(sys.argv) > 3 and sys.argv[3] == "libm") else 0)
 g = splat_amd.synthetic_scene(n, seed); g.compute_cov3d(R)
 R.upload(g)
 sd = scene_dict(g)
