@@ -15,6 +15,7 @@ VARIANTS = [{}, {"SPLAT_PAIR_BLEND": "1"}, {"SPLAT_PAIR_BLEND": "0"}, {"SPLAT_BU
             {"SPLAT_SORT_IN_COMP": "1", "SPLAT_BUCKETS": "0"}, {"SPLAT_FUSED_SORT": "0"}, {"SPLAT_EARLY_EPS": "0"},
             {"SPLAT_EARLY_EPS": "1e-2", "SPLAT_EARLY_MIN": "64"}, {"SPLAT_PIPELINE": "1"}, {"SPLAT_CULL": "0"}]
 KEYS = sorted({k for v in VARIANTS for k in v})
+SH_DIMS = [15, 15, 3, 12, 27, 48, 15]        # what the reference passes (15) most often; the thresholds of src/gaussians.rs:46,61,77 either side
 
 
 def make_case(seed):
@@ -50,7 +51,9 @@ seed0 = int(sys.argv[2]) if (__name__ == "__main__" and len(sys.argv) > 2) else 
 bad = 0
 t0 = time.time()
 for case in range(ncases if __name__ == "__main__" else 0):
-    g, cam, lp, variant, init, desc = make_case(seed0 + case)
+    seed0_case = seed0 + case
+    g, cam, lp, variant, init, desc = make_case(seed0_case)
+    desc += " sh_dim %d" % SH_DIMS[seed0_case % len(SH_DIMS)]
     H, W = int(cam.h), int(cam.w)
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(variant)
@@ -61,7 +64,7 @@ for case in range(ncases if __name__ == "__main__" else 0):
             if mode == 0: g.compute_cov3d(R)
             R.upload(g)
             img = init.copy()
-            st = R.render(cam.to_c(lp, 15), img)
+            st = R.render(cam.to_c(lp, SH_DIMS[seed0_case % len(SH_DIMS)]), img)
             frames[mode] = (img, st)
         finally:
             R.close()
@@ -73,7 +76,7 @@ for case in range(ncases if __name__ == "__main__" else 0):
     keep = np.isfinite(g.positions).all(axis=1)
     if not keep.all():
         sd = {k: np.ascontiguousarray(v[keep]) for k, v in sd.items()}
-    ref, ost = O.render(sd, oracle_camera(cam, lp), O.default_conventions(), init.copy(), nthreads=32)
+    ref, ost = O.render(sd, oracle_camera(cam, lp, SH_DIMS[seed0_case % len(SH_DIMS)]), O.default_conventions(), init.copy(), nthreads=32)
     img, st = frames[0]
     mx, cnt = image_diff(img, ref)
     d = np.abs(np.stack([((frames[splat_amd.MODE_FAST][0] >> sh) & 255).astype(np.int32) - ((img >> sh) & 255).astype(np.int32) for sh in (24, 16, 8, 0)]))
