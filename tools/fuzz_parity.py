@@ -15,6 +15,7 @@ VARIANTS = [{}, {"SPLAT_PAIR_BLEND": "1"}, {"SPLAT_PAIR_BLEND": "0"}, {"SPLAT_BU
             {"SPLAT_SORT_IN_COMP": "1", "SPLAT_BUCKETS": "0"}, {"SPLAT_FUSED_SORT": "0"}, {"SPLAT_EARLY_EPS": "0"},
             {"SPLAT_EARLY_EPS": "1e-2", "SPLAT_EARLY_MIN": "64"}, {"SPLAT_PIPELINE": "1"}, {"SPLAT_CULL": "0"}]
 KEYS = sorted({k for v in VARIANTS for k in v})
+CONVS = [{}, {}, {}, dict(y_up=0), dict(sample_half=0), dict(zclip=0), dict(zmin=-1.0), dict(y_up=0, sample_half=0, zclip=0)]   # euc switches, SURVEY appendix B
 SH_DIMS = [15, 15, 3, 12, 27, 48, 15]        # what the reference passes (15) most often; the thresholds of src/gaussians.rs:46,61,77 either side
 
 
@@ -53,13 +54,13 @@ t0 = time.time()
 for case in range(ncases if __name__ == "__main__" else 0):
     seed0_case = seed0 + case
     g, cam, lp, variant, init, desc = make_case(seed0_case)
-    desc += " sh_dim %d" % SH_DIMS[seed0_case % len(SH_DIMS)]
+    desc += " sh_dim %d conventions %s" % (SH_DIMS[seed0_case % len(SH_DIMS)], CONVS[(seed0_case // 7) % len(CONVS)])
     H, W = int(cam.h), int(cam.w)
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(variant)
     frames = {}
     for mode in (0, splat_amd.MODE_FAST, splat_amd.MODE_LIBM_EXP, splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP):
-        R = splat_amd.Renderer(mode=mode)
+        R = splat_amd.Renderer(mode=mode, **CONVS[(seed0_case // 7) % len(CONVS)])
         try:
             if mode == 0: g.compute_cov3d(R)
             R.upload(g)
@@ -76,7 +77,7 @@ for case in range(ncases if __name__ == "__main__" else 0):
     keep = np.isfinite(g.positions).all(axis=1)
     if not keep.all():
         sd = {k: np.ascontiguousarray(v[keep]) for k, v in sd.items()}
-    ref, ost = O.render(sd, oracle_camera(cam, lp, SH_DIMS[seed0_case % len(SH_DIMS)]), O.default_conventions(), init.copy(), nthreads=32)
+    ref, ost = O.render(sd, oracle_camera(cam, lp, SH_DIMS[seed0_case % len(SH_DIMS)]), O.default_conventions(**CONVS[(seed0_case // 7) % len(CONVS)]), init.copy(), nthreads=32)
     img, st = frames[0]
     mx, cnt = image_diff(img, ref)
     d = np.abs(np.stack([((frames[splat_amd.MODE_FAST][0] >> sh) & 255).astype(np.int32) - ((img >> sh) & 255).astype(np.int32) for sh in (24, 16, 8, 0)]))
