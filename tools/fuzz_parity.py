@@ -15,7 +15,8 @@ VARIANTS = [{}, {"SPLAT_PAIR_BLEND": "1"}, {"SPLAT_PAIR_BLEND": "0"}, {"SPLAT_BU
             {"SPLAT_SORT_IN_COMP": "1", "SPLAT_BUCKETS": "0"}, {"SPLAT_FUSED_SORT": "0"}, {"SPLAT_EARLY_EPS": "0"},
             {"SPLAT_EARLY_EPS": "1e-2", "SPLAT_EARLY_MIN": "64"}, {"SPLAT_PIPELINE": "1"}, {"SPLAT_CULL": "0"}]
 KEYS = sorted({k for v in VARIANTS for k in v})
-CONVS = [{}, {}, {}, dict(y_up=0), dict(sample_half=0), dict(zclip=0), dict(zmin=-1.0), dict(y_up=0, sample_half=0, zclip=0)]   # euc switches, SURVEY appendix B
+CONVS = [{}, {}, {}, dict(y_up=0), dict(sample_half=0), dict(zclip=0), dict(zmin=-1.0), dict(y_up=0, sample_half=0, zclip=0),
+         dict(corrected_projection=1)]   # euc switches; the last one is SPLAT_MODE_CORRECTED_PROJECTION (a mode flag here)
 SH_DIMS = [15, 15, 3, 12, 27, 48, 15]        # what the reference passes (15) most often; the thresholds of src/gaussians.rs:46,61,77 either side
 
 
@@ -60,7 +61,9 @@ for case in range(ncases if __name__ == "__main__" else 0):
     os.environ.update(variant)
     frames = {}
     for mode in (0, splat_amd.MODE_FAST, splat_amd.MODE_LIBM_EXP, splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP):
-        R = splat_amd.Renderer(mode=mode, **CONVS[(seed0_case // 7) % len(CONVS)])
+        conv = dict(CONVS[(seed0_case // 7) % len(CONVS)])
+        corrected = splat_amd.MODE_CORRECTED_PROJECTION if conv.pop("corrected_projection", 0) else 0
+        R = splat_amd.Renderer(mode=mode | corrected, **conv)
         try:
             if mode == 0: g.compute_cov3d(R)
             R.upload(g)
