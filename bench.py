@@ -242,10 +242,37 @@ def main():
                     stream.synchronize()     # gloo's CUDA receive is not ordered after this stream's work (NCCL's is)
                 sdist.gather_slabs(image, slabs, rank)
 
+    from splat_amd.renderer import SplatError
+    from splat_amd import _lib as _abi
+
+    def settle(r):
+        """splat_sync: every frame's status is harvested, so splat_frames_dropped() is final.  A frame that outgrew storage
+        sized from earlier frames is SKIPPED on the device (it costs ~0 ms and leaves the image alone: with a fixed pose
+        the parity check cannot see it) -- the loss surfaces here once as SPLAT_ERR_CAPACITY; the legs count them."""
+        try:
+            r.sync()
+        except SplatError as e:
+            if e.code != _abi.ERR_CAPACITY:
+                raise
+
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        settle(R)
+
+    leg_drops = {}
+
+    class counted:
+        """with counted(name): ... -- frames the device skipped inside a timed leg (must be 0 for the fps to mean anything)"""
+        def __init__(self, name, r=None):
+            self.name, self.r = name, r or R
+        def __enter__(self):
+            settle(self.r)
+            self.d0 = self.r.frames_dropped()
+        def __exit__(self, *a):
+            settle(self.r)
+            leg_drops[self.name] = leg_drops.get(self.name, 0) + self.r.frames_dropped() - self.d0
 
     # one synchronous frame first: settles the pair-buffer capacity and gives the frame's statistics
     with torch.cuda.stream(stream):
@@ -260,11 +287,13 @@ def main():
         step()
     fence()
     R.timing(reset=True)
+    dropped0 = R.frames_dropped()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    fence()                                              # barrier + device fence + splat_sync (statuses harvested)
     dt = time.perf_counter() - t0
+    dropped_timed = R.frames_dropped() - dropped0        # frames the device skipped inside the timed region: must be 0
     kern_ms, frames = R.timing(reset=True)               # HIP events on the kernels' own stream
     last_pose = poses[(frame_no[0] - 1) % len(poses)]
     final = image.clone()
@@ -286,30 +315,33 @@ def main():
                 for k in range(4):
                     R.render_frame_device(orbit[k], image.data_ptr())
                 torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for k in range(K):
-                    R.render_frame_device(orbit[k % 36], image.data_ptr())
-                torch.cuda.synchronize()
-                legs["orbit_36_poses_device_resident_fps"] = K / (time.perf_counter() - t1)
+                with counted("orbit_36_poses_device_resident_fps"):
+                    t1 = time.perf_counter()
+                    for k in range(K):
+                        R.render_frame_device(orbit[k % 36], image.data_ptr())
+                    torch.cuda.synchronize()
+                    legs["orbit_36_poses_device_resident_fps"] = K / (time.perf_counter() - t1)
             # (1b) a short timed region (the driver's --steps 20) is mostly pipeline fill and a GPU coming out of idle:
             # the same step, 400 frames back to back, for the steady state
             if args.steps < 100:
                 for k in range(10):
                     R.render_frame_device(cam_c, image.data_ptr())
                 torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for k in range(400):
-                    R.render_frame_device(cam_c, image.data_ptr())
-                torch.cuda.synchronize()
-                legs["steady_state_400_frames_device_resident_fps"] = 400 / (time.perf_counter() - t1)
+                with counted("steady_state_400_frames_device_resident_fps"):
+                    t1 = time.perf_counter()
+                    for k in range(400):
+                        R.render_frame_device(cam_c, image.data_ptr())
+                    torch.cuda.synchronize()
+                    legs["steady_state_400_frames_device_resident_fps"] = 400 / (time.perf_counter() - t1)
             # (2) host-visible: the literal render_to_buffer -- host image in and out, synchronous (src/main.rs:71-75)
             himg = np.zeros((H, W), np.uint32)
             R.render(cam_c, himg)
-            t1 = time.perf_counter()
-            for _ in range(20):
-                himg[:] = 0
-                R.render(cam_c, himg)
-            legs["host_visible_splat_render_fps"] = 20 / (time.perf_counter() - t1)
+            with counted("host_visible_splat_render_fps"):
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    himg[:] = 0
+                    R.render(cam_c, himg)
+                legs["host_visible_splat_render_fps"] = 20 / (time.perf_counter() - t1)
             # (3) host-visible: the viewer loop (clear, render, present) with pinned frames in flight: frame k is presented
             # (waited for) while frames k+1.. render and cross PCIe.  Two buffers are what a double-buffered window has;
             # four keep the device's frame pipeline (two binning chains + a compositor) full
@@ -321,24 +353,32 @@ def main():
                         R.stream_wait(bufs[(k - (nb - 1)) % nb])
                 for k in range(80 - (nb - 1), 80):
                     R.stream_wait(bufs[k % nb])
-                t1 = time.perf_counter()
-                for k in range(K):
-                    R.render_stream(cam_c, bufs[k % nb])
-                    if k >= nb - 1:
-                        R.stream_wait(bufs[(k - (nb - 1)) % nb])
-                for k in range(max(0, K - (nb - 1)), K):
-                    R.stream_wait(bufs[k % nb])
-                legs["host_visible_splat_render_stream_fps" if nb == 2 else "host_visible_splat_render_stream_4_in_flight_fps"] = K / (time.perf_counter() - t1)
+                leg = "host_visible_splat_render_stream_fps" if nb == 2 else "host_visible_splat_render_stream_4_in_flight_fps"
+                with counted(leg):
+                    t1 = time.perf_counter()
+                    for k in range(K):
+                        R.render_stream(cam_c, bufs[k % nb])
+                        if k >= nb - 1:
+                            R.stream_wait(bufs[(k - (nb - 1)) % nb])
+                    for k in range(max(0, K - (nb - 1)), K):
+                        R.stream_wait(bufs[k % nb])
+                    legs[leg] = K / (time.perf_counter() - t1)
                 last_buf = bufs[(K - 1) % nb]
             legs["host_visible_frames_equal_device_frame"] = bool(np.array_equal(last_buf, himg))
+            legs["frames_dropped"] = dict(leg_drops)
             legs["what"] = ("host-visible = pixels delivered to host memory (PCIe inclusive); never `value`.  %d frames each "
-                            "(splat_render: 20)" % K)
+                            "(splat_render: 20).  frames_dropped = frames the device skipped inside each leg's timed loop "
+                            "(splat_frames_dropped() around it, statuses harvested by splat_sync): a skipped frame costs ~0 ms, "
+                            "so a leg with drops is not a measurement (exit code 4)" % K)
             R.timing(reset=True)
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dr = torch.tensor([dropped_timed], dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(dr, op=dist.ReduceOp.SUM)
     dt = float(t.item())
+    dropped_all = int(dr.item())             # frames any rank's device skipped inside the timed region
 
     # per-rank stats -> whole-frame totals
     tot = torch.tensor([st.n_visible, st.n_pairs, st.bytes_algorithmic, st.flops_algorithmic, st.n_iter_scan, st.n_iter_blend],
@@ -396,7 +436,8 @@ def main():
                                     if world > 1 else "single GPU",
                        "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len),
                        "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback),
-                       "k1_blocks_culled": int(st.n_blocks_culled)},
+                       "k1_blocks_culled": int(st.n_blocks_culled),
+                       "frames_dropped": int(dropped_all)},
             "roofline": {"bound": "hbm", "kernel": "composite_exact_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": per["composite"], "bytes_per_launch": comp_bytes,
@@ -467,12 +508,14 @@ def main():
             for _ in range(5):
                 R2.render_frame_device(last_pose, image.data_ptr())
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(60):
-                R2.render_frame_device(last_pose, image.data_ptr())
-            torch.cuda.synchronize()
+            with counted("parity.libm_exp_mode", R2):
+                t1 = time.perf_counter()
+                for _ in range(60):
+                    R2.render_frame_device(last_pose, image.data_ptr())
+                torch.cuda.synchronize()
+                libm_fps = 60 / (time.perf_counter() - t1)
             out["parity"]["libm_exp_mode"] = {"pixels_differing": int((exact_img != ref).sum()),
-                                              "frames_per_sec": 60 / (time.perf_counter() - t1),
+                                              "frames_per_sec": libm_fps, "frames_dropped": leg_drops["parity.libm_exp_mode"],
                                               "what": "SPLAT_MODE_LIBM_EXP: exp as glibc computes it (double, table + cubic); every "
                                                       "other operation is already the reference's, so the frame must be the "
                                                       "oracle's bit for bit -- the default mode's differing pixels are the "
@@ -493,17 +536,18 @@ def main():
             for _ in range(10):
                 R3.render_frame_device(last_pose, image.data_ptr())
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                R3.render_frame_device(last_pose, image.data_ptr())
-            torch.cuda.synchronize()
-            fast_fps = args.steps / (time.perf_counter() - t1)
+            with counted("parity.other_mode", R3):
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    R3.render_frame_device(last_pose, image.data_ptr())
+                torch.cuda.synchronize()
+                fast_fps = args.steps / (time.perf_counter() - t1)
             R3.close()
 
             def ch(a):
                 return np.stack([((a >> s) & 255).astype(np.int32) for s in (24, 16, 8, 0)])
             dfe, dfo = np.abs(ch(fast_img) - ch(gpu_img)), np.abs(ch(fast_img) - ch(ref))
-            out["parity"]["fast_mode" if args.mode == "exact" else "exact_mode"] = {"frames_per_sec": fast_fps, "max_channel_diff_vs_exact_frame": int(dfe.max()),
+            out["parity"]["fast_mode" if args.mode == "exact" else "exact_mode"] = {"frames_per_sec": fast_fps, "frames_dropped": leg_drops["parity.other_mode"], "max_channel_diff_vs_exact_frame": int(dfe.max()),
                                           "alpha_bytes_differing": int((dfe[0] > 0).sum()),
                                           "pixels_differing_vs_exact_frame": int((dfe.max(0) > 0).sum()),
                                           "max_channel_diff_vs_oracle": int(dfo.max()),
@@ -513,6 +557,10 @@ def main():
                                                   "difference of states, so every colour byte is within 1 of the exact frame's "
                                                   "(must hold: exit code 3 otherwise), alpha bytes equal; %d frames" % args.steps}
             parity_ok = parity_ok and int(dfe.max()) <= 1 and int((dfe[0] > 0).sum()) == 0
+        if dropped_all or any(leg_drops.values()):
+            sys.stderr.write("bench.py: the device SKIPPED frames inside a timed region (headline %d, legs %s): the rate is not "
+                             "a measurement\n" % (dropped_all, json.dumps(leg_drops)))
+            exit_code = 4
         print(json.dumps(out))
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY MISS against the oracle: %s\n" % json.dumps(out["parity"]))

@@ -45,9 +45,11 @@ extern "C" {
 #define SPLAT_MODE_FAST 4        /* the compositor's early-out stops proving the frame EXACT and proves it within one
                                     count instead: the layers behind the walk's start are bracketed as in the exact
                                     mode ([lo,hi] from 0 and from 255, blend() is monotone), but the bracket counts as
-                                    closed at hi - lo <= 1, which half the optical depth achieves.  Every R, G, B byte
-                                    is within 1 of the SPLAT_MODE_EXACT frame's (the alpha byte is the same); about a
-                                    third less compositor time.  The north_star's "front-to-back ... early-out
+                                    closed at hi - lo <= 2 and the walk continues from its MIDDLE (within 1 of the
+                                    exact state; blend() never expands a difference of integer states), which half
+                                    the optical depth achieves.  Every R, G, B byte is within 1 of the
+                                    SPLAT_MODE_EXACT frame's (the alpha byte is the same); about a third less
+                                    compositor time.  (SPLAT_FAST_WIDTH=1: closed at hi - lo <= 1, continue from lo.)  The north_star's "front-to-back ... early-out
                                     on saturated alpha", with the error bound proven instead of hoped for.        */
 
 typedef struct splat_ctx splat_ctx;
@@ -133,7 +135,8 @@ int splat_tile_row_loads(splat_ctx* ctx, const splat_camera* cam, uint64_t* row_
  * copy then blocks the calling thread.  A streamed frame that outgrew its storage on the device (tile
  * bucket, pair buffer, sort launch sizes: all sized from earlier frames) is detected by the wait, which
  * grows the storage and renders that frame again into `argb_out` before it returns: a viewer loop never
- * sees the miss (splat_frames_dropped() counts them). */
+ * sees the miss (splat_frames_dropped() counts them).  On a context restricted to a slab only the slab's rows are
+ * rendered; the other rows of `argb_out` read as zeros. */
 int splat_render_stream(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb_out);
 int splat_stream_wait(splat_ctx* ctx, const uint32_t* argb_out);
 void* splat_host_alloc(uint64_t bytes);      /* page-locked host memory (hipHostMalloc); NULL on failure */
@@ -175,7 +178,8 @@ int splat_set_stream(splat_ctx* ctx, void* hip_stream);
  * frame rendered with a stats pointer; averages = ms[k] / *frames.  Waits for outstanding frames. */
 int splat_get_timing(splat_ctx* ctx, double ms[6], uint64_t* frames, int32_t reset);
 
-/* Debug / stage parity: results of the last frame. */
+/* Debug / stage parity: results of the last frame.  splat_get_tile_lists needs a frame rendered WITH a stats pointer
+ * (ordinary frames keep the short lists they sort on chip and never write them back: SPLAT_ERR_INVALID then). */
 int splat_get_records(splat_ctx* ctx, splat_record* out, uint64_t n);
 /* tile_offsets: n_tiles+1 entries (slab-local tiles, row-major); order: n_pairs Gaussian indices,
  * each tile's list in blend order (far -> near). Pass NULL to query sizes via stats. */
@@ -218,6 +222,11 @@ int splat_comm_set_slabs(splat_ctx* ctx, const int32_t* slabs);
 /* Gather: enqueued on the context's stream behind the frames rendered so far.  d_argb = this rank's w x h
  * device image; afterwards (stream order) the root's image holds every rank's rows. */
 int splat_comm_gather(splat_ctx* ctx, void* d_argb, int32_t w, int32_t h, int32_t root);
+/* Test hook for one-GPU boxes: with `on`, a SINGLE-rank communicator's gather moves this rank's slab rows through
+ * RCCL to itself (ncclSend + ncclRecv to the own rank in one group, on the context's stream) and restores them from
+ * what arrived -- the code path, RCCL kernel included, of the multi-rank gather.  The frame is unchanged if RCCL
+ * delivered the rows intact.  n_ranks > 1: SPLAT_ERR_INVALID. */
+int splat_comm_loopback(splat_ctx* ctx, int32_t on);
 void splat_comm_destroy(splat_ctx* ctx);              /* also done by splat_destroy */
 
 /* (B) one process.  devices[i] = HIP ordinal of rank i (rank 0 is the root).  A device may be listed more than
@@ -231,8 +240,9 @@ void splat_multi_destroy(splat_multi* m);
 const char* splat_multi_last_error(const splat_multi* m);   /* m may be NULL: last create() error */
 int splat_multi_upload_scene(splat_multi* m, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
                              const float* sh);               /* replicated on every device, in parallel */
-/* Load-balanced slabs for this camera (count-only pass on the root + splat_slab_partition); cam == NULL:
- * equal slabs.  The partition stays until the next call. */
+/* Load-balanced slabs for this camera (count-only pass on the root + splat_slab_partition).  cam == NULL: equal
+ * slabs for the target size of the last partition (SPLAT_ERR_INVALID before any frame / balance: the height fixes
+ * the tile rows).  The partition stays until the next call or a frame of another target size. */
 int splat_multi_balance(splat_multi* m, const splat_camera* cam);
 int splat_multi_get_slabs(const splat_multi* m, int32_t* slabs_out /* n_devices x {row0,row1} */);
 /* render_to_buffer across the devices: blends the scene onto `argb` (host, in/out, w*h u32).  stats (nullable)
@@ -242,6 +252,11 @@ int splat_multi_render(splat_multi* m, const splat_camera* cam, uint32_t* argb, 
  * sends them to the root's image.  Asynchronous: returns once the frame is queued on every device's thread;
  * splat_multi_sync waits.  The root's image (device memory on devices[0]) is splat_multi_image(). */
 int splat_multi_render_frame(splat_multi* m, const splat_camera* cam);
+/* Waits for every rank.  SPLAT_ERR_CAPACITY: an asynchronous slab frame outgrew storage sized from earlier frames and
+ * was skipped on its device -- the root's image then holds that slab's rows as the gather found them (cleared or
+ * stale); the storage has been grown: render the frame again (splat_multi_render_frame may report the same for a loss
+ * found while it re-partitions).  Any other error: the first one a rank recorded since the last sync
+ * (splat_multi_last_error names the rank). */
 int splat_multi_sync(splat_multi* m);
 void* splat_multi_image(splat_multi* m);
 int splat_multi_download(splat_multi* m, uint32_t* argb_out, int32_t w, int32_t h);   /* root image -> host (after a sync) */

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("splat_comm_init_rank", C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
     ("splat_comm_set_slabs", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     ("splat_comm_gather", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    ("splat_comm_loopback", C.c_int, [C.c_void_p, C.c_int32]),
     ("splat_comm_destroy", None, [C.c_void_p]),
     ("splat_multi_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
     ("splat_multi_destroy", None, [C.c_void_p]),

@@ -48,6 +48,8 @@ struct Slot {                  // everything one frame writes before the image
     unsigned int* lens = nullptr;           // list length per tile (the list starts at offsets[tile])
     unsigned long long* keys = nullptr;
     unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
+    unsigned int* blockinfo = nullptr;     // per K1 block: the info word this slot's last K1 wrote (see launch_preprocess);
+                                           // per slot, because the K1s of consecutive frames run concurrently
     FrameStatus* d_status = nullptr;
     hipEvent_t ev_binned = nullptr;        // bin stream -> sort stream: buckets and lengths are final
     hipEvent_t ev_ready = nullptr;         // sort stream -> caller's stream: lists are sorted
@@ -67,7 +69,6 @@ struct splat_ctx {
     float4* planes = nullptr;
     unsigned int* orig = nullptr;          // slot -> original Gaussian index (Morton order of position)
     BlockBounds* bounds = nullptr;         // per K1 block of 256 slots (block culling)
-    unsigned int* culled = nullptr;        // per block info word written by the last K1 (see launch_preprocess)
     bool cull_blocks = true;               // SPLAT_CULL=0 disables
     std::vector<unsigned int> h_orig;
     // per-frame buffers
@@ -85,6 +86,7 @@ struct splat_ctx {
     unsigned int bucket_m = 0;             // tile count bucket_failed refers to
     uint64_t frame_idx = 0;
     int last_slot = -1;                    // buffer slot of the most recent frame (debug getters)
+    bool last_lists_in_memory = false;     // ... and whether its compositor wrote the lists it sorted back to the buckets
     FrameStatus* h_status = nullptr;       // pinned, one per event-ring entry
     // Every frame in flight has a device status of its own (one per event-ring entry).  The scan kernel -- where a
     // frame's pair count, longest list and every overflow verdict are decided -- initialises it and writes the same
@@ -426,7 +428,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     if (!c->fc.bucket_cap)                                 // two-pass binning: K1 counts visible Gaussians into the status before the scan
         HIP_TRY(c, hipMemsetAsync(d_st, 0, sizeof(FrameStatus), bs));
     HIP_TRY(c, mark(0, bs));
-    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, c->culled, d_st);
+    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, s.blockinfo, d_st);
     HIP_TRY(c, mark(1, bs));
     if (compositor_sorts_long_lists(c, m) && s.keys2 != nullptr) {
         c->grid_big = m; c->grid_mid = m; c->grid_long = m;        // no sort launches to size: the scan has nothing to validate
@@ -490,6 +492,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     ev.timed = timed;
     c->last_ring = r;
     c->last_slot = si;
+    c->last_lists_in_memory = want_iters || c->fused_sort_max == 0;
     return SPLAT_OK;
 }
 
@@ -580,9 +583,10 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->n_sort_fallback = c->last.n_sort_fallback;
     st->n_iter_scan = 0; st->n_iter_blend = 0;
     st->n_blocks_culled = 0;
-    if (c->culled && c->last_ring >= 0 && (c->fc.cull_blocks || c->fc.bucket_cap)) {   // the frame has finished: sum its block words
+    const unsigned int* binfo = c->last_slot >= 0 ? c->slots[c->last_slot].blockinfo : nullptr;
+    if (binfo && c->last_ring >= 0 && (c->fc.cull_blocks || c->fc.bucket_cap)) {   // the frame has finished: sum its block words
         std::vector<unsigned int> f((c->n + 255) / 256);
-        if (hipMemcpy(f.data(), c->culled, f.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess) {
+        if (hipMemcpy(f.data(), binfo, f.size() * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess) {
             uint64_t vis = 0, sing = 0;
             for (unsigned int v : f) {
                 if (v & 0x80000000u) { st->n_blocks_culled++; continue; }
@@ -622,8 +626,8 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
 }
 
 void free_scene(splat_ctx* c) {
-    dfree(c->planes); dfree(c->orig); dfree(c->bounds); dfree(c->culled);
-    for (Slot& s : c->slots) { dfree(s.recs); dfree(s.depth); dfree(s.rect); dfree(s.vislist); s.used = false; }
+    dfree(c->planes); dfree(c->orig); dfree(c->bounds);
+    for (Slot& s : c->slots) { dfree(s.recs); dfree(s.depth); dfree(s.rect); dfree(s.vislist); dfree(s.blockinfo); s.used = false; }
     c->n = 0;
     c->h_orig.clear();
     c->last_slot = -1;
@@ -790,14 +794,14 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
         UP_TRY(hipMalloc(&s.depth, sizeof(float) * n));
         UP_TRY(hipMalloc(&s.rect, sizeof(ushort4) * n));
         UP_TRY(hipMalloc(&s.vislist, sizeof(unsigned int) * n));
+        UP_TRY(hipMalloc(&s.blockinfo, sizeof(unsigned int) * ((n + 255) / 256)));
+        UP_TRY(hipMemsetAsync(s.blockinfo, 0, sizeof(unsigned int) * ((n + 255) / 256), c->stream));
     }
     UP_TRY(hipMemcpyAsync(c->orig, c->h_orig.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, c->stream));
     std::vector<BlockBounds> hb;
     block_bounds(n, pos4, cov3d, c->h_orig, hb);
     UP_TRY(hipMalloc(&c->bounds, sizeof(BlockBounds) * hb.size()));
     UP_TRY(hipMemcpyAsync(c->bounds, hb.data(), sizeof(BlockBounds) * hb.size(), hipMemcpyHostToDevice, c->stream));
-    UP_TRY(hipMalloc(&c->culled, hb.size() * sizeof(unsigned int)));
-    UP_TRY(hipMemsetAsync(c->culled, 0, hb.size() * sizeof(unsigned int), c->stream));
     UP_TRY(hipMalloc(&d_pos, sizeof(float) * 4 * n));
     UP_TRY(hipMalloc(&d_cov, sizeof(float) * 9 * n));
     UP_TRY(hipMalloc(&d_op, sizeof(float) * n));
@@ -868,7 +872,7 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     Slot& s = c->slots[0];
     fc.bucket_cap = 0;          // count only
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
-    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, c->bounds, c->culled, s.d_status);
+    launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, c->bounds, s.blockinfo, s.d_status);
     launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, ~0ull, 0u, nt, nt, nt);
     HIP_TRY(c, hipGetLastError());
     std::vector<unsigned int> off((size_t)nt + 1);
@@ -999,6 +1003,7 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
         for (int k = 0; k < splat_ctx::S_IMGS; ++k) {
             dfree(c->s_img[k]); c->s_used[k] = false;
             HIP_TRY(c, hipMalloc(&c->s_img[k], bytes));
+            HIP_TRY(c, hipMemset(c->s_img[k], 0, bytes));      // a slab context renders its own rows only: the rest reads as zeros
         }
         c->s_cap = bytes;
     }
@@ -1030,13 +1035,25 @@ int splat_stream_wait(splat_ctx* c, const uint32_t* argb_out) {
             const int r = c->s_ring[k];
             const bool skipped = r >= 0 && c->h_status[r].overflow != 0;
             if (!skipped) return SPLAT_OK;
-            int rc = finish_quiet(c);                 // every frame in flight lands; storage grown; other losses stay pending
+            int rc = finish_quiet(c);                 // every frame in flight lands; storage grown
             if (rc != SPLAT_OK) return rc;
-            c->deferred_drop = false;
-            // (the OTHER image's frame, if it was lost too, is redone by its own wait: its status says so)
+            {   // Streamed losses are redone by their own waits (this one below, the other images' by theirs: their status
+                // words say so) and are therefore settled here; only a loss that belongs to NO streaming image -- a
+                // plain asynchronous splat_render_device frame in flight beside the stream -- stays pending for the
+                // next splat_sync.  (Without this the synchronous redo below found `dropped - reported >= 1` with its
+                // own frame complete and left a spurious SPLAT_ERR_CAPACITY behind for the next splat_sync.)
+                uint64_t streamed = 0;
+                for (int q = 0; q < splat_ctx::S_IMGS; ++q)
+                    if (c->s_used[q] && c->s_ring[q] >= 0 && c->h_status[c->s_ring[q]].overflow != 0) ++streamed;
+                const uint64_t pending = c->frames_dropped - c->frames_drop_reported;
+                c->deferred_drop = pending > streamed;
+                c->frames_drop_reported = c->frames_dropped;
+            }
             const size_t bytes = (size_t)c->s_cam[k].w * (size_t)c->s_cam[k].h * 4;
+            const bool other_pending = c->deferred_drop;
             rc = splat_render_frame_device(c, &c->s_cam[k], c->s_img[k], 1, nullptr);
             if (rc != SPLAT_OK) return rc;
+            c->deferred_drop = other_pending;          // (the redo's own bookkeeping saw only settled streamed losses)
             c->s_ring[k] = c->last_ring;
             HIP_TRY(c, hipMemcpyAsync(const_cast<uint32_t*>(argb_out), c->s_img[k], bytes, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1148,6 +1165,8 @@ int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offset
     int rc = splat_sync(c);
     if (rc != SPLAT_OK) return rc;
     if (c->last_slot < 0) return fail(c, SPLAT_ERR_INVALID, "no frame rendered yet");
+    if (!c->last_lists_in_memory)
+        return fail(c, SPLAT_ERR_INVALID, "the last frame kept its sorted short lists on chip: render it with a stats pointer to read the lists");
     const Slot& s = c->slots[c->last_slot];
     if (n_offsets != (uint64_t)c->n_tiles + 1 || n_order != c->last.n_pairs)
         return fail(c, SPLAT_ERR_INVALID, "tile list size mismatch");

@@ -15,6 +15,10 @@
 
 #include "splat_internal.h"
 
+#ifndef SPLAT_K1X
+#define SPLAT_K1X 0      // K1 timing experiments (tools/k1_ab.sh); 0 = the product
+#endif
+
 namespace splat {
 
 // ---------------------------------------------------------------------------
@@ -377,7 +381,8 @@ struct BucketBinner {
     __device__ __forceinline__ void put(unsigned int tile, unsigned int slot, unsigned long long k) const {
         if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
     }
-    // f(tx, ty, key) for every tile of the thread's aggregated rectangle (see bin_block's each_tile)
+    // f(tx, ty, key) for every tile of the thread's aggregated rectangle (see bin_block's each_tile).  Rectangles of
+    // more than LANE_T tiles are spread over the lanes of their wave, 64 tiles per round.
     template <typename F>
     __device__ __forceinline__ void each_tile(unsigned long long key, F f) const {
         const unsigned int lane = threadIdx.x & 63u;
@@ -392,9 +397,16 @@ struct BucketBinner {
             const int W = __builtin_amdgcn_readlane(w, src), N = __builtin_amdgcn_readlane(ntiles, src);
             const unsigned int klo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)key, src);
             const unsigned int khi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(key >> 32), src);
-            if ((int)lane < N) {
-                const int dy = (int)lane / W, dx = (int)lane - dy * W;
-                f(X0 + dx, Y0 + dy, ((unsigned long long)khi << 32) | klo);
+            // (W <= HASH_DIM: t / W by a float reciprocal, exact for t < 2^20 after the one-step correction)
+            const float rW = __builtin_amdgcn_rcpf((float)W);
+            for (int t0 = 0; t0 < N; t0 += 64) {
+                const int t = t0 + (int)lane;
+                if (t < N) {
+                    int dy = (int)((float)t * rW);
+                    int dx = t - dy * W;
+                    if (dx < 0) { --dy; dx += W; } else if (dx >= W) { ++dy; dx -= W; }
+                    f(X0 + dx, Y0 + dy, ((unsigned long long)khi << 32) | klo);
+                }
             }
         }
     }
@@ -403,7 +415,11 @@ struct BucketBinner {
         const unsigned int tid = threadIdx.x, lane = tid & 63u;
         tx0 = tx0_; tx1 = tx1_; ty0 = ty0_; ty1 = ty1_;
         w = tx1 - tx0 + 1; ntiles = vis ? w * (ty1 - ty0 + 1) : 0;
-        small = vis && ntiles <= AGG_MAX_TILES; big = vis && !small;
+        // Through the hashed table: every rectangle that fits its HASH_DIM x HASH_DIM window (512 x 512 pixels).  Only a
+        // splat wider or taller than that is a close-up for the slow path below.  (The limit used to be 64 tiles, one
+        // lane-spread round; at the C3 bench pose the 0.45 % of the Gaussians above it put 8 % of the pairs -- and three
+        // more barriers, a serial prefix and an exposed atomic round trip -- into most blocks: K1 0.169 -> 0.13 ms.)
+        small = vis && w <= HASH_DIM && (ty1 - ty0) < HASH_DIM; big = vis && !small;
         {   // block statistics and bounding box of the aggregated rectangles: wave reduce, LDS atomics by lane 0
             const unsigned int nv = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vis));
             const unsigned int ns = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(singular));
@@ -450,17 +466,26 @@ struct BucketBinner {
             for (int q = 0; q < NRES; ++q)
                 if (res[q] != 0xffffffffu) sh.table[(int)tid + 256 * q] = res[q];
             __syncthreads();
+#if SPLAT_K1X != 9
             each_tile(key, [&](int tx, int ty, unsigned long long k) {
                 const unsigned int slot = atomicAdd(&sh.table[hslot(tx, ty)], 1u);
+#if SPLAT_K1X == 7
+                if (slot == 0xfffffff0u) put((unsigned int)(ty * tiles_x + tx), slot, k);
+#else
                 put((unsigned int)(ty * tiles_x + tx), slot, k);
+#endif
             });
+#endif
         } else if (any) {
             each_tile(key, [&](int tx, int ty, unsigned long long k) {
                 const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
                 put(tile, atomicAdd(&gcount[tile], 1u), k);
             });
         }
-        // close-ups (more than AGG_MAX_TILES tiles): the whole block takes the tiles of each, one per thread
+        // close-ups (wider or taller than the table's window): the whole block takes the tiles of each, one per thread
+#if SPLAT_K1X == 6 || SPLAT_K1X == 7 || SPLAT_K1X == 9
+        return;
+#endif
         if (__syncthreads_or(big ? 1 : 0) == 0) return;
         if (big) add_big(sh, tx0, tx1, ty0, ty1, key);
         __syncthreads();
@@ -574,12 +599,27 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     bool singular = false, in_slab = false;
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
     float F[64];
+#if SPLAT_K1X == 4
+    if (i < n) {
+        float4 acc0 = make_float4(0, 0, 0, 0), acc1 = acc0, acc2 = acc0;
+#pragma unroll
+        for (int p = 0; p < LIVE_PLANES; ++p) {
+            float4 v = planes[(uint64_t)p * n + i];
+            if (p % 3 == 0) { acc0.x += v.x; acc0.y += v.y; acc0.z += v.z; acc0.w += v.w; }
+            else if (p % 3 == 1) { acc1.x += v.x; acc1.y += v.y; acc1.z += v.z; acc1.w += v.w; }
+            else { acc2.x += v.x; acc2.y += v.y; acc2.z += v.z; acc2.w += v.w; }
+        }
+        Rec r; r.a = acc0; r.b = acc1; r.c = acc2;
+        recs[i] = r;
+    }
+    return;
+#endif
     float cx = 0, cy = 0, hx = 0, hy = 0, ca = 0, cb = 0, cc = 0, zview = 0;
     if (i < n) {
         // geometry first: position, opacity, cov3d live in planes 0-3 (64 B); the SH planes are
         // only fetched for Gaussians that reach this context's slab
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < (SPLAT_K1X == 3 ? LIVE_PLANES : 4); ++p) {
             float4 v = planes[(uint64_t)p * n + i];
             F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
@@ -643,10 +683,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         }
     }
     std::conditional_t<BUCKET, BucketBinner, NoBinner> binner(sh, fc.tiles_x, counts, keys, fc.bucket_cap);
+#if SPLAT_K1X != 2 && SPLAT_K1X != 3
     if constexpr (BUCKET) binner.reserve(in_slab, singular, tx0, tx1, ty0, ty1, blockinfo);     // reservations in flight from here on
-    if (in_slab) {
+#endif
+    if (in_slab && SPLAT_K1X != 5) {
 #pragma unroll
-        for (int p = 4; p < LIVE_PLANES; ++p) {
+        for (int p = (SPLAT_K1X == 3 ? LIVE_PLANES : 4); p < LIVE_PLANES; ++p) {
             float4 v = planes[(uint64_t)p * n + i];
             F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
@@ -716,7 +758,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     }
     if constexpr (BUCKET) {
         const unsigned long long key = in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)(unsigned int)i) : 0ull;
+#if SPLAT_K1X == 0 || SPLAT_K1X >= 5
         binner.place(key);
+#else
+        if (key == 1ull) recs[0].a.x = 1.0f;    // keep `key` alive
+#endif
     } else {
         // compact the slots that reach the slab into vislist (K2 runs over those only)
         {
@@ -2160,7 +2206,7 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
 void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
                  FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max) {
-    if (!n_tiles) return;
+    if (!n_tiles || SPLAT_K1X) return;      // (K1 timing builds leave stale keys behind: nothing may walk them)
     const unsigned int radix_min = sort_radix_min();
     // longest class first (the tiles are ordered longest-first too)
     grid_big = std::min(grid_big, n_tiles); grid_mid = std::min(grid_mid, n_tiles);
@@ -2185,7 +2231,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
                       bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2) {
-    if (!n_tiles) return;
+    if (!n_tiles || SPLAT_K1X) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
     // SPLAT_COMP_LDS_PAD: extra dynamic LDS per workgroup, i.e. an occupancy cap (12 KB are in use:

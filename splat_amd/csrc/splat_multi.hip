@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +37,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -54,12 +56,16 @@ Rccl* rccl() {
             r.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
         }
-        if (!r.handle) { r.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return; }
+        if (!r.handle) {
+            const char* de = dlerror();        // (once: the call clears the error state)
+            r.error = std::string("cannot load RCCL: ") + (de ? de : "librccl.so.1 not found");
+            return;
+        }
 #define SPLAT_SYM(field, name)                                                                   \
     r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name));                         \
     if (!r.field && r.error.empty()) r.error = std::string("RCCL symbol missing: ") + name;
         SPLAT_SYM(GetUniqueId, "ncclGetUniqueId") SPLAT_SYM(CommInitRank, "ncclCommInitRank")
-        SPLAT_SYM(CommInitAll, "ncclCommInitAll") SPLAT_SYM(CommDestroy, "ncclCommDestroy")
+        SPLAT_SYM(CommInitAll, "ncclCommInitAll") SPLAT_SYM(CommDestroy, "ncclCommDestroy") SPLAT_SYM(CommAbort, "ncclCommAbort")
         SPLAT_SYM(GroupStart, "ncclGroupStart") SPLAT_SYM(GroupEnd, "ncclGroupEnd") SPLAT_SYM(Send, "ncclSend")
         SPLAT_SYM(Recv, "ncclRecv") SPLAT_SYM(GetErrorString, "ncclGetErrorString")
 #undef SPLAT_SYM
@@ -82,10 +88,13 @@ struct CommState {
     ncclComm_t comm = nullptr;
     int n_ranks = 0, rank = -1;
     std::vector<int32_t> slabs;      // n_ranks x {row0, row1}
+    std::atomic<bool> aborted{false}; // ncclCommAbort has run on `comm` (a peer could not take part in a gather): it
+                                      // is gone, later gathers fail instead of blocking
+    bool loopback = false;            // test hook (splat_comm_loopback): see splat_comm_gather
 };
 void comm_release(CommState* s) {
     if (!s) return;
-    if (s->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(s->comm);
+    if (s->comm && !s->aborted.load() && rccl()->CommDestroy) (void)rccl()->CommDestroy(s->comm);
     delete s;
 }
 }  // namespace splat
@@ -118,6 +127,41 @@ int gather_rows(splat_ctx* c, CommState* st, uint32_t* img, int w, int h, int ro
     if (e != ncclSuccess) return nccl_fail(c, "ncclSend/ncclRecv", e);
     if (e2 != ncclSuccess) return nccl_fail(c, "ncclGroupEnd", e2);
     return SPLAT_OK;
+}
+
+// Test hook: rank 0 of a one-rank communicator sends its slab rows to ITSELF through RCCL: the rows travel out of the
+// image into a scratch buffer (ncclSend / ncclRecv, same group, same stream), the image rows are then overwritten
+// with a marker and restored from the scratch copy -- so the caller can tell from the pixels that they went through
+// the wire and arrived intact, and a profile of the run shows RCCL's send/recv kernel.
+int loopback_rows(splat_ctx* c, CommState* st, uint32_t* img, int w, int h, hipStream_t stream) {
+    Rccl* R = rccl();
+    int a, b;
+    slab_px(&st->slabs[0], h, &a, &b);
+    if (b <= a) return SPLAT_OK;
+    const size_t count = (size_t)(b - a) * w;
+    uint32_t* scratch = nullptr;
+    if (hipMalloc(&scratch, count * 4) != hipSuccess) return ctx_fail(c, SPLAT_ERR_HIP, "hipMalloc(loopback scratch)");
+    int rc = SPLAT_OK;
+    ncclResult_t e = R->GroupStart();
+    if (e != ncclSuccess) rc = nccl_fail(c, "ncclGroupStart", e);
+    if (rc == SPLAT_OK) {
+        e = R->Send(img + (size_t)a * w, count, ncclUint32, 0, st->comm, stream);
+        ncclResult_t e1 = R->Recv(scratch, count, ncclUint32, 0, st->comm, stream);
+        ncclResult_t e2 = R->GroupEnd();
+        if (e != ncclSuccess) rc = nccl_fail(c, "ncclSend (loopback)", e);
+        else if (e1 != ncclSuccess) rc = nccl_fail(c, "ncclRecv (loopback)", e1);
+        else if (e2 != ncclSuccess) rc = nccl_fail(c, "ncclGroupEnd", e2);
+    }
+    if (rc == SPLAT_OK) {
+        hipError_t he = hipMemsetAsync(img + (size_t)a * w, 0x5a, count * 4, stream);             // marker: the rows are gone ...
+        if (he == hipSuccess) he = hipMemcpyAsync(img + (size_t)a * w, scratch, count * 4, hipMemcpyDeviceToDevice, stream);   // ... and back, from what RCCL delivered
+        if (he == hipSuccess) he = hipStreamSynchronize(stream);
+        if (he != hipSuccess) rc = ctx_fail(c, SPLAT_ERR_HIP, hipGetErrorString(he));
+    } else {
+        (void)hipStreamSynchronize(stream);
+    }
+    (void)hipFree(scratch);
+    return rc;
 }
 }  // namespace
 
@@ -224,9 +268,24 @@ int splat_comm_gather(splat_ctx* c, void* d_argb, int32_t w, int32_t h, int32_t 
     CommState* st = *ctx_comm_slot(c);
     if (!st || st->slabs.empty()) return ctx_fail(c, SPLAT_ERR_INVALID, "no communicator / partition on this context");
     if (!d_argb || w < 1 || h < 1 || root < 0 || root >= st->n_ranks) return ctx_fail(c, SPLAT_ERR_INVALID, "bad gather arguments");
-    if (st->n_ranks == 1) return SPLAT_OK;
+    if (st->aborted.load()) return ctx_fail(c, SPLAT_ERR_HIP, "the communicator was aborted after a rank failed; create it again");
     if (hipSetDevice(ctx_device(c)) != hipSuccess) return ctx_fail(c, SPLAT_ERR_HIP, "hipSetDevice");
+    // A single rank has nobody to exchange rows with ...
+    if (st->n_ranks == 1 && !st->loopback) return SPLAT_OK;
+    // ... unless the loopback hook is on: the rank then moves its own slab rows through RCCL to itself (ncclSend +
+    // ncclRecv to the own rank inside one group, which NCCL/RCCL permit), so that the very code path of the
+    // multi-rank gather -- group, send, receive, the RCCL kernel on the context's stream -- runs on a one-GPU box.
+    if (st->n_ranks == 1) return loopback_rows(c, st, (uint32_t*)d_argb, w, h, ctx_stream(c));
     return gather_rows(c, st, (uint32_t*)d_argb, w, h, root, ctx_stream(c));
+}
+
+int splat_comm_loopback(splat_ctx* c, int32_t on) {
+    if (!c) return SPLAT_ERR_INVALID;
+    CommState* st = *ctx_comm_slot(c);
+    if (!st) return ctx_fail(c, SPLAT_ERR_INVALID, "no communicator on this context");
+    if (st->n_ranks != 1) return ctx_fail(c, SPLAT_ERR_INVALID, "the loopback hook is for single-rank communicators");
+    st->loopback = on != 0;
+    return SPLAT_OK;
 }
 
 void splat_comm_destroy(splat_ctx* c) {
@@ -285,6 +344,7 @@ struct splat_multi {
     std::vector<std::unique_ptr<Worker>> w;
     std::vector<int32_t> slabs;
     bool peer = false;                // rows travel as device copies + events instead of RCCL
+    std::mutex abort_mu;
     int img_w = 0, img_h = 0;
     std::string err;
     uint64_t n_scene = 0;
@@ -297,11 +357,10 @@ int mfail(splat_multi* m, int code, const std::string& msg) {
     return code;
 }
 
-#define W_TRY(expr)                                                                      \
-    do {                                                                                 \
-        hipError_t _e = (expr);                                                          \
-        if (_e != hipSuccess) { note(SPLAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); return; } \
-    } while (0)
+// A rank that cannot take part in a gather (no image to send from / receive into) must not leave its peers blocked
+// in the grouped ncclSend / ncclRecv they have already enqueued: every communicator of the group is aborted (this
+// process owns them all), the kernels waiting on them end, and later gathers fail with a message instead of hanging.
+void abort_all_comms(splat_multi* m);
 
 void worker_main(splat_multi* m, Worker* me) {
     (void)hipSetDevice(me->device);
@@ -312,6 +371,10 @@ void worker_main(splat_multi* m, Worker* me) {
     auto check = [&](int rc, const char* what) {
         if (rc != SPLAT_OK) note(rc, std::string(what) + ": " + splat_last_error(me->ctx));
         return rc == SPLAT_OK;
+    };
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess) note(SPLAT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
     };
     auto ensure_image = [&](int w, int h) -> bool {
         const size_t px = (size_t)w * h;
@@ -341,14 +404,9 @@ void worker_main(splat_multi* m, Worker* me) {
         }
         (void)hipEventRecord(me->ev_rows, st);
     };
-    for (;;) {
-        Cmd c;
-        {
-            std::unique_lock<std::mutex> lk(me->mu);
-            me->cv.wait(lk, [&] { return !me->q.empty(); });
-            c = me->q.front();
-            me->q.pop_front();
-        }
+    // One command.  Every path through it ends in the bookkeeping below (done++): nothing in here may leave the
+    // thread -- drain(), sync_all_ranks and splat_multi_destroy wait for done == posted.
+    auto run = [&](const Cmd& c) {
         hipStream_t st = me->ctx ? (hipStream_t)splat_stream(me->ctx) : nullptr;
         switch (c.kind) {
             case CMD_STOP: break;
@@ -367,27 +425,26 @@ void worker_main(splat_multi* m, Worker* me) {
                 break;
             case CMD_FRAME: {
                 const int w = (int)c.cam.w, h = (int)c.cam.h;
-                if (!ensure_image(w, h)) break;
-                int a, b;
-                slab_px(&m->slabs[2 * me->rank], h, &a, &b);
+                if (!ensure_image(w, h)) { abort_all_comms(m); break; }      // (CMD_ALLOC made the images: not expected)
                 // color.clear(0) + render_to_buffer of src/main.rs:73-74, on this rank's rows only (the clear is fused
-                // into the compositor)
-                if (!check(splat_render_frame_device(me->ctx, &c.cam, me->img, 0, nullptr), "splat_render_frame_device")) break;
+                // into the compositor).  A render that failed still takes part in the gather -- the peers have
+                // enqueued their halves of it -- with whatever its rows hold; the error is reported by the sync.
+                (void)check(splat_render_frame_device(me->ctx, &c.cam, me->img, 0, nullptr), "splat_render_frame_device");
                 gather(w, h);
                 break;
             }
             case CMD_RENDER_HOST: {
                 const int w = (int)c.cam.w, h = (int)c.cam.h;
-                if (!ensure_image(w, h)) break;
+                if (!ensure_image(w, h)) { abort_all_comms(m); break; }
                 int a, b;
                 slab_px(&m->slabs[2 * me->rank], h, &a, &b);
                 const size_t off = (size_t)a * w, bytes = (size_t)std::max(0, b - a) * w * 4;
                 // the slab's rows of the caller's in/out image; the render is synchronous so that a frame that
                 // outgrew its storage is redone here (splat_render_device retries its own frame)
-                if (bytes) W_TRY(hipMemcpyAsync(me->img + off, c.host + off, bytes, hipMemcpyHostToDevice, st));
+                if (bytes) (void)hip_ok(hipMemcpyAsync(me->img + off, c.host + off, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync(slab rows in)");
                 std::memset(&me->stats, 0, sizeof me->stats);
-                if (!check(splat_render_device(me->ctx, &c.cam, me->img, 1, c.want_stats ? &me->stats : nullptr), "splat_render_device")) break;
-                gather(w, h);
+                (void)check(splat_render_device(me->ctx, &c.cam, me->img, 1, c.want_stats ? &me->stats : nullptr), "splat_render_device");
+                gather(w, h);        // (also after a failure: see CMD_FRAME)
                 break;
             }
             case CMD_SYNC: {
@@ -397,6 +454,16 @@ void worker_main(splat_multi* m, Worker* me) {
                 break;
             }
         }
+    };
+    for (;;) {
+        Cmd c;
+        {
+            std::unique_lock<std::mutex> lk(me->mu);
+            me->cv.wait(lk, [&] { return !me->q.empty(); });
+            c = me->q.front();
+            me->q.pop_front();
+        }
+        run(c);
         {
             std::lock_guard<std::mutex> g(me->mu);
             me->done++;
@@ -405,7 +472,16 @@ void worker_main(splat_multi* m, Worker* me) {
         if (c.kind == CMD_STOP) return;
     }
 }
-#undef W_TRY
+
+void abort_all_comms(splat_multi* m) {
+    if (m->peer) return;
+    std::lock_guard<std::mutex> g(m->abort_mu);
+    for (auto& w : m->w) {
+        CommState* st = *ctx_comm_slot(w->ctx);
+        if (!st || !st->comm || st->aborted.exchange(true)) continue;
+        if (rccl()->CommAbort) (void)rccl()->CommAbort(st->comm);
+    }
+}
 
 void post(Worker* w, const Cmd& c) {
     {
@@ -529,12 +605,20 @@ int splat_multi_balance(splat_multi* m, const splat_camera* cam) {
     int rc = sync_all_ranks(m);
     if (rc != SPLAT_OK) return rc;
     const int k = (int)m->w.size();
-    if (!cam) return mfail(m, SPLAT_ERR_INVALID, "camera is NULL (its height fixes the tile rows)");
+    // cam == NULL: equal slabs for the target size of the last partition (a camera is needed once: its height fixes
+    // the number of tile rows)
+    splat_camera eq{};
+    const bool equal = cam == nullptr;
+    if (equal) {
+        if (m->img_h < 1) return mfail(m, SPLAT_ERR_INVALID, "camera is NULL and no frame size is known yet (its height fixes the tile rows)");
+        eq.w = (float)m->img_w; eq.h = (float)m->img_h;
+        cam = &eq;
+    }
     const int n_rows = ((int)cam->h + TILE - 1) / TILE;
     if (n_rows < 1) return mfail(m, SPLAT_ERR_INVALID, "bad camera height");
     std::vector<uint64_t> loads((size_t)n_rows, 0);
     bool have_loads = false;
-    if (m->n_scene && k > 1) {
+    if (m->n_scene && k > 1 && !equal) {
         Cmd c; c.kind = CMD_LOADS; c.cam = *cam; c.row_pairs = loads.data(); c.n_rows = n_rows;
         post(m->w[0].get(), c);
         rc = drain(m);
@@ -549,7 +633,9 @@ int splat_multi_balance(splat_multi* m, const splat_camera* cam) {
     post_all(m, c);
     c.kind = CMD_ALLOC; c.cam = *cam;
     post_all(m, c);
-    return drain(m);
+    rc = drain(m);
+    if (rc != SPLAT_OK) { m->img_w = 0; m->img_h = 0; }      // (the next frame partitions -- and allocates -- again)
+    return rc;
 }
 
 int splat_multi_get_slabs(const splat_multi* m, int32_t* out) {

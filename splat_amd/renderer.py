@@ -124,6 +124,10 @@ class Renderer:
         flat = (C.c_int32 * (2 * len(slabs)))(*[int(v) for s in slabs for v in s])
         self._check(self._L.splat_comm_set_slabs(self._h, flat))
 
+    def comm_loopback(self, on=True):
+        """test hook: a single-rank communicator's gather sends this rank's rows through RCCL to itself"""
+        self._check(self._L.splat_comm_loopback(self._h, 1 if on else 0))
+
     def comm_gather(self, d_ptr, w, h, root=0):
         """enqueue the gather of slab rows to `root` on the context's stream (grouped ncclSend / ncclRecv)"""
         self._check(self._L.splat_comm_gather(self._h, C.c_void_p(d_ptr), int(w), int(h), int(root)))

@@ -113,6 +113,53 @@ def test_comm_single_rank_over_rccl():
 
 
 @pytest.mark.gpu
+def test_rccl_send_recv_really_runs_in_the_single_rank_loopback():
+    """with one rank the gather returned before ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd
+    ever ran, on any hardware.  The loopback hook sends this rank's slab rows through RCCL to itself (send + recv to the
+    own rank in one group, on the context's stream), overwrites the image rows with a marker and restores them from
+    what RCCL delivered: the frame must come back byte for byte -- and the marker must NOT (it would if the receive
+    had delivered nothing).  Run under rocprofv3 --kernel-trace the log shows RCCL's kernel (profiles/r04_rccl_loopback*)."""
+    g = splat_amd.synthetic_scene(20000, 35)
+    R = splat_amd.Renderer()
+    try:
+        g.compute_cov3d(R)
+        R.upload(g)
+        cam_c = make_camera(200, 320).to_c(0.01)          # 13 tile rows, the last one 8 px high
+        rng = np.random.default_rng(9)
+        init = rng.integers(0, 2**32, (200, 320), dtype=np.uint64).astype(np.uint32)
+        ref = init.copy()
+        R.render(cam_c, ref)
+        R.comm_init(splat_amd.Renderer.comm_unique_id(), 1, 0)
+        R.comm_set_slabs([(0, 13)])
+        with pytest.raises(splat_amd.SplatError):
+            R.comm_gather(0, 320, 200, 0)                 # NULL image: argument check comes first
+        R.comm_loopback(True)
+        d = R.device_image(init)
+        R.render_device(cam_c, d)
+        R.comm_gather(d, 320, 200, 0)                     # ncclGroupStart, ncclSend, ncclRecv, ncclGroupEnd on the context's stream
+        R.sync()
+        got = R.device_download(d, 200, 320)
+        assert np.array_equal(got, ref)
+        assert not (got == 0x5a5a5a5a).all()
+        # a thinner slab: only its rows travel
+        R.comm_set_slabs([(3, 7)])
+        R.render_device(cam_c, d)                         # blends the slab's rows a second time: compare with the same on the host
+        R.comm_gather(d, 320, 200, 0)
+        R.sync()
+        ref2 = ref.copy()
+        R.comm_loopback(False)
+        d2 = R.device_image(ref)
+        R.render_device(cam_c, d2)
+        R.comm_gather(d2, 320, 200, 0)                    # single rank, hook off: nothing to exchange
+        R.sync()
+        assert np.array_equal(R.device_download(d, 200, 320), R.device_download(d2, 200, 320))
+        assert np.array_equal(ref2[:48], R.device_download(d2, 200, 320)[:48])      # rows outside the slab untouched
+        R.device_free(d); R.device_free(d2)
+    finally:
+        R.close()
+
+
+@pytest.mark.gpu
 def test_fuzzed_partitions_and_pose_sequences_equal_the_single_context():
     """tools/fuzz_multi.py, 12 seeds: random scenes, target sizes, 1..6 ranks sharing this GPU, balanced and equal slabs,
     host in/out frames onto a random image, viewer-loop frames queued back to back over changing poses (a slab skipped

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Pin kit, oracle side: which euc conventions reproduce the reference's own frames?
+
+    python tools/pin_euc.py DIR            # DIR holds the dumps written by rust/examples/dump_frames.rs
+    python tools/pin_euc.py --write-c1 c1.ply      # the 10k synthetic C1 scene as an INRIA PLY, for dump_frames' 4th frame
+    python tools/pin_euc.py --selftest     # dumps made by the oracle itself under a hidden setting must be identified
+
+Every frame is rendered by oracle/ (CPU, test infrastructure) under all 2 x 2 x 2 x 2 settings of
+(y_up, sample_half, z-clip [0,1] | [-1,1], analytic rectangle | two-triangle raster) and compared with the dump:
+max per-channel difference and number of differing pixels.  The row with (0, 0) -- or, through the last place of
+expf / barycentric rounding, (1, a handful) -- is euc's behaviour; it becomes orc_default_conventions and
+splat_default_config.  Nothing here needs a GPU.  UNTESTED against real dumps: no Rust toolchain in the authoring
+image (rust/README.md); --selftest keeps the comparison logic honest."""
+import itertools
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np  # noqa: E402
+
+import splat_amd  # noqa: E402
+from splat_amd import gaussians as G  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from helpers import scene_dict, oracle_camera, image_diff  # noqa: E402
+
+
+def naive_scene():
+    g = splat_amd.naive_gaussians()
+    g.cov3d = O.compute_cov3d(g.scales, g.rotations)          # compute_cov3d, src/main.rs:24-26 / from_vec
+    return g
+
+
+def frames(c1_ply=None):
+    """name -> (scene, camera, lowpass, (h, w)): the frames rust/examples/dump_frames.rs writes"""
+    out = {}
+    cam = splat_amd.Camera(600, 800, (0.0, 0.0, 5.0)); cam.update_camera_pose()
+    out["naive_800x600_p01.raw"] = (naive_scene(), cam, 0.01, (600, 800))
+    cam = splat_amd.Camera(720, 1280, (-0.57651054, 2.99040512, -0.03924271))       # matrices stay identity (Q20)
+    out["naive_1280x720_p01_identity.raw"] = (naive_scene(), cam, 0.01, (720, 1280))
+    cam = splat_amd.Camera(720, 1280, (0.0, 0.0, 3.0)); cam.update_camera_pose()
+    out["naive_1280x720_p02.raw"] = (naive_scene(), cam, 0.3, (720, 1280))
+    if c1_ply and os.path.exists(c1_ply):
+        s = O.load_ply(c1_ply)
+        g = G.GaussianList(s["pos4"], s["scales"], s["opacity"], s["rot"], s["sh"])
+        g.cov3d = O.compute_cov3d(g.scales, g.rotations)
+        cam = splat_amd.Camera(256, 256, (0.0, 0.0, 5.0)); cam.update_camera_pose()
+        out["c1_256x256_p01.raw"] = (g, cam, 0.01, (256, 256))
+    return out
+
+
+SETTINGS = [dict(y_up=y, sample_half=s, zclip=1, zmin=z, zmax=1.0, raster=r)
+            for y, s, z, r in itertools.product((1, 0), (1, 0), (0.0, -1.0), (0, 1))]
+
+
+def label(k):
+    return "y_up=%d sample_half=%d zclip=[%g,1] raster=%s" % (k["y_up"], k["sample_half"], k["zmin"], "2-triangle" if k["raster"] else "rectangle")
+
+
+def render(scene, cam, lowpass, conv):
+    img, _ = O.render(scene_dict(scene), oracle_camera(cam, lowpass), O.default_conventions(**conv), nthreads=os.cpu_count() or 1)
+    return img
+
+
+def compare(dump_dir, c1_ply=None, out=sys.stdout):
+    """-> {frame: [(max diff, differing pixels, setting), ...] best first}"""
+    results = {}
+    for name, (scene, cam, lowpass, (h, w)) in frames(c1_ply).items():
+        path = os.path.join(dump_dir, name)
+        if not os.path.exists(path):
+            out.write("%-34s (no dump)\n" % name)
+            continue
+        ref = np.fromfile(path, "<u4")
+        if ref.size != h * w:
+            out.write("%-34s wrong size: %d pixels, expected %d\n" % (name, ref.size, h * w))
+            continue
+        ref = ref.reshape(h, w)
+        rows = []
+        for k in SETTINGS:
+            mx, cnt = image_diff(render(scene, cam, lowpass, k), ref)
+            rows.append((mx, cnt, k))
+        rows.sort(key=lambda r: (r[1], r[0]))
+        results[name] = rows
+        out.write("%s  (%d x %d, %d non-zero pixels in the dump)\n" % (name, w, h, int((ref != 0).sum())))
+        for mx, cnt, k in rows:
+            out.write("    max diff %3d  pixels differing %8d   %s\n" % (mx, cnt, label(k)))
+    if results:
+        votes = {}
+        for rows in results.values():
+            votes[label(rows[0][2])] = votes.get(label(rows[0][2]), 0) + 1
+        out.write("best setting per frame: %s\n" % votes)
+    return results
+
+
+def selftest():
+    """the oracle's own frames under a hidden setting, written as dumps, must come back as that setting"""
+    hidden = dict(y_up=0, sample_half=1, zclip=1, zmin=-1.0, zmax=1.0, raster=1)
+    with tempfile.TemporaryDirectory() as d:
+        c1 = os.path.join(d, "c1.ply")
+        G.write_ply(c1, G.synthetic_raw(2000, 1), 2000)
+        for name, (scene, cam, lowpass, _) in frames(c1).items():
+            render(scene, cam, lowpass, hidden).astype("<u4").tofile(os.path.join(d, name))
+        res = compare(d, c1, out=open(os.devnull, "w"))
+    ok = len(res) == 4
+    for name, rows in res.items():
+        mx, cnt, k = rows[0]
+        same = all(k[f] == hidden[f] for f in ("y_up", "sample_half", "zmin", "raster")) or (mx, cnt) == (0, 0)
+        ok &= (mx, cnt) == (0, 0) and same
+        print("%-34s -> %s  (max %d, %d px)" % (name, label(k), mx, cnt))
+    print("selftest", "ok" if ok else "FAILED")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    if a[:1] == ["--write-c1"]:
+        G.write_ply(a[1], G.synthetic_raw(10000, 1), 10000)
+        print("wrote", a[1])
+    elif a[:1] == ["--selftest"]:
+        sys.exit(selftest())
+    elif a:
+        compare(a[0], a[1] if len(a) > 1 else os.path.join(a[0], "c1.ply"))
+    else:
+        sys.exit(__doc__)
