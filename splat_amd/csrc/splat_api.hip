@@ -295,11 +295,11 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens);
         HIP_TRY(c, hipMalloc(&s.lens, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, hipMalloc(&s.counts, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, hipMalloc(&s.counts, sizeof(unsigned int) * (size_t)(m + 1) * (SPLAT_K1X ? 8 : 1)));
         HIP_TRY(c, hipMalloc(&s.offsets, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, hipMalloc(&s.cursor, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, hipMalloc(&s.order, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, hipMemset(s.counts, 0, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, hipMemset(s.counts, 0, sizeof(unsigned int) * (size_t)(m + 1) * (SPLAT_K1X ? 8 : 1)));
     }
     c->m_alloc = m + 1;
     return SPLAT_OK;
@@ -1154,6 +1154,19 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     }
     return SPLAT_OK;
 }
+
+#if SPLAT_K1X == 30 || SPLAT_K1X == 31
+int splat_debug_k1_stamps(splat_ctx* c, unsigned long long* out, unsigned long long n_words) {
+    if (!c || c->last_slot < 0) return SPLAT_ERR_INVALID;
+    (void)sync_all(c);
+    return hipMemcpy(out, c->slots[c->last_slot].depth, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? SPLAT_OK : SPLAT_ERR_HIP;
+}
+int splat_debug_k1_hwid(splat_ctx* c, unsigned long long* out, unsigned long long n_words) {
+    if (!c || c->last_slot < 0) return SPLAT_ERR_INVALID;
+    (void)sync_all(c);
+    return hipMemcpy(out, c->slots[c->last_slot].rect, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? SPLAT_OK : SPLAT_ERR_HIP;
+}
+#endif
 
 int64_t splat_binning_mode(splat_ctx* c) {
     if (!c || c->last_slot < 0) return -1;

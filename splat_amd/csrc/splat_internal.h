@@ -6,6 +6,10 @@
 
 #include "../../include/splat_hip.h"
 
+#ifndef SPLAT_K1X
+#define SPLAT_K1X 0      // K1 timing experiments (tools/k1_ab.py); 0 = the product
+#endif
+
 namespace splat {
 
 constexpr int TILE = SPLAT_TILE;

@@ -15,10 +15,6 @@
 
 #include "splat_internal.h"
 
-#ifndef SPLAT_K1X
-#define SPLAT_K1X 0      // K1 timing experiments (tools/k1_ab.sh); 0 = the product
-#endif
-
 namespace splat {
 
 // ---------------------------------------------------------------------------
@@ -361,22 +357,34 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
 // K1 evaluates the SH colour and writes the record in between: the round trip to the memory-side atomic
 // unit (a third of a block's life when it was waited for on the spot) hides under the SH planes' loads.
 // The caller has run bin_preinit() and a barrier.
+// Workspace of the flattened tile expansion (per wave): see BucketBinner::flat_count.
+constexpr int FLAT_CAP = 512;              // (Gaussian, tile) pairs of one wave that go through it (a wave of C3 has ~350)
+struct FlatShared {
+    unsigned int mark[4][FLAT_CAP / 4];    // bytes: where a source lane's run of tiles begins (value = lane + 1)
+    unsigned short exp[4][FLAT_CAP];       // per pair: table slot | source lane << 10, written by the count pass for the hand-out pass
+};
+
 struct BucketBinner {
     static constexpr int LANE_T = 9;       // see bin_block
     static constexpr int NRES = HASH_CAP / 256;
     BucketShared& sh;
+    FlatShared& fs;
     const int tiles_x;
     unsigned int* __restrict__ const gcount;
     unsigned long long* __restrict__ const keys;
     const unsigned int bcap;
+    unsigned int xstride = 0;
+    unsigned long long* dbg_stamps = nullptr;
     // this thread's rectangle
     int tx0, tx1, ty0, ty1, w, ntiles;
     bool small, big, hashed, any;
+    bool serial;                           // a small rectangle that did not fit the wave's flattened expansion
+    unsigned int flat_total;               // pairs of this wave in the flattened expansion (wave-uniform)
     int bx0, by0;
     unsigned int res[NRES];                // reservations in flight: bucket position of the block's run, per table slot
 
-    __device__ __forceinline__ BucketBinner(BucketShared& s, int tiles_x_, unsigned int* g, unsigned long long* k, unsigned int cap)
-        : sh(s), tiles_x(tiles_x_), gcount(g), keys(k), bcap(cap) {}
+    __device__ __forceinline__ BucketBinner(BucketShared& s, FlatShared& f, int tiles_x_, unsigned int* g, unsigned long long* k, unsigned int cap)
+        : sh(s), fs(f), tiles_x(tiles_x_), gcount(g), keys(k), bcap(cap) {}
     __device__ __forceinline__ static unsigned int hslot(int tx, int ty) { return (unsigned int)(((ty & (HASH_DIM - 1)) << HASH_BITS) | ((tx + 17 * ty) & (HASH_DIM - 1))); }
     __device__ __forceinline__ void put(unsigned int tile, unsigned int slot, unsigned long long k) const {
         if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
@@ -384,12 +392,12 @@ struct BucketBinner {
     // f(tx, ty, key) for every tile of the thread's aggregated rectangle (see bin_block's each_tile).  Rectangles of
     // more than LANE_T tiles are spread over the lanes of their wave, 64 tiles per round.
     template <typename F>
-    __device__ __forceinline__ void each_tile(unsigned long long key, F f) const {
+    __device__ __forceinline__ void each_tile(bool mine, unsigned long long key, F f) const {
         const unsigned int lane = threadIdx.x & 63u;
-        if (small && ntiles <= LANE_T)
+        if (mine && ntiles <= LANE_T)
             for (int ty = ty0; ty <= ty1; ++ty)
                 for (int tx = tx0; tx <= tx1; ++tx) f(tx, ty, key);
-        unsigned long long m = __builtin_amdgcn_ballot_w64(small && ntiles > LANE_T);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(mine && ntiles > LANE_T);
         while (m) {
             const int src = __builtin_ctzll(m);
             m &= m - 1ull;
@@ -410,8 +418,76 @@ struct BucketBinner {
             }
         }
     }
-    __device__ __forceinline__ void reserve(bool vis, bool singular, int tx0_, int tx1_, int ty0_, int ty1_,
-                                            unsigned int* __restrict__ blockinfo) {
+    // The tiles of the wave's small rectangles as ONE index space, 64 per step with every lane busy: pair f belongs to
+    // the source lane whose run [P, P + ntiles) contains it.  (Rectangle by rectangle -- a lane walking its own up to
+    // nine tiles while its neighbours with three wait, then one step per larger rectangle with a fifth of the lanes
+    // active -- a wave took ~25 steps per pass where its ~350 pairs fill six; the two passes over the table were 20 k of
+    // a block's 53 k cycles.)  The source of f: every source lane marks the first index of its run (a byte in LDS);
+    // within a step the lanes find the latest mark at or before their index with a ballot, a carry links the steps.
+    // flat_count adds the pairs to the table and leaves (slot, source lane) per pair for flat_handout, which hands
+    // out the positions and stores the keys.  Runs that end beyond FLAT_CAP take the rectangle-by-rectangle path.
+    __device__ __forceinline__ void flat_count() {
+        const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const unsigned int n = small ? (unsigned int)ntiles : 0u;
+        unsigned int inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = (unsigned int)__shfl_up((int)inc, o);
+            if ((int)lane >= o) inc += t;
+        }
+        const bool flat = n != 0u && inc <= (unsigned int)FLAT_CAP;
+        serial = n != 0u && !flat;
+        const unsigned long long fm = __builtin_amdgcn_ballot_w64(flat);
+        flat_total = fm ? (unsigned int)__builtin_amdgcn_readlane((int)inc, 63 - __builtin_clzll(fm)) : 0u;
+        if (flat_total == 0u) return;
+        const unsigned int P = inc - n;
+        unsigned char* const mark = reinterpret_cast<unsigned char*>(fs.mark[wave]);
+        fs.mark[wave][lane] = 0u; fs.mark[wave][lane + 64u] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (flat) mark[P] = (unsigned char)(lane + 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int pack = tx0 | (ty0 << 12) | ((w - 1) << 24);     // tile coordinates < 4096 (65535 / 16), w <= HASH_DIM
+        int carry = 0;
+        for (unsigned int base = 0; base < flat_total; base += 64u) {
+            const unsigned int f = base + lane;
+            const int m = f < flat_total ? (int)mark[f] : 0;
+            const unsigned long long q = __builtin_amdgcn_ballot_w64(m != 0) & ((2ull << lane) - 1ull);
+            const int at = q ? 63 - __builtin_clzll(q) : 0;
+            const int sm = __builtin_amdgcn_ds_bpermute(at << 2, m);
+            const int src = q ? sm - 1 : carry;
+            carry = __builtin_amdgcn_readlane(src, 63);
+            const int Ps = __builtin_amdgcn_ds_bpermute(src << 2, (int)P), pk = __builtin_amdgcn_ds_bpermute(src << 2, pack);
+            const int t = (int)f - Ps, W = (pk >> 24) + 1;
+            int dy = (int)((float)t * __builtin_amdgcn_rcpf((float)W));      // (t < 1024, W <= 32: exact after the one-step correction)
+            int dx = t - dy * W;
+            if (dx < 0) { --dy; dx += W; } else if (dx >= W) { ++dy; dx -= W; }
+            const unsigned int slot = hslot((pk & 0xfff) + dx, ((pk >> 12) & 0xfff) + dy);
+            if (f < flat_total) {
+                atomicAdd(&sh.table[slot], 1u);
+                fs.exp[wave][f] = (unsigned short)(slot | ((unsigned int)src << 10));
+            }
+        }
+    }
+    // (hashed blocks only: the table slot names the tile)
+    __device__ __forceinline__ void flat_handout(unsigned long long key) const {
+        const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const unsigned int i0 = blockIdx.x * 256u + (threadIdx.x & ~63u);     // scene slot of the wave's lane 0 (a key's low half is its thread's slot)
+        for (unsigned int base = 0; base < flat_total; base += 64u) {
+            const unsigned int f = base + lane;
+            const unsigned int e = f < flat_total ? (unsigned int)fs.exp[wave][f] : 0u;
+            const unsigned int slot = e & (unsigned int)(HASH_CAP - 1), src = e >> 10;
+            const unsigned int khi = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(unsigned int)(key >> 32));
+            if (f < flat_total) {
+                const unsigned int pos = atomicAdd(&sh.table[slot], 1u);
+                const int ty = by0 + ((((int)slot >> HASH_BITS) - by0) & (HASH_DIM - 1));
+                const int tx = bx0 + ((((int)slot & (HASH_DIM - 1)) - 17 * ty - bx0) & (HASH_DIM - 1));
+                put((unsigned int)(ty * tiles_x + tx), pos, ((unsigned long long)khi << 32) | (unsigned long long)(i0 + src));
+            }
+        }
+    }
+    __device__ __forceinline__ void count(bool vis, bool singular, int tx0_, int tx1_, int ty0_, int ty1_) {
         const unsigned int tid = threadIdx.x, lane = tid & 63u;
         tx0 = tx0_; tx1 = tx1_; ty0 = ty0_; ty1 = ty1_;
         w = tx1 - tx0 + 1; ntiles = vis ? w * (ty1 - ty0 + 1) : 0;
@@ -435,8 +511,15 @@ struct BucketBinner {
                 if (c >= 0) { atomicMin(&sh.box[0], a); atomicMin(&sh.box[1], b); atomicMax(&sh.box[2], c); atomicMax(&sh.box[3], d); }
             }
         }
-        each_tile(0ull, [&](int tx, int ty, unsigned long long) { atomicAdd(&sh.table[hslot(tx, ty)], 1u); });
+        flat_count();
+        each_tile(serial, 0ull, [&](int tx, int ty, unsigned long long) { atomicAdd(&sh.table[hslot(tx, ty)], 1u); });
+    }
+    __device__ __forceinline__ void issue(unsigned int* __restrict__ blockinfo) {
+        const unsigned int tid = threadIdx.x;
         __syncthreads();
+#if SPLAT_K1X == 21
+        __syncthreads();
+#endif
         bx0 = sh.box[0]; by0 = sh.box[1];
         any = sh.box[2] >= 0;
         hashed = any && (sh.box[2] - bx0) < HASH_DIM && (sh.box[3] - by0) < HASH_DIM;
@@ -446,28 +529,61 @@ struct BucketBinner {
 #pragma unroll
         for (int q = 0; q < NRES; ++q) res[q] = 0xffffffffu;
         if (hashed) {
-            // reserve every touched tile's run in its bucket: one returning global atomic per (block, tile)
+            // reserve every touched tile's run in its bucket: one returning global atomic per (block, tile).
+            // All counts and addresses first, THEN the atomics back to back: interleaved, the register allocator put a
+            // result register next to the 64-bit operand of the following slot's address arithmetic, and the hardware
+            // waited out the first atomic's round trip (s_waitcnt vmcnt(0)) before it could issue the second -- two
+            // serialised memory round trips per block in front of the SH loads.
+            unsigned int cnt[NRES];
+            unsigned long long addr[NRES];
 #pragma unroll
             for (int q = 0; q < NRES; ++q) {
                 const int e = (int)tid + 256 * q;
-                const unsigned int c = sh.table[e];
-                if (c) {
-                    const int ty = by0 + (((e >> HASH_BITS) - by0) & (HASH_DIM - 1));
-                    const int tx = bx0 + (((e & (HASH_DIM - 1)) - 17 * ty - bx0) & (HASH_DIM - 1));
-                    res[q] = atomicAdd(&gcount[(unsigned int)(ty * tiles_x + tx)], c);
-                }
+                cnt[q] = sh.table[e];
+                const int ty = by0 + (((e >> HASH_BITS) - by0) & (HASH_DIM - 1));
+                const int tx = bx0 + (((e & (HASH_DIM - 1)) - 17 * ty - bx0) & (HASH_DIM - 1));
+                addr[q] = (unsigned long long)(gcount + (unsigned int)(ty * tiles_x + tx));     // (only dereferenced where cnt != 0)
             }
-        }
-    }
-    __device__ __forceinline__ void place(unsigned long long key) {
-        const unsigned int tid = threadIdx.x;
-        if (hashed) {
+            static_assert(NRES == 4, "the scheduling fence below names four addresses");
+            asm volatile("" : "+v"(addr[0]), "+v"(addr[1]), "+v"(addr[2]), "+v"(addr[3]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]), "+v"(cnt[3]));
 #pragma unroll
             for (int q = 0; q < NRES; ++q)
-                if (res[q] != 0xffffffffu) sh.table[(int)tid + 256 * q] = res[q];
+                if (cnt[q] && SPLAT_K1X != 23)     // (a global-address-space pointer: through a generic one this is a FLAT atomic, which every later LDS wait would wait for)
+                    res[q] = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned int*)addr[q], cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // place() in two steps, so that the caller can put its record store between them: publish() waits for the
+    // reservations (issued before the SH planes' loads, so they have arrived when those have) and hands them to the
+    // block through the table; a store issued BEFORE that wait would have to complete first (gfx9 counts loads,
+    // atomics and stores in one counter).
+    __device__ __forceinline__ void publish() {
+#if SPLAT_K1X == 1 || SPLAT_K1X == 16 || SPLAT_K1X == 21 || SPLAT_K1X == 23 || SPLAT_K1X == 24
+        return;
+#endif
+        if (hashed) {
+#pragma unroll
+            for (int q = 0; q < NRES; ++q) sh.table[(int)threadIdx.x + 256 * q] = res[q];     // (slots nobody touched are never read)
+        }
+    }
+    template <typename AFTER>
+    __device__ __forceinline__ void place(unsigned long long key, AFTER after_barrier) {
+#if SPLAT_K1X == 17
+        after_barrier();
+        return;
+#endif
+        if (hashed) {
+#if SPLAT_K1X == 24
+            __builtin_amdgcn_s_barrier();
+#else
             __syncthreads();
-#if SPLAT_K1X != 9
-            each_tile(key, [&](int tx, int ty, unsigned long long k) {
+#endif
+            after_barrier();
+#if SPLAT_K1X == 16 || SPLAT_K1X == 23 || SPLAT_K1X == 24
+            return;
+#endif
+#if SPLAT_K1X != 9 && SPLAT_K1X != 12
+            flat_handout(key);
+            each_tile(serial, key, [&](int tx, int ty, unsigned long long k) {
                 const unsigned int slot = atomicAdd(&sh.table[hslot(tx, ty)], 1u);
 #if SPLAT_K1X == 7
                 if (slot == 0xfffffff0u) put((unsigned int)(ty * tiles_x + tx), slot, k);
@@ -476,14 +592,16 @@ struct BucketBinner {
 #endif
             });
 #endif
-        } else if (any) {
-            each_tile(key, [&](int tx, int ty, unsigned long long k) {
-                const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
-                put(tile, atomicAdd(&gcount[tile], 1u), k);
-            });
+        } else {
+            after_barrier();
+            if (any)
+                each_tile(small, key, [&](int tx, int ty, unsigned long long k) {
+                    const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
+                    put(tile, atomicAdd(&gcount[tile], 1u), k);
+                });
         }
         // close-ups (wider or taller than the table's window): the whole block takes the tiles of each, one per thread
-#if SPLAT_K1X == 6 || SPLAT_K1X == 7 || SPLAT_K1X == 9
+#if SPLAT_K1X == 6 || SPLAT_K1X == 7 || SPLAT_K1X == 9 || SPLAT_K1X == 12
         return;
 #endif
         if (__syncthreads_or(big ? 1 : 0) == 0) return;
@@ -572,12 +690,32 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                                          unsigned int* __restrict__ blockinfo,
                                                          FrameStatus* __restrict__ status) {
     __shared__ std::conditional_t<BUCKET, BucketShared, BinShared> sh;
+    __shared__ std::conditional_t<BUCKET, FlatShared, unsigned int> fsh;
     __shared__ unsigned int swave[4];
     __shared__ unsigned int sbase, sreach;
     // K1 is a chain of dependent phases with little arithmetic in each; beside the compositor's
     // throughput-bound waves every one of its instructions queued behind theirs.  One priority step above the
     // compositor's default: K1 0.38 -> 0.32 ms inside the pipeline, +4 % frames/s on C3.
     __builtin_amdgcn_s_setprio(1);
+#if SPLAT_K1X == 30 || SPLAT_K1X == 31
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(depth) + ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u;
+#define STAMP_(k) do { if ((threadIdx.x & 63u) == 0u) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP_(k) do { } while (0)
+#endif
+#if SPLAT_K1X == 31
+#define STAMP(k) do { if ((k) == 0) STAMP_(0); else if ((k) == 1) STAMP_(4); else if ((k) == 2) STAMP_(5); else if ((k) == 4) STAMP_(6); else if ((k) == 7) STAMP_(7); } while (0)
+#define STAMPF(k) STAMP_(k)
+#else
+#define STAMP(k) STAMP_(k)
+#define STAMPF(k) do { } while (0)
+#endif
+    STAMP(0);
+#if SPLAT_K1X == 30 || SPLAT_K1X == 31
+    if ((threadIdx.x & 63u) == 0u)      // HW_REG_HW_ID (id 4), all 32 bits; HW_REG_XCC_ID (id 20)
+        reinterpret_cast<unsigned long long*>(rect)[(size_t)blockIdx.x * 4u + (threadIdx.x >> 6)] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     if constexpr (BUCKET) {
         // Block culling rides on the barrier the table reset needs anyway: wave 0 alone runs the bounds test (a
         // few hundred instructions that used to be issued by all four waves) while the others clear the table.
@@ -590,6 +728,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         bin_preinit(sh);
         __syncthreads();
         if (fc.cull_blocks && sreach == 0u) return;          // whole block off this context's slab / target: nothing to read
+        STAMPF(1);
     } else if (fc.cull_blocks) {
         const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
         if (threadIdx.x == 0) blockinfo[blockIdx.x] = reach ? 0u : 0x80000000u;
@@ -618,12 +757,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     if (i < n) {
         // geometry first: position, opacity, cov3d live in planes 0-3 (64 B); the SH planes are
         // only fetched for Gaussians that reach this context's slab
+        // (requesting them before the table reset / culling test / barrier of the prologue, so that its ~8 k cycles run
+        // under the loads' flight: measured twice, rounds 2 and 3 -- no gain, 0.147 -> 0.149 ms)
 #pragma unroll
         for (int p = 0; p < (SPLAT_K1X == 3 ? LIVE_PLANES : 4); ++p) {
             float4 v = planes[(uint64_t)p * n + i];
             F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
         const float px = F[0], py = F[1], pz = F[2];
+        asm volatile("" : "+v"(F[12]));
+        STAMPF(2);
 
         // project_cov3d_to_screen                                            src/gaussians.rs:114-161
         float pc[4];
@@ -662,6 +805,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
 
 
         singular = (det == 0.0f);
+        asm volatile("" : "+v"(ca), "+v"(cb), "+v"(cc), "+v"(cx), "+v"(cy), "+v"(hx), "+v"(hy));
+        STAMPF(3);
         bool vis = !singular && finitef(cx) && finitef(cy) && finitef(hx) && finitef(hy) && finitef(ca) && finitef(cb) &&
                    finitef(cc) && finitef(ndcz);
         if (vis && fc.zclip) vis = (fc.zmin <= ndcz) && (ndcz <= fc.zmax);
@@ -682,16 +827,40 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                 : make_ushort4(1, 0, 1, 0);
         }
     }
-    std::conditional_t<BUCKET, BucketBinner, NoBinner> binner(sh, fc.tiles_x, counts, keys, fc.bucket_cap);
-#if SPLAT_K1X != 2 && SPLAT_K1X != 3
-    if constexpr (BUCKET) binner.reserve(in_slab, singular, tx0, tx1, ty0, ty1, blockinfo);     // reservations in flight from here on
+    std::conditional_t<BUCKET, BucketBinner, NoBinner> binner(sh, fsh, fc.tiles_x, counts, keys, fc.bucket_cap);
+#if SPLAT_K1X == 12 || SPLAT_K1X == 13
+    if constexpr (BUCKET) binner.xstride = (unsigned int)(fc.tiles_x * fc.n_tile_rows + 1);
 #endif
+#if SPLAT_K1X == 30
+    if constexpr (BUCKET) binner.dbg_stamps = stamps;
+#endif
+    // The SH planes' loads go out BEFORE the reservations: vector memory returns in order, so loads issued behind
+    // the returning atomics could not be consumed before those have made their round trip to the L2 atomic unit
+    // (queued behind every other block's atomics on the same hot tile counters) -- the SH stage, the record store
+    // and the whole rest of the block used to wait that out.  In this order the reservations are in flight under
+    // the SH arithmetic instead.
+    Rec r;
     if (in_slab && SPLAT_K1X != 5) {
 #pragma unroll
         for (int p = (SPLAT_K1X == 3 ? LIVE_PLANES : 4); p < LIVE_PLANES; ++p) {
             float4 v = planes[(uint64_t)p * n + i];
             F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
+    }
+#if SPLAT_K1X != 2 && SPLAT_K1X != 3
+    if constexpr (BUCKET) {
+        STAMP(1);
+        binner.count(in_slab, singular, tx0, tx1, ty0, ty1);     // the block's pairs per tile, in LDS -- under the loads
+        STAMP(2);
+        // (all six planes in flight -- left alone, the compiler sinks each plane's load into the sh_dim branch that uses
+        // it: three dependent round trips -- and landed, before the barrier of the count and the atomics behind it)
+        asm volatile("" : "+v"(F[16]), "+v"(F[20]), "+v"(F[24]), "+v"(F[28]), "+v"(F[32]), "+v"(F[36]));
+        STAMP(3);
+        binner.issue(blockinfo);            // reservations in flight from here on
+        STAMP(4);
+    }
+#endif
+    if (in_slab && SPLAT_K1X != 5) {
         const float px = F[0], py = F[1], pz = F[2], opacity = F[3];
         const float* sh = F + 13;
 
@@ -699,6 +868,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         float dxw = px - fc.cam[0], dyw = py - fc.cam[1], dzw = pz - fc.cam[2];
         float nrm = sqrtf((dxw * dxw + dyw * dyw) + dzw * dzw);
         float x = dxw / nrm, y = dyw / nrm, z = dzw / nrm;
+        if constexpr (!BUCKET) asm volatile("" : "+v"(F[16]), "+v"(F[20]), "+v"(F[24]), "+v"(F[28]), "+v"(F[32]), "+v"(F[36]));   // (all six SH planes in flight at once)
 
         // eval_spherical_harmonics                                           src/gaussians.rs:40-99
         float col[3];
@@ -750,17 +920,28 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
             const float v = col[ch];
             col[ch] = (v != v) ? -3.402823466e+38f : fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);
         }
-        Rec r;
         r.a = make_float4(cx, cy, hx, hy);
         r.b = make_float4(ca, fc.y_up ? cb : -cb, cc, opacity);   // cross term carries the y-axis sign (exact)
         r.c = make_float4(col[0], col[1], col[2], pthr);
-        recs[i] = r;                        // slot order: coalesced here, Morton-local for the compositor's gathers
     }
+    // the reservations have arrived with the SH planes (issued before them): hand them to the block BEFORE the record
+    // store is issued -- the wait for a reservation issued after a store would include that store's completion
+    STAMP(5);
+    if constexpr (BUCKET) binner.publish();
+    STAMP(6);
+    auto store_record = [&] { if (in_slab && SPLAT_K1X != 5) recs[i] = r; };   // slot order: coalesced here, Morton-local for the compositor's gathers
+    if constexpr (!BUCKET) store_record();
     if constexpr (BUCKET) {
         const unsigned long long key = in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)(unsigned int)i) : 0ull;
-#if SPLAT_K1X == 0 || SPLAT_K1X >= 5
-        binner.place(key);
+#if SPLAT_K1X == 21
+        store_record();
+        if (key == 1ull) recs[0].a.x = 1.0f;
+#elif SPLAT_K1X == 0 || SPLAT_K1X >= 5
+        binner.place(key, store_record);        // (the record store goes out behind the barrier of the hand-out)
+        STAMP(7);
+        if (SPLAT_K1X == 16 || SPLAT_K1X == 17 || SPLAT_K1X == 23 || SPLAT_K1X == 24) { if (key == 1ull) recs[0].a.x = 1.0f; }
 #else
+        store_record();
         if (key == 1ull) recs[0].a.x = 1.0f;    // keep `key` alive
 #endif
     } else {
