@@ -34,7 +34,30 @@ WORKLOADS = {
     "C2": (281_498, 1280, 720, 2),
     "C3": (1_500_000, 1920, 1080, 3),
     "C5": (6_000_000, 3840, 2160, 5),
+    # not a BASELINE config: the trained-like stand-in (flat anisotropic Gaussians on surfaces, heavy-tailed scales,
+    # opacities near 0 / 1 -- splat_amd.synthetic_surface_raw) at C3's size; a parity case and an extra bench leg
+    "C3s": (1_500_000, 1920, 1080, 13),
 }
+SURFACE_WORKLOADS = ("C3s",)
+
+
+def make_scene(wl, via_ply=False):
+    """The seeded scene of a workload.  via_ply: written as an INRIA PLY (62 floats per vertex) and read back through the
+    C++ host mirror's load_from_ply -- the route SURVEY section 8(d) specifies (activations + recentring exercised)."""
+    import tempfile
+    import splat_amd
+    n, _, _, seed = WORKLOADS[wl]
+    raw_of = splat_amd.synthetic_surface_raw if wl in SURFACE_WORKLOADS else splat_amd.synthetic_raw
+    if not via_ply:
+        return (splat_amd.synthetic_surface_scene if wl in SURFACE_WORKLOADS else splat_amd.synthetic_scene)(n, seed)
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(d, "splat_bench_%s_%d.ply" % (wl, os.getpid()))
+    try:
+        splat_amd.write_ply(path, raw_of(n, seed), n)
+        return splat_amd.load_from_ply(path)
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ROW_OVERHEAD = 2000.0     # slab balancing: fixed cost of a tile row, in (Gaussian, tile) pairs
 
@@ -126,6 +149,54 @@ def single_process(args, n, W, H, seed):
 SETTLE_FRAMES = 200     # see the timed loop
 
 
+def surface_leg(R0, image, stream, device, args, counted, leg_drops):
+    import torch
+    import splat_amd
+    n, W, H, seed = WORKLOADS["C3s"]
+    t0 = time.perf_counter()
+    g = make_scene("C3s", via_ply=True)
+    t_load = time.perf_counter() - t0
+    R = splat_amd.Renderer(device=device)
+    out = {"workload": "C3s: %d Gaussians @%dx%d, synthetic surfaces seed %d, written as a PLY and loaded by load_from_ply (%.1f s)"
+                       % (n, W, H, seed, t_load)}
+    try:
+        g.compute_cov3d(R)
+        R.upload(g)
+        R.set_stream(stream.cuda_stream)
+        for name, pos, yaw in (("bench_pose", (0.0, 0.0, 5.0), 0.0), ("inside_pose", (0.3, 0.2, 0.4), 1.0)):
+            cam = splat_amd.Camera(H, W, pos)
+            if yaw:
+                cam.update_yaw_angle(yaw)
+            cam.update_camera_pose()
+            cam_c = cam.to_c(0.01, 15)
+            with torch.cuda.stream(stream):
+                image.zero_()
+                st = R.render_device(cam_c, image.data_ptr(), sync=True, want_stats=True)
+            img = image.cpu().numpy().view(np.uint32).copy()
+            for _ in range(30):
+                R.render_frame_device(cam_c, image.data_ptr())
+            torch.cuda.synchronize()
+            with counted("c3s_" + name, R):
+                t1 = time.perf_counter()
+                for _ in range(100):
+                    R.render_frame_device(cam_c, image.data_ptr())
+                torch.cuda.synchronize()
+                fps = 100 / (time.perf_counter() - t1)
+            leg = {"frames_per_sec": fps, "frames_dropped": leg_drops["c3s_" + name], "n_visible": int(st.n_visible), "n_pairs": int(st.n_pairs),
+                   "max_tile_len": int(st.max_tile_len), "early_out_fallback_waves": int(st.n_fallback),
+                   "sort_fallback_tiles": int(st.n_sort_fallback), "binning_bucket_keys": int(R.binning_mode())}
+            if not args.no_cpu_baseline:
+                ref, ost, cdt = cpu_baseline(g, cam_c, args.cpu_threads or (os.cpu_count() or 1))
+                d = np.abs(np.stack([((img >> s) & 255).astype(np.int32) - ((ref >> s) & 255).astype(np.int32) for s in (0, 8, 16, 24)]))
+                leg["parity"] = {"max_channel_diff_lsb": int(d.max()), "pixels_differing": int((d.max(0) > 0).sum()),
+                                 "pairs_equal": bool(int(st.n_pairs) == int(ost.n_tile_pairs) and int(st.n_visible) == int(ost.n_visible)),
+                                 "oracle_frames_per_sec": 1.0 / cdt}
+            out[name] = leg
+    finally:
+        R.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,8 +261,8 @@ def main():
         n = len(g.opacities)
         data_kind, scene_name = "ply:" + os.path.basename(args.scene), "%s (%d Gaussians)" % (os.path.basename(args.scene), n)
     else:
-        g = splat_amd.synthetic_scene(n, seed)
-        data_kind, scene_name = "synthetic", "synthetic seed %d" % seed
+        g = make_scene(args.workload)
+        data_kind, scene_name = "synthetic", ("synthetic surfaces seed %d" if args.workload in SURFACE_WORKLOADS else "synthetic seed %d") % seed
     g.compute_cov3d(R)                                   # K0 on the GPU (load-time, not timed)
     cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0))        # src/main.rs:13,29
     cam.update_camera_pose()
@@ -365,6 +436,10 @@ def main():
                     legs[leg] = K / (time.perf_counter() - t1)
                 last_buf = bufs[(K - 1) % nb]
             legs["host_visible_frames_equal_device_frame"] = bool(np.array_equal(last_buf, himg))
+            # (4) the trained-like stand-in (C3s: flat anisotropic Gaussians on surfaces) at C3's size, loaded through
+            # write_ply -> load_from_ply, bench pose and a pose inside the sphere: fps, counters, parity
+            if args.workload == "C3" and not args.scene:
+                legs["c3s_surface_scene"] = surface_leg(R, image, stream, local, args, counted, leg_drops)
             legs["frames_dropped"] = dict(leg_drops)
             legs["what"] = ("host-visible = pixels delivered to host memory (PCIe inclusive); never `value`.  %d frames each "
                             "(splat_render: 20).  frames_dropped = frames the device skipped inside each leg's timed loop "
@@ -561,6 +636,9 @@ def main():
             sys.stderr.write("bench.py: the device SKIPPED frames inside a timed region (headline %d, legs %s): the rate is not "
                              "a measurement\n" % (dropped_all, json.dumps(leg_drops)))
             exit_code = 4
+        for leg in (out.get("extra_legs", {}).get("c3s_surface_scene", {}) or {}).values():
+            if isinstance(leg, dict) and "parity" in leg and not (leg["parity"]["max_channel_diff_lsb"] <= 1 and leg["parity"]["pairs_equal"]):
+                parity_ok = False
         print(json.dumps(out))
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY MISS against the oracle: %s\n" % json.dumps(out["parity"]))

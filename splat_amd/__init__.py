@@ -6,7 +6,8 @@ Host-side mirror of the reference's operator interface (`Camera`, `GaussianList`
 fallback: anything that computes needs the built library and a GPU, and says so loudly.
 """
 from .camera import Camera  # noqa: F401
-from .gaussians import GaussianList, naive_gaussians, load_from_ply, synthetic_scene, write_ply, trim_ply  # noqa: F401
+from .gaussians import (GaussianList, naive_gaussians, load_from_ply, synthetic_scene, synthetic_surface_scene,  # noqa: F401
+                        synthetic_raw, synthetic_surface_raw, write_ply, trim_ply)
 from .pipelines import GaussianSplatPipeline01, GaussianSplatPipeline02  # noqa: F401
 from .renderer import Renderer, SplatError  # noqa: F401
 from .multi import MultiRenderer, slab_partition_native  # noqa: F401

@@ -206,6 +206,60 @@ def synthetic_raw(n, seed):
     return raw
 
 
+def synthetic_surface_raw(n, seed):
+    """Seeded stand-in that looks like a TRAINED scene rather than a cloud of blobs, in PLY
+    (pre-activation) units: flat, anisotropic Gaussians lying ON thin surfaces -- half on a sphere shell of radius 2,
+    a quarter on a ground plane, a quarter on a back wall -- their thin axis along the surface normal, tangential
+    scales heavy-tailed (one in ten several times larger), opacities skewed to ~0 and ~1.  A tile then sees hundreds of
+    splats within a sliver of depth, most of them opaque: unbounded overdraw with early saturation, which is where a
+    real 'truck' differs from the isotropic cloud of synthetic_raw."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    k, m = n // 2, n // 4
+    pos = np.zeros((n, 3), np.float64)
+    nrm = np.zeros((n, 3), np.float64)
+    d = rng.standard_normal((k, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pos[:k] = (2.0 + rng.normal(0.0, 0.002, (k, 1))) * d; nrm[:k] = d                    # sphere shell, millimetres thick
+    pos[k:k + m, 0] = rng.uniform(-4, 4, m); pos[k:k + m, 2] = rng.uniform(-4, 4, m)
+    pos[k:k + m, 1] = 1.5 + rng.normal(0.0, 0.001, m); nrm[k:k + m] = (0.0, 1.0, 0.0)   # ground plane (up is -y, src/camera.rs:31)
+    r = n - k - m
+    pos[k + m:, 0] = rng.uniform(-4, 4, r); pos[k + m:, 1] = rng.uniform(-3, 1.5, r)
+    pos[k + m:, 2] = -3.0 + rng.normal(0.0, 0.001, r); nrm[k + m:] = (0.0, 0.0, 1.0)    # back wall
+    raw = {}
+    raw["x"], raw["y"], raw["z"] = (pos[:, a].astype(f32) for a in range(3))
+    big = rng.random(n) < 0.1
+    for a in (0, 1):                                                                      # tangential axes: heavy tail
+        raw["scale_%d" % a] = np.where(big, rng.normal(-2.2, 0.6, n), rng.normal(-3.6, 0.5, n)).astype(f32)
+    raw["scale_2"] = rng.normal(-7.0, 0.3, n).astype(f32)                                 # the thin axis
+    # rotation: local z -> surface normal (shortest arc), then a random spin about it.  PLY order: rot_0 = w, rot_1..3 = x, y, z
+    w = 1.0 + nrm[:, 2]
+    q = np.stack([w, -nrm[:, 1], nrm[:, 0], np.zeros(n)], 1)                              # (w, cross(e_z, n))
+    flip = w < 1e-6
+    q[flip] = (0.0, 1.0, 0.0, 0.0)                                                        # n = -e_z: half a turn about x
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    a = rng.uniform(0, 2 * np.pi, n)
+    s = np.stack([np.cos(a / 2), np.zeros(n), np.zeros(n), np.sin(a / 2)], 1)             # spin about local z, applied first
+    qw = q[:, 0] * s[:, 0] - q[:, 3] * s[:, 3]
+    qx = q[:, 1] * s[:, 0] + q[:, 2] * s[:, 3]
+    qy = q[:, 2] * s[:, 0] - q[:, 1] * s[:, 3]
+    qz = q[:, 0] * s[:, 3] + q[:, 3] * s[:, 0]
+    scale = rng.uniform(0.5, 2.0, n)                                                      # stored un-normalised, as trained PLYs are
+    for i, c in enumerate((qw, qx, qy, qz)):
+        raw["rot_%d" % i] = (c * scale).astype(f32)
+    raw["opacity"] = np.where(rng.random(n) < 0.7, rng.normal(4.0, 1.5, n), rng.normal(-2.0, 1.5, n)).astype(f32)
+    dc = rng.standard_normal((n, 3)).astype(f32)
+    for i in range(3):
+        raw["f_dc_%d" % i] = dc[:, i].copy()
+    rest = (rng.standard_normal((n, 45)) * 0.15).astype(f32)
+    for i in range(45):
+        raw["f_rest_%d" % i] = rest[:, i].copy()
+    return raw
+
+
+def synthetic_surface_scene(n, seed):
+    """synthetic_surface_raw pushed through the loader's activations + recentring (no file round trip)."""
+    return _activate_and_recentre(synthetic_surface_raw(n, seed))
+
+
 def synthetic_scene(n, seed):
     """synthetic_raw pushed through the loader's activations + recentring (no file round trip)."""
     return _activate_and_recentre(synthetic_raw(n, seed))

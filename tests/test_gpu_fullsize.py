@@ -16,7 +16,7 @@ import pytest
 import splat_amd
 from oracle import oracle as O
 from helpers import scene_dict, oracle_camera, image_diff
-from bench import WORKLOADS
+from bench import WORKLOADS, make_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +28,7 @@ POSES = {
 }
 CASES = [("C2", "bench"), ("C2", "inside"),
          ("C3", "bench"), ("C3", "orbit70"), ("C3", "orbit250"), ("C3", "inside"),
+         ("C3s", "bench"), ("C3s", "inside"),       # the trained-like stand-in: flat anisotropic Gaussians on surfaces
          ("C5", "bench")]
 
 _cache = {}
@@ -41,7 +42,7 @@ def workload(name):
         _cache.clear()
         n, W, H, seed = WORKLOADS[name]
         R = splat_amd.Renderer()
-        g = splat_amd.synthetic_scene(n, seed)
+        g = make_scene(name)
         g.compute_cov3d(R)
         R.upload(g)
         _cache.update(name=name, R=R, g=g, sd=scene_dict(g), W=W, H=H)

@@ -310,3 +310,30 @@ def test_ply_loader_survives_malformed_files(tmp_path):
         outcomes.append((kind, r.stdout.split()[0]))
     assert all(o == "raised" for k, o in outcomes if k in (0, 1, 3, 6))          # truncation / size mismatch / no header end
     assert all(o == "ok" for k, o in outcomes if k == 7)                         # any payload of the right size loads
+
+
+def test_surface_scene_generator_and_ply_round_trip(tmp_path):
+    """the trained-like stand-in (bench WORKLOADS['C3s']): seeded, flat along the surface normal, opacities skewed to the
+    ends, and identical whether it goes through write_ply -> load_from_ply (the C++ loader) or straight through the
+    activations (the bench leg takes the file route)"""
+    from splat_amd import gaussians as G
+    from oracle import oracle as O
+    n = 3000
+    raw = G.synthetic_surface_raw(n, 13)
+    assert all(np.array_equal(raw[k], G.synthetic_surface_raw(n, 13)[k]) for k in raw)          # seeded
+    g = G.synthetic_surface_scene(n, 13)
+    path = str(tmp_path / "s.ply")
+    G.write_ply(path, raw, n)
+    h = splat_amd.load_from_ply(path)
+    for a in ("positions", "scales", "opacities", "rotations", "sh"):
+        x, y = getattr(g, a), getattr(h, a)
+        if a in ("scales", "opacities"):        # numpy's f32 exp and libm's expf may differ in the last place
+            assert np.allclose(x, y, rtol=3e-7, atol=0), a
+        else:
+            assert np.array_equal(x, y), a
+    cov = O.compute_cov3d(h.scales, h.rotations).reshape(n, 3, 3).astype(np.float64)
+    pos = np.stack([raw["x"], raw["y"], raw["z"]], 1).astype(np.float64)
+    for i in range(0, n // 2, 37):                                # sphere shell: the thin axis is the radial direction
+        w, v = np.linalg.eigh(cov[i])
+        assert w[0] < 2e-2 * w[1] and abs(v[:, 0] @ (pos[i] / np.linalg.norm(pos[i]))) > 0.999      # thin: sigma ratio < 0.15
+    assert (h.opacities > 0.9).mean() > 0.4 and (h.opacities < 0.2).mean() > 0.1
