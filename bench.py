@@ -184,7 +184,8 @@ def surface_leg(R0, image, stream, device, args, counted, leg_drops):
                 fps = 100 / (time.perf_counter() - t1)
             leg = {"frames_per_sec": fps, "frames_dropped": leg_drops["c3s_" + name], "n_visible": int(st.n_visible), "n_pairs": int(st.n_pairs),
                    "max_tile_len": int(st.max_tile_len), "early_out_fallback_waves": int(st.n_fallback),
-                   "sort_fallback_tiles": int(st.n_sort_fallback), "binning_bucket_keys": int(R.binning_mode())}
+                   "sort_fallback_tiles": int(st.n_sort_fallback), "key_buffer_entries_per_slot": int(R.binning_mode()),
+                   "device_bytes_peak": int(R.device_bytes()[1])}
             if not args.no_cpu_baseline:
                 ref, ost, cdt = cpu_baseline(g, cam_c, args.cpu_threads or (os.cpu_count() or 1))
                 d = np.abs(np.stack([((img >> s) & 255).astype(np.int32) - ((ref >> s) & 255).astype(np.int32) for s in (0, 8, 16, 24)]))
@@ -366,6 +367,8 @@ def main():
     dt = time.perf_counter() - t0
     dropped_timed = R.frames_dropped() - dropped0        # frames the device skipped inside the timed region: must be 0
     kern_ms, frames = R.timing(reset=True)               # HIP events on the kernels' own stream
+    dev_peak = R.device_bytes()[1]                       # device memory the context has held at most (scene, frame slots, key buffers)
+    key_entries = R.binning_mode()
     last_pose = poses[(frame_no[0] - 1) % len(poses)]
     final = image.clone()
     # The context overlaps the binning + sort of frame N+1 (its own stream) with the compositor of
@@ -512,7 +515,8 @@ def main():
                        "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len),
                        "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback),
                        "k1_blocks_culled": int(st.n_blocks_culled),
-                       "frames_dropped": int(dropped_all)},
+                       "frames_dropped": int(dropped_all),
+                       "device_bytes_peak": int(dev_peak), "key_buffer_entries_per_slot": int(key_entries)},
             "roofline": {"bound": "hbm", "kernel": "composite_exact_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": per["composite"], "bytes_per_launch": comp_bytes,

@@ -168,6 +168,9 @@ int splat_sync(splat_ctx* ctx);
  * splat_render_device.  With a slab set, only the slab's rows are cleared and rendered. */
 int splat_render_frame_device(splat_ctx* ctx, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats);
 uint64_t splat_frames_dropped(const splat_ctx* ctx);  /* frames skipped on the device since splat_create (redone or reported) */
+/* Device memory this context holds right now (scene planes, per-frame buffers of its frame slots, key buffers, images it
+ * allocated); *peak (nullable) = the most it has held since splat_create. */
+uint64_t splat_device_bytes(const splat_ctx* ctx, uint64_t* peak);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */
 /* Run on a caller-owned hipStream_t (e.g. the stream a device image / RCCL gather lives on). */
 int splat_set_stream(splat_ctx* ctx, void* hip_stream);
@@ -185,11 +188,12 @@ int splat_get_records(splat_ctx* ctx, splat_record* out, uint64_t n);
  * each tile's list in blend order (far -> near). Pass NULL to query sizes via stats. */
 int splat_get_tile_lists(splat_ctx* ctx, uint32_t* tile_offsets, uint64_t n_offsets, uint32_t* order,
                          uint64_t n_order);
-/* How the last frame was binned: the per-tile bucket size (keys) of one-pass binning, 0 for
- * two-pass binning (count, scan, emit into exactly sized lists), < 0 without a frame.  One-pass
- * is the default (buckets of up to 16384 keys, grown to at most 65536 when a frame needs it);
- * SPLAT_BUCKETS=0, a caller-fixed pair_capacity, buckets that would not fit SPLAT_BUCKET_BYTES
- * (default 128 GiB for all frame slots together) or a tile list longer than 65536 select two-pass. */
+/* How the last frame was binned: > 0 = one-pass binning (the default), the value being the entries of the key buffer
+ * its tiles' regions live in -- every tile owns a region sized from the list it had two frames earlier (x 1.5 + 512 keys),
+ * so the buffer holds ~1.6 x the frame's (Gaussian, tile) pairs; a frame whose list outgrows its region is skipped and
+ * redone / reported like any frame that outgrows its storage (splat_sync).  0 = two-pass binning (count, scan, emit into
+ * exactly sized lists): SPLAT_BUCKETS=0, a caller-fixed pair_capacity, or key buffers that would not fit
+ * SPLAT_BUCKET_BYTES (default 128 GiB for all frame slots together).  < 0 without a frame. */
 int64_t splat_binning_mode(splat_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------

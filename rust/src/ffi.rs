@@ -67,6 +67,7 @@ extern "C" {
                                      sync: i32, stats: *mut SplatStats) -> c_int;
     pub fn splat_sync(ctx: *mut SplatCtx) -> c_int;
     pub fn splat_frames_dropped(ctx: *const SplatCtx) -> u64;
+    pub fn splat_device_bytes(ctx: *const SplatCtx, peak: *mut u64) -> u64;
     pub fn splat_binning_mode(ctx: *mut SplatCtx) -> i64;
     pub fn splat_stream(ctx: *mut SplatCtx) -> *mut c_void;               // the hipStream_t the kernels run on
     pub fn splat_set_stream(ctx: *mut SplatCtx, hip_stream: *mut c_void) -> c_int;

@@ -15,8 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "splat_internal.h"
@@ -41,7 +43,12 @@ struct Slot {                  // everything one frame writes before the image
     float* depth = nullptr;
     ushort4* rect = nullptr;
     unsigned int* vislist = nullptr;
-    unsigned int* counts = nullptr;
+    unsigned int* counts = nullptr;        // per tile: pair count (two-pass binning, zero between frames) / cursor of the tile's region (one-pass)
+    unsigned int* counts_b = nullptr;      // one-pass binning: cursors and regions exist twice per slot -- the layout of the slot's NEXT frame
+    unsigned int* lay_a = nullptr;         // is written (layout_kernel of an earlier frame on the same stream) while nothing reads that copy
+    unsigned int* lay_b = nullptr;
+    int flip = 0;                          // which copy the slot's next frame uses (0: counts / lay_a, 1: counts_b / lay_b)
+    bool layout_valid = false;             // ... and whether it holds regions for the current scene / target / slab
     unsigned int* offsets = nullptr;
     unsigned int* cursor = nullptr;
     unsigned int* order = nullptr;
@@ -78,12 +85,16 @@ struct splat_ctx {
     bool have_keys2 = false;               // keys2 (two-pass path only) is allocated at the same size
     // one-pass binning (per-tile buckets): on unless SPLAT_BUCKETS=0, the caller fixed pair_capacity,
     // the buckets would not fit bucket_bytes, or a tile outgrew the largest LDS-sortable bucket
+    // one-pass binning (per-tile regions of the key buffer, sized from earlier frames' lists): on unless SPLAT_BUCKETS=0, the
+    // caller fixed pair_capacity, or the key buffers would not fit bucket_bytes
     bool use_buckets = true;
-    bool bucket_failed = false;            // sticky until the scene / target geometry changes
+    bool bucket_failed = false;            // sticky until the scene changes
     uint64_t bucket_bytes = 128ull << 30;  // SPLAT_BUCKET_BYTES: all key buffers of all slots together (288 GB of HBM per GPU)
-    unsigned int bucket_min = 0;           // a tile outgrew a smaller bucket: buckets of at least this many keys
-    unsigned int bucket_want = 0;          // longest list of a harvested frame that overflowed its bucket
-    unsigned int bucket_m = 0;             // tile count bucket_failed refers to
+    uint64_t layout_want = 0;              // entries the regions of a harvested frame asked for and did not get (grow to this)
+    unsigned int layout_m = 0;             // tile count the slots' layouts were built for
+    bool last_one_pass = false;            // what the previous frame's binning was (the cursors must be zero for two-pass counting)
+    unsigned int* zero_layout = nullptr;   // m_alloc zeros: the empty layout of the bootstrap (every key dropped, every pair counted)
+    uint64_t dev_bytes = 0, dev_bytes_peak = 0;   // device memory held by this context
     uint64_t frame_idx = 0;
     int last_slot = -1;                    // buffer slot of the most recent frame (debug getters)
     bool last_lists_in_memory = false;     // ... and whether its compositor wrote the lists it sorted back to the buckets
@@ -244,9 +255,19 @@ void block_bounds(uint64_t n, const float* pos4, const float* cov3d, const std::
     }
 }
 
+// Device allocations of a context go through these two, so that splat_device_bytes() can say what it holds (sizes are
+// kept in a side table: hipFree does not tell).
+void ledger_add(splat_ctx* c, void* p, size_t bytes);
+void ledger_del(void* p);
+template <typename T>
+hipError_t dmalloc(splat_ctx* c, T** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) ledger_add(c, (void*)*p, bytes);
+    return e;
+}
 template <typename T>
 void dfree(T*& p) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { ledger_del((void*)p); (void)hipFree(p); p = nullptr; }
 }
 
 const float* ev_times(const EvSet& s, float t[N_TIMES]) {
@@ -271,11 +292,28 @@ void harvest(splat_ctx* c, int r) {
     const FrameStatus& st = c->h_status[r];
     if (st.overflow) c->frames_dropped++;
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
-    if (st.overflow == 2) { c->bucket_overflow = true; c->bucket_want = std::max(c->bucket_want, st.max_tile_len); }
+    if (st.overflow == 2) c->bucket_overflow = true;           // a tile's list outgrew its region: the layouts are stale
+    if (st.layout_total > c->cap) c->layout_want = std::max<uint64_t>(c->layout_want, st.layout_total);   // the regions were cut off
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
     if (st.overflow == 0) { c->hint_pairs = st.n_pairs; c->hint_maxlen = st.max_tile_len; }
     s.used = false;
+}
+
+std::mutex g_ledger_mu;
+std::unordered_map<void*, std::pair<splat_ctx*, size_t>> g_ledger;
+void ledger_add(splat_ctx* c, void* p, size_t bytes) {
+    std::lock_guard<std::mutex> g(g_ledger_mu);
+    g_ledger[p] = {c, bytes};
+    c->dev_bytes += bytes;
+    c->dev_bytes_peak = std::max(c->dev_bytes_peak, c->dev_bytes);
+}
+void ledger_del(void* p) {
+    std::lock_guard<std::mutex> g(g_ledger_mu);
+    auto it = g_ledger.find(p);
+    if (it == g_ledger.end()) return;
+    it->second.first->dev_bytes -= it->second.second;
+    g_ledger.erase(it);
 }
 
 int sync_all(splat_ctx* c) {
@@ -292,14 +330,21 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     if (rc != SPLAT_OK) return rc;
     c->m_alloc = 0;
     c->sort_hint = false;                  // another target geometry: the list-length profile is unknown again
+    dfree(c->zero_layout);
+    HIP_TRY(c, dmalloc(c, &c->zero_layout, sizeof(unsigned int) * (size_t)(m + 1)));
+    HIP_TRY(c, hipMemset(c->zero_layout, 0, sizeof(unsigned int) * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
-        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens);
-        HIP_TRY(c, hipMalloc(&s.lens, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, hipMalloc(&s.counts, sizeof(unsigned int) * (size_t)(m + 1) * (SPLAT_K1X ? 8 : 1)));
-        HIP_TRY(c, hipMalloc(&s.offsets, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, hipMalloc(&s.cursor, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, hipMalloc(&s.order, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, hipMemset(s.counts, 0, sizeof(unsigned int) * (size_t)(m + 1) * (SPLAT_K1X ? 8 : 1)));
+        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
+        s.layout_valid = false; s.flip = 0;
+        HIP_TRY(c, dmalloc(c, &s.counts_b, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.lay_a, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.lay_b, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.lens, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.counts, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.offsets, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.cursor, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.order, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, hipMemset(s.counts, 0, sizeof(unsigned int) * (size_t)(m + 1)));
     }
     c->m_alloc = m + 1;
     return SPLAT_OK;
@@ -319,8 +364,8 @@ int ensure_keys(splat_ctx* c, uint64_t want, bool need_keys2) {
     for (Slot& s : c->slots) { dfree(s.keys); dfree(s.keys2); }
     for (int k = 0; k < slots_in_use(c); ++k) {
         Slot& s = c->slots[k];
-        hipError_t e = hipMalloc(&s.keys, sizeof(unsigned long long) * want);
-        if (e == hipSuccess && need_keys2) e = hipMalloc(&s.keys2, sizeof(unsigned long long) * want);
+        hipError_t e = dmalloc(c, &s.keys, sizeof(unsigned long long) * want);
+        if (e == hipSuccess && need_keys2) e = dmalloc(c, &s.keys2, sizeof(unsigned long long) * want);
         if (e != hipSuccess) return fail(c, SPLAT_ERR_CAPACITY, std::string("cannot allocate pair buffer: ") + hipGetErrorString(e));
     }
     c->cap = want; c->have_keys2 = need_keys2;
@@ -331,11 +376,7 @@ uint64_t default_pair_capacity(const splat_ctx* c) {
     return c->cfg.pair_capacity ? c->cfg.pair_capacity : std::max<uint64_t>(1ull << 22, 16 * c->n);
 }
 
-// Bucket size for one-pass binning over m tiles, or 0 for the two-pass path.  A bucket never needs
-// more than n entries; up to 16384 keys a list sorts in LDS, up to 65536 as four runs plus a merge
-// through a second key buffer (buckets of that size only once a frame needed them); all buffers
-// of all slots must fit the byte budget, and list positions 32 bits.
-constexpr unsigned int BUCKET_MAX = 65536;
+// Who sorts the lists of more than 2048 keys (see splat_ctx::sort_in_comp).
 bool compositor_sorts_long_lists(const splat_ctx* c, unsigned int m) {
     if (c->fused_sort_max < 2048u) return false;
     // auto: the average list is longer than 2048 keys (the sort launches would carry most of the frame) AND the frame is
@@ -345,19 +386,12 @@ bool compositor_sorts_long_lists(const splat_ctx* c, unsigned int m) {
     return c->sort_in_comp > 0 ||
            (c->sort_in_comp < 0 && c->hint_pairs > 2048ull * (uint64_t)m && c->hint_pairs > 1500ull * (uint64_t)c->hint_maxlen);
 }
-unsigned int choose_bucket_cap(splat_ctx* c, unsigned int m, bool* need_keys2) {
-    *need_keys2 = false;
-    if (!c->use_buckets || c->cfg.pair_capacity || m == 0) return 0;
-    if (c->bucket_failed && c->bucket_m == m) return 0;
-    uint64_t cap = 1024;
-    while (cap < 16384 && cap < c->n) cap <<= 1;
-    cap = std::max<uint64_t>(cap, c->bucket_min);
-    if (cap > BUCKET_MAX) return 0;
-    *need_keys2 = cap > 16384 || compositor_sorts_long_lists(c, m);
-    const uint64_t bytes = (uint64_t)m * cap * 8ull * (*need_keys2 ? 2u : 1u) * (uint64_t)slots_in_use(c);
-    if (bytes > c->bucket_bytes || (uint64_t)m * cap >= 0xFFFFFFF0ull) return 0;
-    return (unsigned int)cap;
+// One-pass binning (per-tile regions of the key buffer)?  Not when switched off, when the caller fixed the pair capacity
+// (exactly sized lists then), or after the key buffers failed to fit.
+bool one_pass_wanted(const splat_ctx* c, unsigned int m) {
+    return c->use_buckets && !c->cfg.pair_capacity && m != 0 && !c->bucket_failed;
 }
+constexpr uint64_t KEY_ENTRIES_MAX = 0xfff00000ull - 65536ull;      // (positions beyond it mean "dropped": BucketBinner::DROP)
 
 int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, unsigned int* n_tiles) {
     if (!cam) return fail(c, SPLAT_ERR_INVALID, "camera is NULL");
@@ -427,8 +461,23 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     }
     if (!c->fc.bucket_cap)                                 // two-pass binning: K1 counts visible Gaussians into the status before the scan
         HIP_TRY(c, hipMemsetAsync(d_st, 0, sizeof(FrameStatus), bs));
+    // One-pass binning: the tiles' regions of the key buffer and their cursors.  Normally the layout_kernel of the frame
+    // before this one ON THIS STREAM has left them in the slot's other copy (below); a slot without a layout (first
+    // frames, a new scene / target / slab, after a frame outgrew a region) counts its pairs first -- K1 against the
+    // empty layout drops every key and counts every pair -- and builds regions that fit exactly this camera.
+    unsigned int *cursors = s.counts, *layout = nullptr;
+    if (c->fc.bucket_cap) {
+        if (!s.layout_valid) {
+            HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));
+            launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout);
+            launch_layout(bs, m, s.counts, c->zero_layout, s.lay_b, s.counts_b, c->fc.bucket_cap, nullptr, nullptr);
+            s.flip = 1; s.layout_valid = true;
+        }
+        cursors = s.flip ? s.counts_b : s.counts;
+        layout = s.flip ? s.lay_b : s.lay_a;
+    }
     HIP_TRY(c, mark(0, bs));
-    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, s.blockinfo, d_st);
+    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, layout);
     HIP_TRY(c, mark(1, bs));
     if (compositor_sorts_long_lists(c, m) && s.keys2 != nullptr) {
         c->grid_big = m; c->grid_mid = m; c->grid_long = m;        // no sort launches to size: the scan has nothing to validate
@@ -443,7 +492,18 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     } else {
         c->grid_big = m; c->grid_mid = m; c->grid_long = m;
     }
-    launch_scan(bs, m, s.counts, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r]);
+    // (one-pass binning: a second workgroup of the scan's launch builds the regions of the NEXT frame on this binning
+    // stream -- two frames on with two chains in flight -- from this frame's lists, into that slot's idle copy)
+    unsigned int *next_layout = nullptr, *next_counts = nullptr;
+    if (c->fc.bucket_cap) {
+        const int stride = (c->pipeline >= 6) ? 2 : 1;
+        Slot& nx = c->slots[(si + stride) % slots_in_use(c)];
+        const int into = (&nx == &s) ? (s.flip ^ 1) : (nx.layout_valid ? (nx.flip ^ 1) : 1);
+        next_layout = into ? nx.lay_b : nx.lay_a; next_counts = into ? nx.counts_b : nx.counts;
+        nx.flip = into; nx.layout_valid = true;
+    }
+    launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
+                next_layout, next_counts);
     HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
         HIP_TRY(c, hipEventRecord(s.ev_binned, bs));
@@ -467,7 +527,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     if (want_iters) {       // statistics frame: every compositor wave leaves its iteration counts (plain stores)
         if (c->iters_alloc < m * 4u) {
             dfree(c->d_iters); c->iters_alloc = 0;
-            HIP_TRY(c, hipMalloc(&c->d_iters, sizeof(uint2) * (size_t)m * 4u));
+            HIP_TRY(c, dmalloc(c, &c->d_iters, sizeof(uint2) * (size_t)m * 4u));
             c->iters_alloc = m * 4u;
         }
         HIP_TRY(c, hipMemsetAsync(c->d_iters, 0, sizeof(uint2) * (size_t)m * 4u, c->stream));
@@ -514,16 +574,26 @@ int finish_frame(splat_ctx* c, bool* last_skipped = nullptr) {
         c->sort_grid_miss = false;
         msg = "more long tile lists than the sort launches covered; frame must be re-rendered";
     }
-    if (c->bucket_overflow) {
-        // larger buckets (lists up to 65536 keys sort as runs + merge) if they fit, else exact lists
+    if (c->bucket_overflow || c->layout_want) {
+        // A tile's list outgrew the region it had been given (sized from a frame two back: the camera moved, or nothing
+        // was known yet), or the regions did not fit the key buffer.  The slots' layouts are dropped -- the next frame
+        // counts its pairs first (bootstrap, enqueue_frame) and gets regions that fit it -- and the buffer grows to what
+        // the layout asked for.
+        const bool overflowed = c->bucket_overflow;
         c->bucket_overflow = false;
-        uint64_t want = (((uint64_t)c->bucket_want + c->bucket_want / 4) + 1023u) & ~1023ull;   // + 25 %, in steps of 1024 keys
-        want = std::max<uint64_t>(want, 16384 + 1024);
-        if (want > BUCKET_MAX && c->bucket_want <= BUCKET_MAX) want = BUCKET_MAX;
-        c->bucket_want = 0;
-        if (want <= BUCKET_MAX) c->bucket_min = std::max<unsigned int>(c->bucket_min, (unsigned int)want);
-        else { c->bucket_failed = true; c->bucket_m = c->n_tiles; }
-        msg = "a tile outgrew its bucket; storage regrown, frame must be re-rendered";
+        for (Slot& sl : c->slots) sl.layout_valid = false;
+        if (c->layout_want > c->cap) {
+            const uint64_t asked = c->layout_want + c->layout_want / 4 + 1024, want = std::min<uint64_t>(asked, KEY_ENTRIES_MAX);
+            const uint64_t bytes = want * 8ull * (c->have_keys2 ? 2u : 1u) * (uint64_t)slots_in_use(c);
+            if (bytes > c->bucket_bytes || asked > KEY_ENTRIES_MAX) c->bucket_failed = true;    // no room: exactly sized lists instead
+            else {
+                rc = ensure_keys(c, want, c->have_keys2);
+                if (rc == SPLAT_ERR_CAPACITY) { c->bucket_failed = true; rc = SPLAT_OK; }
+                else if (rc != SPLAT_OK) return rc;
+            }
+        }
+        c->layout_want = 0;
+        if (overflowed) msg = "a tile outgrew its region of the key buffer; regions rebuilt, frame must be re-rendered";
     }
     if (c->overflow_want) {
         uint64_t want = (uint64_t)((double)c->overflow_want * 1.25) + 1024;
@@ -560,14 +630,31 @@ int slots_in_use(const splat_ctx* c) { return c->pipeline >= 5 ? 4 : (c->pipelin
 
 // Pick the binning path for a frame over m tiles and make sure its key storage exists.
 int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
-    bool need2 = false;
-    fc->bucket_cap = choose_bucket_cap(c, m, &need2);
-    if (fc->bucket_cap) {
-        int rc = ensure_keys(c, (uint64_t)m * fc->bucket_cap, need2);
-        if (rc == SPLAT_OK) return rc;
+    const bool one_pass = one_pass_wanted(c, m);
+    if (one_pass != c->last_one_pass || m != c->layout_m) {
+        // another path or another tile grid: the counters hold the other path's state (cursors / zeros), the regions
+        // describe another grid
+        int rc = finish_quiet(c);
+        if (rc != SPLAT_OK) return rc;
+        for (Slot& sl : c->slots) {
+            sl.layout_valid = false; sl.flip = 0;
+            if (sl.counts) HIP_TRY(c, hipMemsetAsync(sl.counts, 0, sizeof(unsigned int) * (size_t)(m + 1), c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->last_one_pass = one_pass; c->layout_m = m;
+    }
+    fc->bucket_cap = 0;
+    if (one_pass) {
+        // key buffer: what the two-pass path would start with, unless a layout has asked for more (finish_frame grows it)
+        // (always with the second buffer: a region may hold a list of any length, and a list beyond 16384 keys sorts as
+        // runs merged through it -- fixed-stride buckets could cap the lists at what the buffers at hand could sort)
+        const bool need2 = true;
+        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, default_pair_capacity(c)), KEY_ENTRIES_MAX);
+        int rc = (want * 8ull * (need2 ? 2u : 1u) * (uint64_t)slots_in_use(c) > c->bucket_bytes) ? SPLAT_ERR_CAPACITY : ensure_keys(c, want, need2);
+        if (rc == SPLAT_OK) { fc->bucket_cap = (unsigned int)std::min<uint64_t>(c->cap, KEY_ENTRIES_MAX); return rc; }
         if (rc != SPLAT_ERR_CAPACITY) return rc;
-        c->bucket_failed = true; c->bucket_m = m;      // no room for the buckets: exact lists instead
-        fc->bucket_cap = 0;
+        c->bucket_failed = true;                          // no room: exactly sized lists instead
+        return prepare_binning(c, m, fc);
     }
     return ensure_keys(c, default_pair_capacity(c), true);
 }
@@ -704,13 +791,13 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         if ((e = hipStreamCreateWithPriority(&c->sort_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
     }
     for (Slot& s : c->slots) {
-        if ((e = hipMalloc(&s.d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
+        if ((e = dmalloc(c, &s.d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
         if ((e = hipMemset(s.d_status, 0, sizeof(FrameStatus))) != hipSuccess) return bail("hipMemset(status)", e);
         if ((e = hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_binned, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
-    if ((e = hipMalloc(&c->d_status_ring, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMalloc(status ring)", e);
+    if ((e = dmalloc(c, &c->d_status_ring, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMalloc(status ring)", e);
     if ((e = hipMemset(c->d_status_ring, 0, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMemset(status ring)", e);
     if ((e = hipHostMalloc(&c->h_status, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipHostMalloc(status)", e);
     std::memset(c->h_status, 0, sizeof(FrameStatus) * EV_RING);
@@ -729,8 +816,10 @@ void splat_destroy(splat_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { comm_release(c->comm); c->comm = nullptr; }
     free_scene(c);
+    dfree(c->zero_layout);
     for (Slot& s : c->slots) {
-        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
+        dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
+        dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
         if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);
         if (s.ev_free) (void)hipEventDestroy(s.ev_free);
@@ -787,25 +876,25 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
         cleanup();                                                               \
         return fail(c, SPLAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e)); \
     }
-    UP_TRY(hipMalloc(&c->planes, sizeof(float4) * SCENE_PLANES * n));
-    UP_TRY(hipMalloc(&c->orig, sizeof(unsigned int) * n));
+    UP_TRY(dmalloc(c, &c->planes, sizeof(float4) * SCENE_PLANES * n));
+    UP_TRY(dmalloc(c, &c->orig, sizeof(unsigned int) * n));
     for (Slot& s : c->slots) {
-        UP_TRY(hipMalloc(&s.recs, sizeof(Rec) * n));
-        UP_TRY(hipMalloc(&s.depth, sizeof(float) * n));
-        UP_TRY(hipMalloc(&s.rect, sizeof(ushort4) * n));
-        UP_TRY(hipMalloc(&s.vislist, sizeof(unsigned int) * n));
-        UP_TRY(hipMalloc(&s.blockinfo, sizeof(unsigned int) * ((n + 255) / 256)));
+        UP_TRY(dmalloc(c, &s.recs, sizeof(Rec) * n));
+        UP_TRY(dmalloc(c, &s.depth, sizeof(float) * n));
+        UP_TRY(dmalloc(c, &s.rect, sizeof(ushort4) * n));
+        UP_TRY(dmalloc(c, &s.vislist, sizeof(unsigned int) * n));
+        UP_TRY(dmalloc(c, &s.blockinfo, sizeof(unsigned int) * ((n + 255) / 256)));
         UP_TRY(hipMemsetAsync(s.blockinfo, 0, sizeof(unsigned int) * ((n + 255) / 256), c->stream));
     }
     UP_TRY(hipMemcpyAsync(c->orig, c->h_orig.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, c->stream));
     std::vector<BlockBounds> hb;
     block_bounds(n, pos4, cov3d, c->h_orig, hb);
-    UP_TRY(hipMalloc(&c->bounds, sizeof(BlockBounds) * hb.size()));
+    UP_TRY(dmalloc(c, &c->bounds, sizeof(BlockBounds) * hb.size()));
     UP_TRY(hipMemcpyAsync(c->bounds, hb.data(), sizeof(BlockBounds) * hb.size(), hipMemcpyHostToDevice, c->stream));
-    UP_TRY(hipMalloc(&d_pos, sizeof(float) * 4 * n));
-    UP_TRY(hipMalloc(&d_cov, sizeof(float) * 9 * n));
-    UP_TRY(hipMalloc(&d_op, sizeof(float) * n));
-    UP_TRY(hipMalloc(&d_sh, sizeof(float) * 48 * n));
+    UP_TRY(dmalloc(c, &d_pos, sizeof(float) * 4 * n));
+    UP_TRY(dmalloc(c, &d_cov, sizeof(float) * 9 * n));
+    UP_TRY(dmalloc(c, &d_op, sizeof(float) * n));
+    UP_TRY(dmalloc(c, &d_sh, sizeof(float) * 48 * n));
     UP_TRY(hipMemcpyAsync(d_pos, pos4, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream));
     UP_TRY(hipMemcpyAsync(d_cov, cov3d, sizeof(float) * 9 * n, hipMemcpyHostToDevice, c->stream));
     UP_TRY(hipMemcpyAsync(d_op, opacity, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
@@ -816,7 +905,8 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
 #undef UP_TRY
     cleanup();
     c->n = n;
-    c->bucket_failed = false; c->bucket_min = 0;   // key storage is sized at the first frame (prepare_binning)
+    c->bucket_failed = false;              // key storage is sized at the first frame (prepare_binning)
+    for (Slot& sl : c->slots) sl.layout_valid = false;
     c->sort_hint = false;
     return SPLAT_OK;
 }
@@ -830,9 +920,9 @@ int splat_compute_cov3d(splat_ctx* c, uint64_t n, const float* scales3, const fl
     hipError_t e = hipSuccess;
     int rc = SPLAT_OK;
     do {
-        if ((e = hipMalloc(&d_s, sizeof(float) * 3 * n)) != hipSuccess) break;
-        if ((e = hipMalloc(&d_r, sizeof(float) * 4 * n)) != hipSuccess) break;
-        if ((e = hipMalloc(&d_o, sizeof(float) * 9 * n)) != hipSuccess) break;
+        if ((e = dmalloc(c, &d_s, sizeof(float) * 3 * n)) != hipSuccess) break;
+        if ((e = dmalloc(c, &d_r, sizeof(float) * 4 * n)) != hipSuccess) break;
+        if ((e = dmalloc(c, &d_o, sizeof(float) * 9 * n)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_s, scales3, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_r, rot4, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
         launch_cov3d(c->stream, n, d_s, d_r, d_o);
@@ -871,6 +961,8 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     if (rc != SPLAT_OK) return rc;
     Slot& s = c->slots[0];
     fc.bucket_cap = 0;          // count only
+    HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)nt + 1), c->stream));   // (one-pass frames leave cursors there)
+    s.layout_valid = false; s.flip = 0;                                                          // ... and will find them gone
     HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
     launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, c->bounds, s.blockinfo, s.d_status);
     launch_scan(c->stream, nt, s.counts, s.offsets, s.cursor, s.order, s.lens, s.d_status, ~0ull, 0u, nt, nt, nt);
@@ -971,7 +1063,7 @@ int splat_render(splat_ctx* c, const splat_camera* cam, uint32_t* argb, splat_st
     if (bytes > c->img_cap) {
         (void)finish_quiet(c);
         dfree(c->d_img); c->img_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_img, bytes));
+        HIP_TRY(c, dmalloc(c, &c->d_img, bytes));
         c->img_cap = bytes;
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_img, argb, bytes, hipMemcpyHostToDevice, c->stream));
@@ -1002,7 +1094,7 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
         if (rc != SPLAT_OK) return rc;
         for (int k = 0; k < splat_ctx::S_IMGS; ++k) {
             dfree(c->s_img[k]); c->s_used[k] = false;
-            HIP_TRY(c, hipMalloc(&c->s_img[k], bytes));
+            HIP_TRY(c, dmalloc(c, &c->s_img[k], bytes));
             HIP_TRY(c, hipMemset(c->s_img[k], 0, bytes));      // a slab context renders its own rows only: the rest reads as zeros
         }
         c->s_cap = bytes;
@@ -1067,7 +1159,7 @@ void* splat_device_alloc(splat_ctx* c, uint64_t bytes) {
     if (!c) return nullptr;
     void* p = nullptr;
     hipError_t e = hipSetDevice(c->cfg.device);
-    if (e == hipSuccess) e = hipMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1));
+    if (e == hipSuccess) e = dmalloc(c, &p, (size_t)std::max<uint64_t>(bytes, 1));
     if (e != hipSuccess) { c->err = std::string("splat_device_alloc: ") + hipGetErrorString(e); return nullptr; }
     return p;
 }
@@ -1075,6 +1167,7 @@ void splat_device_free(splat_ctx* c, void* p) {
     if (!c || !p) return;
     (void)hipSetDevice(c->cfg.device);
     (void)sync_all(c);                      // frames in flight may still be writing the image
+    ledger_del(p);
     (void)hipFree(p);
 }
 int splat_device_upload(splat_ctx* c, void* d_dst, const void* h_src, uint64_t bytes) {
@@ -1108,6 +1201,12 @@ int splat_sync(splat_ctx* c) {
 
 uint64_t splat_frames_dropped(const splat_ctx* c) { return c ? c->frames_dropped : 0; }
 
+uint64_t splat_device_bytes(const splat_ctx* c, uint64_t* peak) {
+    if (!c) return 0;
+    if (peak) *peak = c->dev_bytes_peak;
+    return c->dev_bytes;
+}
+
 int splat_get_timing(splat_ctx* c, double ms_out[6], uint64_t* frames, int32_t reset) {
     if (!c) return SPLAT_ERR_INVALID;
     int rc = splat_sync(c);
@@ -1136,6 +1235,9 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
         // the counting flavour of K1, culling off (same code, same values), then clear its counts again.
         FrameConst fc = c->fc;
         fc.bucket_cap = 0; fc.cull_blocks = 0;
+        Slot& sl = c->slots[c->last_slot];
+        HIP_TRY(c, hipMemsetAsync(sl.counts, 0, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), c->stream));   // (cursors of a one-pass frame)
+        sl.layout_valid = false; sl.flip = 0;
         HIP_TRY(c, hipMemsetAsync(s.d_status, 0, sizeof(FrameStatus), c->stream));
         launch_preprocess(c->stream, c->n, c->planes, c->orig, fc, s.recs, s.depth, s.rect, s.counts, s.vislist, nullptr, nullptr, nullptr, s.d_status);
         HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)c->n_tiles + 1), c->stream));

@@ -39,7 +39,7 @@ struct FrameConst {
     int early_min;         // shortest list the early-out is tried on
     int early_scan8;       // the transmittance scan gives up after this many eighths of the list
     int prio_len;          // lists >= prio_len / 2x / 4x run at wave priority 1 / 2 / 3
-    unsigned int bucket_cap; // one-pass binning: keys per tile bucket (0: two-pass binning with exact lists)
+    unsigned int bucket_cap; // one-pass binning: entries of the key buffer the tiles' regions live in (0: two-pass binning with exact lists)
     int corrected;         // SPLAT_MODE_CORRECTED_PROJECTION: J enters transposed (perspective-shear terms kept)
     int cull_blocks;       // K1 skips 256-Gaussian blocks whose bounds cannot reach the slab (needs lowpass > 0)
 };
@@ -63,6 +63,7 @@ struct FrameStatus {
     unsigned int n_ge8192, n_ge2048;    // tiles whose list has >= 8192 / >= 2048 keys: in `order` they are a prefix
     unsigned int n_ge16384, pad_;       // likewise >= 16384 (the lists sorted as several runs and merged)
     unsigned long long n_blocks_culled; // K1 blocks skipped by the bounds test (filled on the host from the block flags)
+    unsigned long long layout_total;    // one-pass binning: key-buffer entries the regions built from this frame ask for (layout_kernel)
 };
 
 // 48-byte projected record (3 x float4), stored in SLOT order (the Morton order of the scene planes: K1 writes them
@@ -80,11 +81,20 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
                        float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
                        const BlockBounds* bounds,
                        unsigned int* blockinfo /* per block: bit 31 = skipped by culling; one-pass binning: visible | singular << 9 */,
-                       FrameStatus* status);
+                       FrameStatus* status,
+                       const unsigned int* layout = nullptr /* one-pass binning (fc.bucket_cap != 0): counts[t] is the cursor of tile t's
+                                                               region keys[layout[t] .. layout[t+1]); nullptr: two-pass counting */);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
-                 FrameStatus* host_status = nullptr /* pinned, device-visible: the scan also delivers the status there */);
+                 FrameStatus* host_status = nullptr /* pinned, device-visible: the scan also delivers the status there */,
+                 const unsigned int* layout = nullptr /* one-pass binning: the regions the frame was binned into */,
+                 unsigned int* next_layout = nullptr, unsigned int* next_counts = nullptr /* both given: a second workgroup of
+                     the launch builds the regions + cursors of the next frame on this stream (see launch_layout) */);
+// the regions (and cursors) of the slot's next one-pass frame from this frame's lists; an all-zero `layout` with cursors
+// counted from zero is the bootstrap
+void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
+                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status);
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 // grid_big / grid_mid: how many entries of `order` (longest lists first) the 1024- and 512-thread

@@ -10,6 +10,7 @@
 //   K3 sort_tiles_*       per-tile painter's order      src/gaussians.rs:302-303 (stable asc. z)
 //   K4 composite_kernel   euc raster + fragment + blend src/pipelines.rs:127-168
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <type_traits>
 
@@ -370,25 +371,27 @@ struct BucketBinner {
     BucketShared& sh;
     FlatShared& fs;
     const int tiles_x;
-    unsigned int* __restrict__ const gcount;
+    unsigned int* __restrict__ const gcount;      // per tile: the CURSOR of its region (initialised to the region's start)
     unsigned long long* __restrict__ const keys;
-    const unsigned int bcap;
-    unsigned int xstride = 0;
-    unsigned long long* dbg_stamps = nullptr;
+    const unsigned int bcap;                      // entries of the key buffer: nothing is stored at or beyond it
+    // (A run that outgrows its tile's region spills into the next tile's.  Nobody looks: the scan sees the cursor beyond
+    // the region's end and the frame is skipped as a whole -- sort and compositor never read its lists.)
     // this thread's rectangle
     int tx0, tx1, ty0, ty1, w, ntiles;
     bool small, big, hashed, any;
     bool serial;                           // a small rectangle that did not fit the wave's flattened expansion
     unsigned int flat_total;               // pairs of this wave in the flattened expansion (wave-uniform)
     int bx0, by0;
-    unsigned int res[NRES];                // reservations in flight: bucket position of the block's run, per table slot
+    unsigned int res[NRES];                // reservations in flight: position of the block's run in the tile's region, per table slot
 
     __device__ __forceinline__ BucketBinner(BucketShared& s, FlatShared& f, int tiles_x_, unsigned int* g, unsigned long long* k, unsigned int cap)
         : sh(s), fs(f), tiles_x(tiles_x_), gcount(g), keys(k), bcap(cap) {}
     __device__ __forceinline__ static unsigned int hslot(int tx, int ty) { return (unsigned int)(((ty & (HASH_DIM - 1)) << HASH_BITS) | ((tx + 17 * ty) & (HASH_DIM - 1))); }
-    __device__ __forceinline__ void put(unsigned int tile, unsigned int slot, unsigned long long k) const {
-        if (slot < bcap) keys[(size_t)tile * bcap + slot] = k;
+    __device__ __forceinline__ void put_at(unsigned int pos, unsigned long long k) const {
+        if (pos < bcap) keys[pos] = k;
     }
+    // one pair straight on the tile's cursor (blocks the table cannot hold, close-ups)
+    __device__ __forceinline__ void put_direct(unsigned int tile, unsigned long long k) const { put_at(atomicAdd(&gcount[tile], 1u), k); }
     // f(tx, ty, key) for every tile of the thread's aggregated rectangle (see bin_block's each_tile).  Rectangles of
     // more than LANE_T tiles are spread over the lanes of their wave, 64 tiles per round.
     template <typename F>
@@ -480,10 +483,8 @@ struct BucketBinner {
             const unsigned int slot = e & (unsigned int)(HASH_CAP - 1), src = e >> 10;
             const unsigned int khi = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(unsigned int)(key >> 32));
             if (f < flat_total) {
-                const unsigned int pos = atomicAdd(&sh.table[slot], 1u);
-                const int ty = by0 + ((((int)slot >> HASH_BITS) - by0) & (HASH_DIM - 1));
-                const int tx = bx0 + ((((int)slot & (HASH_DIM - 1)) - 17 * ty - bx0) & (HASH_DIM - 1));
-                put((unsigned int)(ty * tiles_x + tx), pos, ((unsigned long long)khi << 32) | (unsigned long long)(i0 + src));
+                const unsigned int pos = atomicAdd(&sh.table[slot], 1u);      // (the table holds positions in the key buffer)
+                put_at(pos, ((unsigned long long)khi << 32) | (unsigned long long)(i0 + src));
             }
         }
     }
@@ -517,9 +518,6 @@ struct BucketBinner {
     __device__ __forceinline__ void issue(unsigned int* __restrict__ blockinfo) {
         const unsigned int tid = threadIdx.x;
         __syncthreads();
-#if SPLAT_K1X == 21
-        __syncthreads();
-#endif
         bx0 = sh.box[0]; by0 = sh.box[1];
         any = sh.box[2] >= 0;
         hashed = any && (sh.box[2] - bx0) < HASH_DIM && (sh.box[3] - by0) < HASH_DIM;
@@ -548,8 +546,9 @@ struct BucketBinner {
             asm volatile("" : "+v"(addr[0]), "+v"(addr[1]), "+v"(addr[2]), "+v"(addr[3]), "+v"(cnt[0]), "+v"(cnt[1]), "+v"(cnt[2]), "+v"(cnt[3]));
 #pragma unroll
             for (int q = 0; q < NRES; ++q)
-                if (cnt[q] && SPLAT_K1X != 23)     // (a global-address-space pointer: through a generic one this is a FLAT atomic, which every later LDS wait would wait for)
+                if (cnt[q])     // (a global-address-space pointer: through a generic one this is a FLAT atomic, which every later LDS wait would wait for)
                     res[q] = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned int*)addr[q], cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
         }
     }
     // place() in two steps, so that the caller can put its record store between them: publish() waits for the
@@ -557,9 +556,6 @@ struct BucketBinner {
     // block through the table; a store issued BEFORE that wait would have to complete first (gfx9 counts loads,
     // atomics and stores in one counter).
     __device__ __forceinline__ void publish() {
-#if SPLAT_K1X == 1 || SPLAT_K1X == 16 || SPLAT_K1X == 21 || SPLAT_K1X == 23 || SPLAT_K1X == 24
-        return;
-#endif
         if (hashed) {
 #pragma unroll
             for (int q = 0; q < NRES; ++q) sh.table[(int)threadIdx.x + 256 * q] = res[q];     // (slots nobody touched are never read)
@@ -567,47 +563,20 @@ struct BucketBinner {
     }
     template <typename AFTER>
     __device__ __forceinline__ void place(unsigned long long key, AFTER after_barrier) {
-#if SPLAT_K1X == 17
-        after_barrier();
-        return;
-#endif
         if (hashed) {
-#if SPLAT_K1X == 24
-            __builtin_amdgcn_s_barrier();
-#else
             __syncthreads();
-#endif
             after_barrier();
-#if SPLAT_K1X == 16 || SPLAT_K1X == 23 || SPLAT_K1X == 24
-            return;
-#endif
-#if SPLAT_K1X != 9 && SPLAT_K1X != 12
             flat_handout(key);
-            each_tile(serial, key, [&](int tx, int ty, unsigned long long k) {
-                const unsigned int slot = atomicAdd(&sh.table[hslot(tx, ty)], 1u);
-#if SPLAT_K1X == 7
-                if (slot == 0xfffffff0u) put((unsigned int)(ty * tiles_x + tx), slot, k);
-#else
-                put((unsigned int)(ty * tiles_x + tx), slot, k);
-#endif
-            });
-#endif
+            each_tile(serial, key, [&](int tx, int ty, unsigned long long k) { put_at(atomicAdd(&sh.table[hslot(tx, ty)], 1u), k); });
         } else {
             after_barrier();
-            if (any)
-                each_tile(small, key, [&](int tx, int ty, unsigned long long k) {
-                    const unsigned int tile = (unsigned int)(ty * tiles_x + tx);
-                    put(tile, atomicAdd(&gcount[tile], 1u), k);
-                });
+            if (any) each_tile(small, key, [&](int tx, int ty, unsigned long long k) { put_direct((unsigned int)(ty * tiles_x + tx), k); });
         }
         // close-ups (wider or taller than the table's window): the whole block takes the tiles of each, one per thread
-#if SPLAT_K1X == 6 || SPLAT_K1X == 7 || SPLAT_K1X == 9 || SPLAT_K1X == 12
-        return;
-#endif
         if (__syncthreads_or(big ? 1 : 0) == 0) return;
         if (big) add_big(sh, tx0, tx1, ty0, ty1, key);
         __syncthreads();
-        expand_big(sh, tiles_x, [&](unsigned int tile, unsigned long long kk) { put(tile, atomicAdd(&gcount[tile], 1u), kk); });
+        expand_big(sh, tiles_x, [&](unsigned int tile, unsigned long long kk) { put_direct(tile, kk); });
     }
 };
 
@@ -673,9 +642,10 @@ __device__ __forceinline__ bool block_may_reach_slab(const BlockBounds& bb, cons
 // whole vertex stage, a 48-B record, the exactly covered pixel rectangle, and per-tile counts.
 // BUCKET = false (two-pass binning): counts only; depth/rect/vislist feed K2, which emits the keys
 //          into exactly sized lists after the scan.
-// BUCKET = true  (one-pass binning): every tile owns a fixed-stride bucket of fc.bucket_cap keys;
-//          the slot reservation that counts a (Gaussian, tile) pair also places its key, so there is
-//          no K2 and no second read of the per-Gaussian data.
+// BUCKET = true  (one-pass binning): every tile owns a REGION of the key buffer, keys[layout[t] .. layout[t + 1]) --
+//          sized from the list the tile had two frames earlier (layout_kernel) -- and counts[t] is the region's cursor;
+//          the reservation that counts a (Gaussian, tile) pair also places its key, so there is no K2 and no
+//          second read of the per-Gaussian data.  fc.bucket_cap = entries of the key buffer.
 // CORRECTED = SPLAT_MODE_CORRECTED_PROJECTION, a compile-time flavour: in the reference's projection the clamped tx/ty
 // and the Jacobian's shear entries only reach the discarded third column of cov (src/gaussians.rs:133-151), so the
 // compiler drops them -- two divisions, the clamps and a third of the products -- when it can see that.
@@ -738,21 +708,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     bool singular = false, in_slab = false;
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
     float F[64];
-#if SPLAT_K1X == 4
-    if (i < n) {
-        float4 acc0 = make_float4(0, 0, 0, 0), acc1 = acc0, acc2 = acc0;
-#pragma unroll
-        for (int p = 0; p < LIVE_PLANES; ++p) {
-            float4 v = planes[(uint64_t)p * n + i];
-            if (p % 3 == 0) { acc0.x += v.x; acc0.y += v.y; acc0.z += v.z; acc0.w += v.w; }
-            else if (p % 3 == 1) { acc1.x += v.x; acc1.y += v.y; acc1.z += v.z; acc1.w += v.w; }
-            else { acc2.x += v.x; acc2.y += v.y; acc2.z += v.z; acc2.w += v.w; }
-        }
-        Rec r; r.a = acc0; r.b = acc1; r.c = acc2;
-        recs[i] = r;
-    }
-    return;
-#endif
     float cx = 0, cy = 0, hx = 0, hy = 0, ca = 0, cb = 0, cc = 0, zview = 0;
     if (i < n) {
         // geometry first: position, opacity, cov3d live in planes 0-3 (64 B); the SH planes are
@@ -760,7 +715,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         // (requesting them before the table reset / culling test / barrier of the prologue, so that its ~8 k cycles run
         // under the loads' flight: measured twice, rounds 2 and 3 -- no gain, 0.147 -> 0.149 ms)
 #pragma unroll
-        for (int p = 0; p < (SPLAT_K1X == 3 ? LIVE_PLANES : 4); ++p) {
+        for (int p = 0; p < 4; ++p) {
             float4 v = planes[(uint64_t)p * n + i];
             F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
@@ -828,26 +783,19 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         }
     }
     std::conditional_t<BUCKET, BucketBinner, NoBinner> binner(sh, fsh, fc.tiles_x, counts, keys, fc.bucket_cap);
-#if SPLAT_K1X == 12 || SPLAT_K1X == 13
-    if constexpr (BUCKET) binner.xstride = (unsigned int)(fc.tiles_x * fc.n_tile_rows + 1);
-#endif
-#if SPLAT_K1X == 30
-    if constexpr (BUCKET) binner.dbg_stamps = stamps;
-#endif
     // The SH planes' loads go out BEFORE the reservations: vector memory returns in order, so loads issued behind
     // the returning atomics could not be consumed before those have made their round trip to the L2 atomic unit
     // (queued behind every other block's atomics on the same hot tile counters) -- the SH stage, the record store
     // and the whole rest of the block used to wait that out.  In this order the reservations are in flight under
     // the SH arithmetic instead.
     Rec r;
-    if (in_slab && SPLAT_K1X != 5) {
+    if (in_slab) {
 #pragma unroll
-        for (int p = (SPLAT_K1X == 3 ? LIVE_PLANES : 4); p < LIVE_PLANES; ++p) {
+        for (int p = 4; p < LIVE_PLANES; ++p) {
             float4 v = planes[(uint64_t)p * n + i];
             F[4 * p] = v.x; F[4 * p + 1] = v.y; F[4 * p + 2] = v.z; F[4 * p + 3] = v.w;
         }
     }
-#if SPLAT_K1X != 2 && SPLAT_K1X != 3
     if constexpr (BUCKET) {
         STAMP(1);
         binner.count(in_slab, singular, tx0, tx1, ty0, ty1);     // the block's pairs per tile, in LDS -- under the loads
@@ -859,8 +807,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         binner.issue(blockinfo);            // reservations in flight from here on
         STAMP(4);
     }
-#endif
-    if (in_slab && SPLAT_K1X != 5) {
+    if (in_slab) {
         const float px = F[0], py = F[1], pz = F[2], opacity = F[3];
         const float* sh = F + 13;
 
@@ -929,21 +876,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     STAMP(5);
     if constexpr (BUCKET) binner.publish();
     STAMP(6);
-    auto store_record = [&] { if (in_slab && SPLAT_K1X != 5) recs[i] = r; };   // slot order: coalesced here, Morton-local for the compositor's gathers
+    auto store_record = [&] { if (in_slab) recs[i] = r; };   // slot order: coalesced here, Morton-local for the compositor's gathers
     if constexpr (!BUCKET) store_record();
     if constexpr (BUCKET) {
         const unsigned long long key = in_slab ? (((unsigned long long)depth_key(zview) << 32) | (unsigned long long)(unsigned int)i) : 0ull;
-#if SPLAT_K1X == 21
-        store_record();
-        if (key == 1ull) recs[0].a.x = 1.0f;
-#elif SPLAT_K1X == 0 || SPLAT_K1X >= 5
         binner.place(key, store_record);        // (the record store goes out behind the barrier of the hand-out)
         STAMP(7);
-        if (SPLAT_K1X == 16 || SPLAT_K1X == 17 || SPLAT_K1X == 23 || SPLAT_K1X == 24) { if (key == 1ull) recs[0].a.x = 1.0f; }
-#else
-        store_record();
-        if (key == 1ull) recs[0].a.x = 1.0f;    // keep `key` alive
-#endif
     } else {
         // compact the slots that reach the slab into vislist (K2 runs over those only)
         {
@@ -1051,6 +989,67 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
     for (unsigned int k = tid; k < m; k += 1024) order[atomicAdd(&start[cls_of(lens[k])], 1u)] = k;
 }
 
+// The key-buffer regions of a slot's NEXT one-pass frame, from the lists of this one: tile k gets room for its list
+// plus a half plus 512 keys (a camera that moves between the two frames shifts lists from tile to tile), regions back to
+// back: next_layout[0 .. m], and next_counts[k] = next_layout[k] -- the cursors start at their regions.  (Per-tile
+// buckets of one fixed stride -- what this replaces -- had to hold the LONGEST list in every tile: 1.07 GB per frame slot
+// at 1080p, 9 GB at 4K with 6 M Gaussians, times two buffers, times four slots in flight; the regions take ~1.6 x the
+// frame's pairs.)  A layout that would outgrow the buffer is cut off at key_entries -- the tiles behind the cut get
+// empty regions, their frame is skipped like any other that outgrows its storage -- and layout_total tells the host
+// how many entries the layout asked for.  One workgroup; every thread a contiguous run of tiles.
+// An empty current layout (all zeros, cursors from zero) makes this the bootstrap: a frame whose keys all fell on the
+// floor still counted its pairs exactly.
+__device__ __forceinline__ unsigned int region_for(unsigned int len) { return (len + (len >> 1) + 512u + 63u) & ~63u; }
+template <int NT>
+__device__ __forceinline__ void build_layout(unsigned int m, const unsigned int* __restrict__ counts, const unsigned int* __restrict__ layout,
+                                             unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
+                                             unsigned int key_entries, FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status,
+                                             unsigned long long* wsum /* LDS, NT / 64 */) {
+    const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned int C = (m + NT - 1u) / NT, k0 = min(tid * C, m), k1 = min(k0 + C, m);
+    // (eight tiles' loads in flight at a time: the kernel is a chain of round trips to L2 otherwise)
+    auto sum_regions = [&](auto&& each) {
+        for (unsigned int kb = k0; kb < k1; kb += 8u) {
+            unsigned int c[8], l[8];
+#pragma unroll
+            for (unsigned int u = 0; u < 8u; ++u) { const unsigned int k = kb + u; c[u] = k < k1 ? counts[k] : 0u; l[u] = k < k1 ? layout[k] : 0u; }
+#pragma unroll
+            for (unsigned int u = 0; u < 8u; ++u) if (kb + u < k1) each(kb + u, region_for(c[u] - l[u]));
+        }
+    };
+    unsigned long long local = 0;
+    sum_regions([&](unsigned int, unsigned int r) { local += r; });
+    unsigned long long v = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = (unsigned long long)__shfl_up((long long)v, o);
+        if ((int)lane >= o) v += t;
+    }
+    if (lane == 63u) wsum[wave] = v;
+    __syncthreads();
+    unsigned long long run = v - local, total = 0;
+#pragma unroll
+    for (unsigned int w = 0; w < NT / 64u; ++w) { const unsigned long long x = wsum[w]; total += x; if (w < wave) run += x; }
+    sum_regions([&](unsigned int k, unsigned int r) {
+        const unsigned int off = (unsigned int)min(run, (unsigned long long)key_entries);
+        next_layout[k] = off; next_counts[k] = off;
+        run += r;
+    });
+    if (tid == 0u) {
+        next_layout[m] = (unsigned int)min(total, (unsigned long long)key_entries);
+        if (status) status->layout_total = total;
+        if (host_status) host_status->layout_total = total;
+    }
+}
+// (on its own: the bootstrap of a slot without a layout; otherwise the second workgroup of the scan's launch)
+__global__ __launch_bounds__(1024) void layout_kernel(unsigned int m, const unsigned int* __restrict__ counts,
+                                                      const unsigned int* __restrict__ layout, unsigned int* __restrict__ next_layout,
+                                                      unsigned int* __restrict__ next_counts, unsigned int key_entries,
+                                                      FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status) {
+    __shared__ unsigned long long wsum[16];
+    build_layout<1024>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, wsum);
+}
+
 // The scan of one-pass binning has no prefix sum to do (a list starts at its bucket): lengths, the
 // frame totals, and the longest-first tile order.  The order is a counting sort by length class whose
 // counters are per-wave rows of LDS (8160 atomics on a handful of shared class counters serialised:
@@ -1062,10 +1061,19 @@ template <int SCAN_NT>
 __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, unsigned int* __restrict__ counts,
                                                            unsigned int* __restrict__ offsets,
                                                            unsigned int* __restrict__ order, unsigned int* __restrict__ lens,
-                                                           FrameStatus* __restrict__ status, unsigned int bucket_cap,
+                                                           FrameStatus* __restrict__ status, const unsigned int* __restrict__ layout,
                                                            unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
-                                                           unsigned int cls_in_lds, FrameStatus* __restrict__ host_status) {
+                                                           unsigned int cls_in_lds, FrameStatus* __restrict__ host_status,
+                                                           unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
+                                                           unsigned int key_entries) {
     constexpr int NCLS = 64;
+    // Workgroup 1 of the launch (when there is one) builds the regions of the next frame on this binning stream from
+    // the same cursors, beside the scan: no launch of its own, nothing added to the chain K1 -> scan -> sort.
+    if (blockIdx.x == 1u) {
+        __shared__ unsigned long long lsum[SCAN_NT / 64];
+        build_layout<SCAN_NT>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, lsum);
+        return;
+    }
     __shared__ unsigned int row[SCAN_NT / 64][NCLS];
     __shared__ unsigned int start[NCLS];
     __shared__ unsigned long long wsum[SCAN_NT / 64];
@@ -1080,24 +1088,32 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
     row[wave][lane] = 0;
     __syncthreads();
     unsigned long long sum = 0;
-    unsigned int mx = 0;
+    unsigned int mx = 0, over = 0;
     // The kernel is a latency chain on the frame's critical path (K1 -> scan -> sort): a thread's counts are
     // fetched eight at a time (eight loads in flight instead of one dependent round trip per tile), and the
     // length class of every tile is parked in LDS for the second pass instead of being read back from memory.
     extern __shared__ unsigned char cls_lds[];            // m bytes when the launch provides them (cls_in_lds)
     constexpr unsigned int U = 8;
     for (unsigned int base = 0; base < m; base += U * SCAN_NT) {
-        unsigned int c[U];
+        // counts[k] is the CURSOR of tile k's region [layout[k], layout[k + 1]): the list's length is how far it moved
+        // (it may have moved past the region's end: those keys were not stored and the frame is skipped).  The cursors
+        // are left alone: layout_kernel re-initialises them together with the regions of the slot's next frame.
+        unsigned int c[U], l0[U], l1[U];
 #pragma unroll
-        for (unsigned int u = 0; u < U; ++u) { const unsigned int k = base + u * SCAN_NT + tid; c[u] = (k < m) ? counts[k] : 0u; }
+        for (unsigned int u = 0; u < U; ++u) {
+            const unsigned int k = base + u * SCAN_NT + tid;
+            c[u] = (k < m) ? counts[k] : 0u; l0[u] = (k < m) ? layout[k] : 0u; l1[u] = (k < m) ? layout[k + 1u] : 0u;
+        }
 #pragma unroll
         for (unsigned int u = 0; u < U; ++u) {
             const unsigned int k = base + u * SCAN_NT + tid;
             if (k < m) {
-                counts[k] = 0;
-                const unsigned int len = min(c[u], bucket_cap);
+                const unsigned int raw = c[u] - l0[u], cap = l1[u] - l0[u];
+                const unsigned int len = min(raw, cap);
+                over |= raw > cap ? 1u : 0u;
+                c[u] = raw;
                 lens[k] = len;
-                offsets[k] = k * bucket_cap;
+                offsets[k] = l0[u];
                 sum += c[u]; mx = max(mx, c[u]);
                 const unsigned int cls = cls_of(len);
                 if (cls_in_lds) cls_lds[k] = (unsigned char)cls;
@@ -1105,6 +1121,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
             }
         }
     }
+    mx |= over ? 0x80000000u : 0u;           // (a list is far shorter than 2^31: the flag rides on the maximum)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
@@ -1133,15 +1150,21 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         }
         offsets[m] = (unsigned int)tot;
         status->n_pairs = tot;
-        status->max_tile_len = mx;
+        status->max_tile_len = mx & 0x7fffffffu;
         status->n_ge16384 = ge[0]; status->n_ge8192 = ge[1]; status->n_ge2048 = ge[2];
-        status->overflow = (mx > bucket_cap) ? 2u : ((ge[1] > grid_big || ge[2] > grid_mid || ge[0] > grid_long) ? 3u : 0u);
+        status->overflow = (mx & 0x80000000u) ? 2u : ((ge[1] > grid_big || ge[2] > grid_mid || ge[0] > grid_long) ? 3u : 0u);
         // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
         status->n_visible = 0; status->n_singular = 0;
         status->n_fallback = 0; status->n_sort_fallback = 0; status->n_iter_scan = 0; status->n_iter_blend = 0;
         status->pad_ = 0; status->n_blocks_culled = 0;
-        // ... and delivers it to the host: everything an asynchronous frame reports is decided here
-        if (host_status) *host_status = *status;
+        // ... and delivers it to the host: everything an asynchronous frame reports is decided here (layout_total, the
+        // last word, belongs to the workgroup that builds the layout: both copies are its to write)
+        if (host_status) {
+            static_assert(offsetof(FrameStatus, layout_total) + 8 == sizeof(FrameStatus), "layout_total is the last word");
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(status);
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(host_status);
+            for (unsigned int q = 0; q < offsetof(FrameStatus, layout_total) / 8u; ++q) dst[q] = src[q];
+        }
     }
     __syncthreads();
     // second pass: thread t keeps the same tiles, so its wave's row offsets are its own
@@ -2339,10 +2362,10 @@ void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* 
 }
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
                        float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
-                       const BlockBounds* bounds, unsigned int* blockinfo, FrameStatus* status) {
+                       const BlockBounds* bounds, unsigned int* blockinfo, FrameStatus* status, const unsigned int* layout) {
     if (!n) return;
     if (!bounds || !blockinfo) fc.cull_blocks = 0;
-    if (!blockinfo) fc.bucket_cap = 0;
+    if (!blockinfo || !layout) fc.bucket_cap = 0;
     const dim3 grid(blocks_for(n, 256)), block(256);
     if (fc.bucket_cap && fc.corrected)
         hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
@@ -2356,9 +2379,10 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
-                 FrameStatus* host_status) {
-    if (bucket_cap)
+                 FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts) {
+    if (bucket_cap && layout)
     {
+        const unsigned int nwg = (next_layout && next_counts) ? 2u : 1u;
         static const char* env = std::getenv("SPLAT_SCAN_THREADS");
         // small grids: 256 threads start at once beside a busy compositor; 4K-sized ones need the width
         const int nt = env ? std::atoi(env) : (m > 12000u ? 1024 : 256);
@@ -2366,18 +2390,22 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         const unsigned int cls_bytes = (m + 15u) & ~15u, in_lds = cls_bytes <= 49152u ? 1u : 0u;
         const unsigned int dyn = in_lds ? cls_bytes : 0u;
         if (nt == 256)
-            hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(1), dim3(256), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long, in_lds, host_status);
+            hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(nwg), dim3(256), dyn, s, m, counts, offsets, order, lens, status, layout,
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap);
         else if (nt == 512)
-            hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(1), dim3(512), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long, in_lds, host_status);
+            hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(nwg), dim3(512), dyn, s, m, counts, offsets, order, lens, status, layout,
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap);
         else
-            hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(1), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, bucket_cap,
-                               grid_big, grid_mid, grid_long, in_lds, host_status);
+            hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(nwg), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, layout,
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
                            bucket_cap, grid_big, grid_mid, grid_long, host_status);
+}
+void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
+                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status) {
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
@@ -2387,7 +2415,7 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
 void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
                  FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max) {
-    if (!n_tiles || SPLAT_K1X) return;      // (K1 timing builds leave stale keys behind: nothing may walk them)
+    if (!n_tiles) return;
     const unsigned int radix_min = sort_radix_min();
     // longest class first (the tiles are ordered longest-first too)
     grid_big = std::min(grid_big, n_tiles); grid_mid = std::min(grid_mid, n_tiles);
@@ -2412,7 +2440,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
                       bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2) {
-    if (!n_tiles || SPLAT_K1X) return;
+    if (!n_tiles) return;
     static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
     if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
     // SPLAT_COMP_LDS_PAD: extra dynamic LDS per workgroup, i.e. an occupancy cap (12 KB are in use:

@@ -163,6 +163,12 @@ class Renderer:
         skipped on the device (storage has been grown: render it again)."""
         self._check(self._L.splat_sync(self._h))
 
+    def device_bytes(self):
+        """(bytes of device memory the context holds now, the most it has held)"""
+        peak = C.c_uint64()
+        now = int(self._L.splat_device_bytes(self._h, C.byref(peak)))
+        return now, int(peak.value)
+
     def frames_dropped(self):
         """frames skipped on the device since the context was created (redone internally or reported)"""
         return int(self._L.splat_frames_dropped(self._h))

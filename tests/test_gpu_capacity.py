@@ -31,6 +31,11 @@ def scene_and_poses():
     near = make_camera(256, 256, (0.0, 0.0, 5.0))
     far = make_camera(256, 256, (0.0, 0.0, 40.0))     # the whole cloud on one or two tiles: lists far beyond a bucket
     r.upload(g)
+    # every frame slot gets tile regions sized for the NEAR pose (a slot without a layout would count its pairs first and
+    # fit any pose: the tests below are about frames that outgrow storage sized from earlier frames)
+    warm = np.zeros((256, 256), np.uint32)
+    for _ in range(6):
+        r.render(near.to_c(0.01), warm)
     yield r, g, near, far
     r.close()
 

@@ -320,9 +320,9 @@ def test_close_up_camera_many_big_rectangles(buckets):
 
 
 def test_binning_paths_agree():
-    """One-pass binning (per-tile buckets filled by K1) and two-pass binning (count, scan, emit) must
-    give the same lists and the same frame; a tile that outgrows its bucket, or buckets that do not
-    fit the byte budget, fall back to two-pass on their own."""
+    """One-pass binning (per-tile regions of the key buffer filled by K1) and two-pass binning (count, scan, emit) must
+    give the same lists and the same frame; key buffers that do not fit the byte budget fall back to two-pass on
+    their own."""
     import os
     g = splat_amd.synthetic_scene(60000, 41)
     g.positions[:, :3] *= 0.6
@@ -363,31 +363,35 @@ def test_binning_paths_agree():
     assert image_diff(out["one"][0], ref)[0] <= TOL_LSB
 
 
-def test_bucket_overflow_grows_buckets_then_falls_back_to_two_pass():
-    """a tile list longer than its bucket: the frame is redone with larger buckets (up to 65536 keys:
-    sorted as runs of 16384 + merge through the second key buffer), and with two-pass binning beyond"""
+def test_lists_longer_than_any_lds_sort_stay_on_one_pass_binning():
+    """every tile owns a REGION of the key buffer sized for its own list, so a list of any length -- 16 385..65 536 keys:
+    sorted as runs of 16 384 + merge through the second key buffer; beyond: radix passes through memory -- stays on
+    one-pass binning (fixed-stride buckets had to grow for the longest list and gave up beyond 65 536 keys), and a
+    scene with short lists afterwards gets a small buffer's worth of regions again"""
     import os
     forced_two_pass = os.environ.get("SPLAT_BUCKETS") == "0"
     r = splat_amd.Renderer()
     try:
-        for n, want_mode in ((40000, "grown"), (130000, "two-pass")):
+        for n, lo, hi in ((40000, 16384, 65536), (130000, 65536, 1 << 30)):
             g = splat_amd.synthetic_scene(n, 17)
             g.positions[:, :3] *= 0.02
             g.compute_cov3d(r)
             cam = make_camera(96, 96)
             img, st, ref, ost = render_both(r, g, cam, 0.01)
-            assert st.max_tile_len > 16384
-            if not forced_two_pass:
-                if want_mode == "grown":
-                    assert st.max_tile_len <= 65536 and r.binning_mode() >= st.max_tile_len, (st.max_tile_len, r.binning_mode())
-                else:
-                    assert st.max_tile_len > 65536 and r.binning_mode() == 0, (st.max_tile_len, r.binning_mode())
+            assert lo < st.max_tile_len <= hi, st.max_tile_len
+            assert forced_two_pass or r.binning_mode() > 0, r.binning_mode()
             assert st.n_pairs == ost.n_tile_pairs
             assert image_diff(img, ref)[0] <= TOL_LSB
-        # a scene that fits afterwards goes back to ordinary one-pass buckets
+            # ... and again, now with regions from the frame before instead of the bootstrap's
+            for _ in range(4):
+                img2 = np.zeros_like(img)
+                st2 = r.render(cam.to_c(0.01), img2)
+                assert np.array_equal(img2, img) and st2.n_pairs == st.n_pairs
         g2 = gpu_scene(r, 20000, 5)
         img, st, ref, ost = render_both(r, g2, make_camera(96, 96), 0.01)
-        assert (0 < r.binning_mode() <= 16384 or forced_two_pass) and image_diff(img, ref)[0] <= TOL_LSB
+        assert (r.binning_mode() > 0 or forced_two_pass) and image_diff(img, ref)[0] <= TOL_LSB
+        now, peak = r.device_bytes()
+        assert 0 < now <= peak
     finally:
         r.close()
 
