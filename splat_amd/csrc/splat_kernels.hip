@@ -360,10 +360,13 @@ __device__ __forceinline__ void bin_block(BinShared& sh, const bool (&vis)[G], c
 // The caller has run bin_preinit() and a barrier.
 // Workspace of the flattened tile expansion (per wave): see BucketBinner::flat_count.
 constexpr int FLAT_CAP = 512;              // (Gaussian, tile) pairs of one wave that go through it (a wave of C3 has ~350)
+// (The run-start marks -- a byte per pair: value = source lane + 1 -- live in the 2 KB of BucketShared's union behind the
+// table, which only the close-up arrays use, later: 10.4 instead of 12.5 KB per workgroup, and a K1 workgroup fits in the
+// 11.5 KB of LDS that seven compositor workgroups leave of a CU.)
 struct FlatShared {
-    unsigned int mark[4][FLAT_CAP / 4];    // bytes: where a source lane's run of tiles begins (value = lane + 1)
     unsigned short exp[4][FLAT_CAP];       // per pair: table slot | source lane << 10, written by the count pass for the hand-out pass
 };
+static_assert(BucketShared::cap >= HASH_CAP + 4 * (FLAT_CAP / 4), "the marks fit behind the table");
 
 struct BucketBinner {
     static constexpr int LANE_T = 9;       // see bin_block
@@ -444,8 +447,9 @@ struct BucketBinner {
         flat_total = fm ? (unsigned int)__builtin_amdgcn_readlane((int)inc, 63 - __builtin_clzll(fm)) : 0u;
         if (flat_total == 0u) return;
         const unsigned int P = inc - n;
-        unsigned char* const mark = reinterpret_cast<unsigned char*>(fs.mark[wave]);
-        fs.mark[wave][lane] = 0u; fs.mark[wave][lane + 64u] = 0u;
+        unsigned int* const markw = sh.table + HASH_CAP + wave * (FLAT_CAP / 4);
+        unsigned char* const mark = reinterpret_cast<unsigned char*>(markw);
+        markw[lane] = 0u; markw[lane + 64u] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (flat) mark[P] = (unsigned char)(lane + 1u);
