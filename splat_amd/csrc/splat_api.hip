@@ -95,6 +95,7 @@ struct splat_ctx {
     bool last_one_pass = false;            // what the previous frame's binning was (the cursors must be zero for two-pass counting)
     unsigned int* zero_layout = nullptr;   // m_alloc zeros: the empty layout of the bootstrap (every key dropped, every pair counted)
     uint64_t dev_bytes = 0, dev_bytes_peak = 0;   // device memory held by this context
+    float region_spare = 4.0f;             // SPLAT_REGION_SPARE: how far a tile's region may grow into the key buffer's spare room (1: not at all)
     uint64_t frame_idx = 0;
     int last_slot = -1;                    // buffer slot of the most recent frame (debug getters)
     bool last_lists_in_memory = false;     // ... and whether its compositor wrote the lists it sorted back to the buckets
@@ -470,7 +471,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         if (!s.layout_valid) {
             HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));
             launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout);
-            launch_layout(bs, m, s.counts, c->zero_layout, s.lay_b, s.counts_b, c->fc.bucket_cap, nullptr, nullptr);
+            launch_layout(bs, m, s.counts, c->zero_layout, s.lay_b, s.counts_b, c->fc.bucket_cap, nullptr, nullptr, c->region_spare);
             s.flip = 1; s.layout_valid = true;
         }
         cursors = s.flip ? s.counts_b : s.counts;
@@ -503,7 +504,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         nx.flip = into; nx.layout_valid = true;
     }
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
-                next_layout, next_counts);
+                next_layout, next_counts, c->region_spare);
     HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
         HIP_TRY(c, hipEventRecord(s.ev_binned, bs));
@@ -769,6 +770,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e8 = std::getenv("SPLAT_DBG_TIGHT_GRIDS")) c->tight_grids = std::atoi(e8) != 0;
     if (const char* e10 = std::getenv("SPLAT_PAIR_BLEND")) c->pair_mode = std::atoi(e10) < 0 ? -1 : (std::atoi(e10) != 0 ? 1 : 0);
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
+    if (const char* e12 = std::getenv("SPLAT_REGION_SPARE")) c->region_spare = std::max(1.0f, (float)std::atof(e12));
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         splat_destroy(c);

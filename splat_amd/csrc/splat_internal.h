@@ -90,11 +90,12 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  FrameStatus* host_status = nullptr /* pinned, device-visible: the scan also delivers the status there */,
                  const unsigned int* layout = nullptr /* one-pass binning: the regions the frame was binned into */,
                  unsigned int* next_layout = nullptr, unsigned int* next_counts = nullptr /* both given: a second workgroup of
-                     the launch builds the regions + cursors of the next frame on this stream (see launch_layout) */);
+                     the launch builds the regions + cursors of the next frame on this stream (see launch_layout) */,
+                 float spare_max = 4.0f /* how far a region may grow into the buffer's spare room */);
 // the regions (and cursors) of the slot's next one-pass frame from this frame's lists; an all-zero `layout` with cursors
 // counted from zero is the bootstrap
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
-                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status);
+                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max = 4.0f);
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 // grid_big / grid_mid: how many entries of `order` (longest lists first) the 1024- and 512-thread

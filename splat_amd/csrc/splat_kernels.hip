@@ -1008,7 +1008,7 @@ template <int NT>
 __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int* __restrict__ counts, const unsigned int* __restrict__ layout,
                                              unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
                                              unsigned int key_entries, FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status,
-                                             unsigned long long* wsum /* LDS, NT / 64 */) {
+                                             unsigned long long* wsum /* LDS, NT / 64 */, float spare_max) {
     const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned int C = (m + NT - 1u) / NT, k0 = min(tid * C, m), k1 = min(k0 + C, m);
     // (eight tiles' loads in flight at a time: the kernel is a chain of round trips to L2 otherwise)
@@ -1021,26 +1021,44 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
             for (unsigned int u = 0; u < 8u; ++u) if (kb + u < k1) each(kb + u, region_for(c[u] - l[u]));
         }
     };
-    unsigned long long local = 0;
+    // block-wide exclusive scan of one value per thread (and the total); two barriers
+    auto block_scan = [&](unsigned long long local, unsigned long long& total) -> unsigned long long {
+        unsigned long long v = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = (unsigned long long)__shfl_up((long long)v, o);
+            if ((int)lane >= o) v += t;
+        }
+        __syncthreads();                                   // (wsum may still be read from the previous scan)
+        if (lane == 63u) wsum[wave] = v;
+        __syncthreads();
+        unsigned long long run = v - local;
+        total = 0;
+#pragma unroll
+        for (unsigned int w = 0; w < NT / 64u; ++w) { const unsigned long long x = wsum[w]; total += x; if (w < wave) run += x; }
+        return run;
+    };
+    unsigned long long local = 0, total = 0;
     sum_regions([&](unsigned int, unsigned int r) { local += r; });
-    unsigned long long v = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long t = (unsigned long long)__shfl_up((long long)v, o);
-        if ((int)lane >= o) v += t;
-    }
-    if (lane == 63u) wsum[wave] = v;
-    __syncthreads();
-    unsigned long long run = v - local, total = 0;
-#pragma unroll
-    for (unsigned int w = 0; w < NT / 64u; ++w) { const unsigned long long x = wsum[w]; total += x; if (w < wave) run += x; }
+    (void)block_scan(local, total);
+    // The buffer is there: what the regions do not ask for is handed out in proportion (up to four times a region's
+    // size), so that a camera that jumps finds room in the tiles its lists move to -- a frame that outgrows a region is
+    // skipped and redone, or lost if it was asynchronous.  C3: 24 M entries for regions that ask for 16 M.
+    const float spare = total ? fminf(spare_max, (float)key_entries / (float)total) : 1.0f;
+    auto grown = [&](unsigned int r) -> unsigned int {
+        return spare > 1.0f ? max(r, (unsigned int)((float)r * spare) & ~63u) : r;    // (the sum stays within key_entries: every term is rounded down)
+    };
+    local = 0;
+    sum_regions([&](unsigned int, unsigned int r) { local += grown(r); });
+    unsigned long long dummy;
+    unsigned long long run = block_scan(local, dummy);
     sum_regions([&](unsigned int k, unsigned int r) {
         const unsigned int off = (unsigned int)min(run, (unsigned long long)key_entries);
         next_layout[k] = off; next_counts[k] = off;
-        run += r;
+        run += grown(r);
     });
+    if (tid == NT - 1u) next_layout[m] = (unsigned int)min(run, (unsigned long long)key_entries);      // (the last thread's run ends the last region)
     if (tid == 0u) {
-        next_layout[m] = (unsigned int)min(total, (unsigned long long)key_entries);
         if (status) status->layout_total = total;
         if (host_status) host_status->layout_total = total;
     }
@@ -1049,9 +1067,9 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
 __global__ __launch_bounds__(1024) void layout_kernel(unsigned int m, const unsigned int* __restrict__ counts,
                                                       const unsigned int* __restrict__ layout, unsigned int* __restrict__ next_layout,
                                                       unsigned int* __restrict__ next_counts, unsigned int key_entries,
-                                                      FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status) {
+                                                      FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status, float spare_max) {
     __shared__ unsigned long long wsum[16];
-    build_layout<1024>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, wsum);
+    build_layout<1024>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, wsum, spare_max);
 }
 
 // The scan of one-pass binning has no prefix sum to do (a list starts at its bucket): lengths, the
@@ -1069,13 +1087,13 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
                                                            unsigned int cls_in_lds, FrameStatus* __restrict__ host_status,
                                                            unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
-                                                           unsigned int key_entries) {
+                                                           unsigned int key_entries, float spare_max) {
     constexpr int NCLS = 64;
     // Workgroup 1 of the launch (when there is one) builds the regions of the next frame on this binning stream from
     // the same cursors, beside the scan: no launch of its own, nothing added to the chain K1 -> scan -> sort.
     if (blockIdx.x == 1u) {
         __shared__ unsigned long long lsum[SCAN_NT / 64];
-        build_layout<SCAN_NT>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, lsum);
+        build_layout<SCAN_NT>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, lsum, spare_max);
         return;
     }
     __shared__ unsigned int row[SCAN_NT / 64][NCLS];
@@ -2383,7 +2401,7 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
-                 FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts) {
+                 FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts, float spare_max) {
     if (bucket_cap && layout)
     {
         const unsigned int nwg = (next_layout && next_counts) ? 2u : 1u;
@@ -2395,21 +2413,21 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         const unsigned int dyn = in_lds ? cls_bytes : 0u;
         if (nt == 256)
             hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(nwg), dim3(256), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max);
         else if (nt == 512)
             hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(nwg), dim3(512), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max);
         else
             hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(nwg), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
                            bucket_cap, grid_big, grid_mid, grid_long, host_status);
 }
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
-                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status) {
-    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status);
+                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max) {
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {

@@ -25,11 +25,20 @@ def oracle_frame(g, cam, init=None):
 
 @pytest.fixture()
 def scene_and_poses():
-    r = splat_amd.Renderer()
+    # (regions exactly as their tiles' lists ask: the spare room of the key buffer -- normally handed out, up to four times
+    # a region's size -- would let the far pose below fit, and these tests are about frames that do NOT fit)
+    saved = os.environ.get("SPLAT_REGION_SPARE")
+    os.environ["SPLAT_REGION_SPARE"] = "1"
+    try:
+        r = splat_amd.Renderer()
+    finally:
+        os.environ.pop("SPLAT_REGION_SPARE", None)
+        if saved is not None:
+            os.environ["SPLAT_REGION_SPARE"] = saved
     g = splat_amd.synthetic_scene(120000, 71)
     g.compute_cov3d(r)
     near = make_camera(256, 256, (0.0, 0.0, 5.0))
-    far = make_camera(256, 256, (0.0, 0.0, 40.0))     # the whole cloud on one or two tiles: lists far beyond a bucket
+    far = make_camera(256, 256, (0.0, 0.0, 40.0))     # the whole cloud on one or two tiles: lists far beyond their regions
     r.upload(g)
     # every frame slot gets tile regions sized for the NEAR pose (a slot without a layout would count its pairs first and
     # fit any pose: the tests below are about frames that outgrow storage sized from earlier frames)
