@@ -1011,8 +1011,25 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
                                              unsigned long long* wsum /* LDS, NT / 64 */, float spare_max) {
     const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned int C = (m + NT - 1u) / NT, k0 = min(tid * C, m), k1 = min(k0 + C, m);
-    // (eight tiles' loads in flight at a time: the kernel is a chain of round trips to L2 otherwise)
+    // A thread's tiles are visited three times (sum of the regions; sum of the grown regions; offsets).  Up to 32 tiles per
+    // thread (1080p with 256 threads) their regions stay in registers after the first visit; more are re-read, eight
+    // tiles' loads in flight at a time -- the kernel is a chain of round trips to L2 otherwise, and the scan's launch
+    // (the frame's chain K1 -> scan -> sort) ends when this workgroup does.
+    constexpr unsigned int KEEP = 32u;
+    const bool keep = C <= KEEP;
+    unsigned int kept[KEEP];
+    bool loaded = false;
     auto sum_regions = [&](auto&& each) {
+        if (keep) {
+            if (!loaded) {
+#pragma unroll
+                for (unsigned int u = 0; u < KEEP; ++u) { const unsigned int k = k0 + u; kept[u] = k < k1 ? region_for(counts[k] - layout[k]) : 0u; }
+                loaded = true;
+            }
+#pragma unroll
+            for (unsigned int u = 0; u < KEEP; ++u) if (k0 + u < k1) each(k0 + u, kept[u]);
+            return;
+        }
         for (unsigned int kb = k0; kb < k1; kb += 8u) {
             unsigned int c[8], l[8];
 #pragma unroll
