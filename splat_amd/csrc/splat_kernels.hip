@@ -58,6 +58,35 @@ __device__ __forceinline__ void mat4_vec(const float* m, float x, float y, float
 }
 __device__ __forceinline__ bool finitef(float v) { return fabsf(v) <= 3.402823466e+38f; }
 
+// Wave64 reductions / scans on the DPP path (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9):
+// six VALU instructions and no LDS traffic, where __shfl_xor / __shfl_up are a ds_bpermute plus address arithmetic per
+// step.  K1 reduces a bounding box and scans a tile count per wave.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_identity(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false); }
+// op over the whole wave, valid in lane 63 only (read it with wave_last)
+template <typename Op>
+__device__ __forceinline__ int wave_reduce_to_last(int v, int identity, Op op) {
+    v = op(v, dpp_or_identity<0x111, 0xf>(identity, v));     // row_shr:1
+    v = op(v, dpp_or_identity<0x112, 0xf>(identity, v));     // row_shr:2
+    v = op(v, dpp_or_identity<0x114, 0xf>(identity, v));     // row_shr:4
+    v = op(v, dpp_or_identity<0x118, 0xf>(identity, v));     // row_shr:8   -> lane 15 of every row holds its row
+    v = op(v, dpp_or_identity<0x142, 0xa>(identity, v));     // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_or_identity<0x143, 0xc>(identity, v));     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave
+    return v;
+}
+__device__ __forceinline__ int wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
+// inclusive prefix sum over the lanes of the wave
+__device__ __forceinline__ unsigned int wave_inclusive_sum(unsigned int x) {
+    int v = (int)x;
+    v += dpp_or_identity<0x111, 0xf>(0, v);
+    v += dpp_or_identity<0x112, 0xf>(0, v);
+    v += dpp_or_identity<0x114, 0xf>(0, v);
+    v += dpp_or_identity<0x118, 0xf>(0, v);
+    v += dpp_or_identity<0x142, 0xa>(0, v);
+    v += dpp_or_identity<0x143, 0xc>(0, v);
+    return (unsigned int)v;
+}
+
 // ---------------------------------------------------------------------------
 // Scene packing (upload time).  GaussianList buffers -> 16 planes of float4, plane p of
 // Gaussian i at planes[p*n + i] so every per-frame load is a coalesced 16 B/lane stream.
@@ -435,12 +464,7 @@ struct BucketBinner {
     __device__ __forceinline__ void flat_count() {
         const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         const unsigned int n = small ? (unsigned int)ntiles : 0u;
-        unsigned int inc = n;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned int t = (unsigned int)__shfl_up((int)inc, o);
-            if ((int)lane >= o) inc += t;
-        }
+        const unsigned int inc = wave_inclusive_sum(n);
         const bool flat = n != 0u && inc <= (unsigned int)FLAT_CAP;
         serial = n != 0u && !flat;
         const unsigned long long fm = __builtin_amdgcn_ballot_w64(flat);
@@ -504,12 +528,12 @@ struct BucketBinner {
         {   // block statistics and bounding box of the aggregated rectangles: wave reduce, LDS atomics by lane 0
             const unsigned int nv = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vis));
             const unsigned int ns = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(singular));
-            int a = small ? tx0 : 0x7fffffff, b = small ? ty0 : 0x7fffffff, c = small ? tx1 : -1, d = small ? ty1 : -1;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                a = min(a, __shfl_xor(a, o)); b = min(b, __shfl_xor(b, o));
-                c = max(c, __shfl_xor(c, o)); d = max(d, __shfl_xor(d, o));
-            }
+            auto mn = [](int x, int y) { return min(x, y); };
+            auto mx = [](int x, int y) { return max(x, y); };
+            const int a = wave_last(wave_reduce_to_last(small ? tx0 : 0x7fffffff, 0x7fffffff, mn));
+            const int b = wave_last(wave_reduce_to_last(small ? ty0 : 0x7fffffff, 0x7fffffff, mn));
+            const int c = wave_last(wave_reduce_to_last(small ? tx1 : -1, -1, mx));
+            const int d = wave_last(wave_reduce_to_last(small ? ty1 : -1, -1, mx));
             if (lane == 0) {
                 if (nv) atomicAdd(&sh.nvis, nv);
                 if (ns) atomicAdd(&sh.nsing, ns);
