@@ -277,18 +277,19 @@ def main():
     if world > 1:
         # balanced contiguous slabs from per-tile-row pair counts; every rank derives the same partition
         slabs = splat_amd.slab_partition_native(R.tile_row_loads(cam_c), world, ROW_OVERHEAD)
-        if not share:
+        # (SPLAT_BENCH_TRY_NATIVE=1 on the shared-GPU test path: attempt the native communicator anyway -- RCCL refuses ranks
+        # that share a device -- so that the fallback and the reason it names are exercised)
+        if not share or os.environ.get("SPLAT_BENCH_TRY_NATIVE") == "1":
             try:        # data plane: the C ABI's own communicator (RCCL); torch.distributed carries the id only
                 box = [splat_amd.Renderer.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0, device=torch.device("cuda", local))
+                dist.broadcast_object_list(box, src=0, device=None if share else torch.device("cuda", local))
                 R.comm_init(box[0], world, rank)
                 R.comm_set_slabs(slabs)
                 gather_kind = "native"
             except Exception as e:      # keep the run alive on the other transport, and say so
                 sys.stderr.write("bench.py rank %d: native RCCL gather unavailable (%s); using torch.distributed\n" % (rank, e))
-        flag = torch.tensor([1 if gather_kind == "native" else 0], device="cuda")
-        if not share:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        flag = torch.tensor([1 if gather_kind == "native" else 0], device="cpu" if share else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             gather_kind = "torch.distributed"
             R.set_slab(*slabs[rank])
