@@ -704,7 +704,18 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
         if (c->iters_valid && c->d_iters) {
             std::vector<uint2> it(m * 4u);
             if (hipMemcpy(it.data(), c->d_iters, sizeof(uint2) * it.size(), hipMemcpyDeviceToHost) == hipSuccess)
+            {
                 for (const uint2& v : it) { st->n_iter_scan += v.x; st->n_iter_blend += v.y; }
+                if (std::getenv("SPLAT_DBG_IMBALANCE")) {      // how much of a tile's four wave slots its slowest wave leaves idle
+                    double sum = 0, held = 0;
+                    for (size_t t = 0; t < m; ++t) {
+                        double mx = 0;
+                        for (int w = 0; w < 4; ++w) { const double cst = 14.0 * it[4 * t + w].x + 50.0 * it[4 * t + w].y + 300.0; sum += cst; mx = std::max(mx, cst); }
+                        held += 4.0 * mx;
+                    }
+                    std::fprintf(stderr, "compositor wave imbalance: sum of wave costs / (4 x slowest wave per tile) = %.3f\n", held > 0 ? sum / held : 1.0);
+                }
+            }
         }
     }
     float t[N_TIMES] = {0};

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""K1 alone on the chip, for one or more builds: usage k1_ab.py [--wl C3] lib.so [lib.so ...]
+"""K1 alone on the chip, for one or more builds (A/B libraries, e.g. experiment builds with -D switches): usage k1_ab.py [--wl C3] lib.so [lib.so ...]
 (each build in its own process, SPLAT_PIPELINE=1, statistics frames -> HIP-event time of the preprocess launch)."""
 import os, subprocess, sys
 if len(sys.argv) >= 3 and sys.argv[1] == "--one":
