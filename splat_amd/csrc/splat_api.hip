@@ -392,7 +392,7 @@ bool compositor_sorts_long_lists(const splat_ctx* c, unsigned int m) {
 bool one_pass_wanted(const splat_ctx* c, unsigned int m) {
     return c->use_buckets && !c->cfg.pair_capacity && m != 0 && !c->bucket_failed;
 }
-constexpr uint64_t KEY_ENTRIES_MAX = 0xfff00000ull - 65536ull;      // (positions beyond it mean "dropped": BucketBinner::DROP)
+constexpr uint64_t KEY_ENTRIES_MAX = 0xfff00000ull - 65536ull;      // (cursors are 32 bits and run past their regions' ends on a frame that overflows: headroom)
 
 int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, unsigned int* n_tiles) {
     if (!cam) return fail(c, SPLAT_ERR_INVALID, "camera is NULL");
