@@ -488,7 +488,7 @@ def main():
         slab_px = (sdist.slab_pixel_rows(slabs[0], H)[1] - sdist.slab_pixel_rows(slabs[0], H)[0]) * W
         comp_bytes = st.n_pairs * 48 + slab_px * 4
         achieved = comp_bytes / (per["composite"] * 1e-3) / 1e9 if per["composite"] > 0 else 0.0
-        traffic, valu_util, prof_src = None, None, None
+        traffic, valu_util, prof_src, valu_insts = None, None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
@@ -497,6 +497,7 @@ def main():
                 kname = next((k for k in sorted(wl) if k.startswith("composite_exact_kernel") and not k.endswith(":detail")), None)
                 traffic = wl.get(kname) if kname else None
                 valu_util = wl.get(kname + ":detail", {}).get("valu_issue_util") if kname else None
+                valu_insts = wl.get(kname + ":detail", {}).get("valu_insts") if kname else None
                 prof_src = tj.get(args.workload + ":source")
             except Exception:
                 traffic = None
@@ -534,9 +535,14 @@ def main():
                          "compositor_work": {"flops_alg": int(tot[3]),
                                              "gflops_alg_per_s": (int(tot[3]) / (per["composite"] * 1e-3) / 1e9) if per["composite"] > 0 else None,
                                              "wave_record_iterations_scan": int(tot[4]), "wave_record_iterations_blend": int(tot[5]),
+                                             "valu_per_wave_record_iteration": (valu_insts / (int(tot[4]) + int(tot[5]))) if (valu_insts and int(tot[4]) + int(tot[5]) > 0) else None,
                                              "what": "flops_alg = sum over pixels of its tile's list length x 25 (BASELINE.md section 4); "
                                                      "iterations = (wave, record) steps the compositor actually took on the "
-                                                     "statistics frame (early-out + coverage compaction), 64 pixels each"},
+                                                     "statistics frame (early-out + coverage compaction), 64 pixels each; "
+                                                     "valu_per_wave_record_iteration = the launch's SQ_INSTS_VALU (committed "
+                                                     "profile) / those iterations: every VALU instruction of the kernel -- "
+                                                     "staging, alpha pass, sort of the short lists -- charged to the walks "
+                                                     "(the blend loop itself is 47 per step, 72 with the bracket's second state)"},
                          "note": "the compositor is bound by VALU issue and LDS latency, not by HBM (DESIGN.md section 4)"},
             "roofline_frame": {"bytes_algorithmic": int(tot[2]), "t_frame_ms": t_frame,
                                "sum_of_kernel_ms": t_gpu,
