@@ -253,8 +253,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     # per-kernel HIP events ride on every 8th asynchronous frame by default (each record is a queue
-    # bubble); a short timed region needs them on every frame to have launches to average over
-    os.environ.setdefault("SPLAT_TIMING_EVERY", "8" if args.steps >= 64 else "1")
+    # bubble); a short timed region takes them on every 4th to have a few launches to average over (on every
+    # frame they cost the 20-step run 4 % of its frame rate)
+    os.environ.setdefault("SPLAT_TIMING_EVERY", "8" if args.steps >= 64 else "4")
     main_mode = splat_amd.MODE_FAST if args.mode == "fast" else splat_amd.MODE_EXACT
     R = splat_amd.Renderer(device=local, mode=main_mode)
     if args.scene:
