@@ -95,6 +95,7 @@ struct splat_ctx {
     bool last_one_pass = false;            // what the previous frame's binning was (the cursors must be zero for two-pass counting)
     unsigned int* zero_layout = nullptr;   // m_alloc zeros: the empty layout of the bootstrap (every key dropped, every pair counted)
     uint64_t dev_bytes = 0, dev_bytes_peak = 0;   // device memory held by this context
+    LaunchKnobs knobs;                     // experiment switches of the launch wrappers (this context's)
     float region_spare = 4.0f;             // SPLAT_REGION_SPARE: how far a tile's region may grow into the key buffer's spare room (1: not at all)
     uint64_t frame_idx = 0;
     int last_slot = -1;                    // buffer slot of the most recent frame (debug getters)
@@ -433,6 +434,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
 // 590 us frame -- so untimed frames (all but every `timing_every`-th of an asynchronous run) record
 // only the one event that tells the host the frame's status has arrived.
 int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = false) {
+    use_launch_knobs(&c->knobs);
     const int r = c->ring_next;
     EvSet& ev = c->ring[r];
     auto mark = [&](int k, hipStream_t st) -> hipError_t { return timed ? hipEventRecord(ev.e[k], st) : hipSuccess; };
@@ -782,6 +784,10 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e10 = std::getenv("SPLAT_PAIR_BLEND")) c->pair_mode = std::atoi(e10) < 0 ? -1 : (std::atoi(e10) != 0 ? 1 : 0);
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
     if (const char* e12 = std::getenv("SPLAT_REGION_SPARE")) c->region_spare = std::max(1.0f, (float)std::atof(e12));
+    if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
+    if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
+    if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
+    if (const char* k4 = std::getenv("SPLAT_COMP_LDS_PAD")) c->knobs.comp_lds_pad = (unsigned int)std::max(0, std::atoi(k4));
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         splat_destroy(c);

@@ -74,6 +74,16 @@ struct Rec {
     float4 c;   // r, g, b, power below which alpha < 1/255 for certain
 };
 
+// Experiment switches of the launch wrappers (SPLAT_SORT_RADIX_MIN, SPLAT_SCAN_THREADS, SPLAT_DBG_NTILES, SPLAT_COMP_LDS_PAD):
+// per context, read at splat_create; use_launch_knobs() makes a context's set current for the calling thread.
+struct LaunchKnobs {
+    unsigned int sort_radix_min = 128;     // lists up to this length use the bitonic network
+    int scan_threads = 0;                  // 0: by the tile count
+    unsigned int dbg_ntiles = 0;           // != 0: composite only the N longest tiles
+    unsigned int comp_lds_pad = 0;         // extra dynamic LDS per compositor workgroup (an occupancy cap)
+};
+void use_launch_knobs(const LaunchKnobs* k);
+
 void launch_pack_scene(hipStream_t s, uint64_t n, const float* pos4, const float* cov3d, const float* opacity,
                        const float* sh, const unsigned int* perm, float4* planes);
 void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* rot4, float* cov3d);

@@ -2397,11 +2397,12 @@ __global__ __launch_bounds__(256, LONG ? 7 : SPLAT_COMP_WAVES) void composite_ex
 // ---------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------
-static unsigned int sort_radix_min() {
-    static const char* rm = std::getenv("SPLAT_SORT_RADIX_MIN");     // lists up to this length use the bitonic network
-    static const unsigned int radix_min = rm ? (unsigned int)std::atoi(rm) : 128u;
-    return radix_min;
-}
+// Experiment switches of the launches below: the CONTEXT's (read from the environment at splat_create), handed over by
+// the API layer for the calling thread before it enqueues a frame -- two contexts of one process may differ.
+static const LaunchKnobs g_default_knobs{};
+static thread_local const LaunchKnobs* g_knobs = &g_default_knobs;
+void use_launch_knobs(const LaunchKnobs* k) { g_knobs = k ? k : &g_default_knobs; }
+static unsigned int sort_radix_min() { return g_knobs->sort_radix_min; }
 static inline unsigned int blocks_for(uint64_t n, unsigned int bs) { return (unsigned int)((n + bs - 1) / bs); }
 
 // Per-DEVICE kernel attributes (the large sort classes need more dynamic LDS than the default limit): called by
@@ -2446,9 +2447,8 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
     if (bucket_cap && layout)
     {
         const unsigned int nwg = (next_layout && next_counts) ? 2u : 1u;
-        static const char* env = std::getenv("SPLAT_SCAN_THREADS");
         // small grids: 256 threads start at once beside a busy compositor; 4K-sized ones need the width
-        const int nt = env ? std::atoi(env) : (m > 12000u ? 1024 : 256);
+        const int nt = g_knobs->scan_threads ? g_knobs->scan_threads : (m > 12000u ? 1024 : 256);
         // one byte of LDS per tile for the length classes (up to 48 KB: a 6-megapixel target), else they are re-read
         const unsigned int cls_bytes = (m + 15u) & ~15u, in_lds = cls_bytes <= 49152u ? 1u : 0u;
         const unsigned int dyn = in_lds ? cls_bytes : 0u;
@@ -2504,12 +2504,10 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
                       bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2) {
     if (!n_tiles) return;
-    static const char* dbg = std::getenv("SPLAT_DBG_NTILES");   // debug: composite only the N longest tiles
-    if (dbg) n_tiles = std::min(n_tiles, (unsigned int)std::atoi(dbg));
+    if (g_knobs->dbg_ntiles) n_tiles = std::min(n_tiles, g_knobs->dbg_ntiles);   // debug: composite only the N longest tiles
     // SPLAT_COMP_LDS_PAD: extra dynamic LDS per workgroup, i.e. an occupancy cap (12 KB are in use:
     // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
-    static const char* padenv = std::getenv("SPLAT_COMP_LDS_PAD");
-    static const unsigned int pad = padenv ? (unsigned int)std::atoi(padenv) : 0u;
+    const unsigned int pad = g_knobs->comp_lds_pad;
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
                            sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u, keys2);
