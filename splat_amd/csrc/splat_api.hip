@@ -858,6 +858,10 @@ void splat_destroy(splat_ctx* c) {
     if (c->bin_stream) (void)hipStreamDestroy(c->bin_stream);
     if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    {   // (nothing of this context may stay in the allocation table: an entry outliving it would be a dangling owner)
+        std::lock_guard<std::mutex> g(g_ledger_mu);
+        for (auto it = g_ledger.begin(); it != g_ledger.end();) it = (it->second.first == c) ? g_ledger.erase(it) : std::next(it);
+    }
     delete c;
 }
 
