@@ -60,6 +60,7 @@ def make_scene(wl, via_ply=False):
             os.remove(path)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ROW_OVERHEAD = 2000.0     # slab balancing: fixed cost of a tile row, in (Gaussian, tile) pairs
+ROW_OVERHEAD_SWAP = 100000.0   # ... when consecutive frames composite side by side (two-image swap chain): tools/slab_try.py auto:8:<overhead>
 
 
 def cpu_baseline(g, cam_c, threads):
@@ -275,9 +276,10 @@ def main():
     R.upload(g)
 
     gather_kind = None
+    swap_chain = False
     if world > 1:
-        # balanced contiguous slabs from per-tile-row pair counts; every rank derives the same partition
-        slabs = splat_amd.slab_partition_native(R.tile_row_loads(cam_c), world, ROW_OVERHEAD)
+        row_loads = R.tile_row_loads(cam_c)
+        slabs = sdist.slab_partition(H, world)               # (placeholder until the transport is known: it decides the balance)
         # (SPLAT_BENCH_TRY_NATIVE=1 on the shared-GPU test path: attempt the native communicator anyway -- RCCL refuses ranks
         # that share a device -- so that the fallback and the reason it names are exercised)
         if not share or os.environ.get("SPLAT_BENCH_TRY_NATIVE") == "1":
@@ -285,32 +287,45 @@ def main():
                 box = [splat_amd.Renderer.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0, device=None if share else torch.device("cuda", local))
                 R.comm_init(box[0], world, rank)
-                R.comm_set_slabs(slabs)
                 gather_kind = "native"
             except Exception as e:      # keep the run alive on the other transport, and say so
                 sys.stderr.write("bench.py rank %d: native RCCL gather unavailable (%s); using torch.distributed\n" % (rank, e))
         flag = torch.tensor([1 if gather_kind == "native" else 0], device="cpu" if share else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        # balanced contiguous slabs from per-tile-row pair counts; every rank derives the same partition.  Over RCCL the
+        # ranks render into a two-image swap chain (splat_set_frame_overlap(2): the compositor of frame N+1 runs beside the
+        # one of frame N and its gather, so a slab's frame costs its work rather than its densest tile's latency) and a
+        # tile row's fixed cost weighs accordingly.
         if int(flag.item()) == 0:
             gather_kind = "torch.distributed"
+            slabs = splat_amd.slab_partition_native(row_loads, world, ROW_OVERHEAD)
             R.set_slab(*slabs[rank])
+        else:
+            swap_chain = os.environ.get("SPLAT_BENCH_SWAP_CHAIN", "1") != "0"
+            slabs = splat_amd.slab_partition_native(row_loads, world, ROW_OVERHEAD_SWAP if swap_chain else ROW_OVERHEAD)
+            R.comm_set_slabs(slabs)
     else:
         slabs = sdist.slab_partition(H, world)
         R.set_slab(*slabs[rank])
     stream = torch.cuda.Stream()
     R.set_stream(stream.cuda_stream)
     image = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    images = [image]
+    if swap_chain:
+        images.append(torch.zeros((H, W), dtype=torch.int32, device="cuda"))
+        R.set_frame_overlap(2)
 
     frame_no = [0]
 
     def step():
         pose = poses[frame_no[0] % len(poses)]
+        image = images[frame_no[0] % len(images)]
         frame_no[0] += 1
         with torch.cuda.stream(stream):
             # color.clear(0) + render_to_buffer (src/main.rs:73-74): one call, the clear fused into the compositor
             R.render_frame_device(pose, image.data_ptr())        # enqueue only
             if gather_kind == "native":
-                R.comm_gather(image.data_ptr(), W, H, 0)         # grouped ncclSend / ncclRecv on the same stream
+                R.comm_gather(image.data_ptr(), W, H, 0)         # grouped ncclSend / ncclRecv behind the frame, on its stream
             elif world > 1:
                 if share:
                     stream.synchronize()     # gloo's CUDA receive is not ordered after this stream's work (NCCL's is)
@@ -372,7 +387,7 @@ def main():
     dev_peak = R.device_bytes()[1]                       # device memory the context has held at most (scene, frame slots, key buffers)
     key_entries = R.binning_mode()
     last_pose = poses[(frame_no[0] - 1) % len(poses)]
-    final = image.clone()
+    final = images[(frame_no[0] - 1) % len(images)].clone()
     # The context overlaps the binning + sort of frame N+1 (its own stream) with the compositor of
     # frame N, so the durations above include time shared with a neighbouring frame's kernels.  For
     # reference, a few frames with a sync after each (nothing overlaps): every kernel alone on the chip.
@@ -513,8 +528,11 @@ def main():
                        "partition": ("one rank per GPU, load-balanced tile-row slabs %s, one gather of slab rows per frame: %s"
                                      % ([b - a for a, b in slabs],
                                         {"native": "grouped ncclSend/ncclRecv issued by the C ABI (splat_comm_gather)",
-                                         "torch.distributed": "torch.distributed batch_isend_irecv"}[gather_kind]))
+                                         "torch.distributed": "torch.distributed batch_isend_irecv"}[gather_kind])
+                                     + ("; frames alternate between two device images (splat_set_frame_overlap(2): the compositors of "
+                                        "consecutive frames share the chip)" if swap_chain else ""))
                                     if world > 1 else "single GPU",
+                       "frame_overlap": 2 if swap_chain else 1,
                        "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len),
                        "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback),
                        "k1_blocks_culled": int(st.n_blocks_culled),

@@ -171,6 +171,19 @@ uint64_t splat_frames_dropped(const splat_ctx* ctx);  /* frames skipped on the d
 /* Device memory this context holds right now (scene planes, per-frame buffers of its frame slots, key buffers, images it
  * allocated); *peak (nullable) = the most it has held since splat_create. */
 uint64_t splat_device_bytes(const splat_ctx* ctx, uint64_t* peak);
+/* Frame overlap for SWAP CHAINS (default 1; SPLAT_FRAME_OVERLAP=2 sets it at splat_create).  The reference's loop clears and
+ * renders ONE buffer per frame (src/main.rs:71-75), and so does every entry point above: the compositors of consecutive
+ * frames run one after the other, in call order, on the context's stream.  A frame that is bound by the latency of its
+ * densest tile's lone wavefront -- a small scene, a tile-row slab of a multi-GPU frame -- then leaves most of the chip idle.
+ * With n = 2 an ASYNCHRONOUS frame (sync == 0, stats == NULL) to an image that no frame in flight touches composites on
+ * a second internal stream, beside the previous frame's compositor: alternate two device images and two frames share
+ * the chip (C2: 5.7 k -> 7.9 k frames/s, an eighth-of-a-frame slab of C3: 0.13 -> 0.08 ms per frame).  Frames to the SAME image
+ * keep their call order (stream order on one lane: in/out blending and clear+render behave as before), synchronous
+ * frames order themselves behind everything in flight, splat_comm_gather follows the frame rendered last.  What changes:
+ * an overlapped frame is no longer ordered against work the CALLER enqueues on splat_stream() -- use splat_sync (or a
+ * synchronous frame) before touching a target image from a stream of your own.  splat_render_stream overlaps the
+ * frames of its own images whatever this setting says. */
+int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */
 /* Run on a caller-owned hipStream_t (e.g. the stream a device image / RCCL gather lives on). */
 int splat_set_stream(splat_ctx* ctx, void* hip_stream);

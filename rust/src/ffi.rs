@@ -69,6 +69,7 @@ extern "C" {
     pub fn splat_frames_dropped(ctx: *const SplatCtx) -> u64;
     pub fn splat_device_bytes(ctx: *const SplatCtx, peak: *mut u64) -> u64;
     pub fn splat_binning_mode(ctx: *mut SplatCtx) -> i64;
+    pub fn splat_set_frame_overlap(ctx: *mut SplatCtx, n: i32) -> c_int;   // 2: frames to different images composite side by side
     pub fn splat_stream(ctx: *mut SplatCtx) -> *mut c_void;               // the hipStream_t the kernels run on
     pub fn splat_set_stream(ctx: *mut SplatCtx, hip_stream: *mut c_void) -> c_int;
     pub fn splat_get_timing(ctx: *mut SplatCtx, ms: *mut f64 /* [6] */, frames: *mut u64, reset: i32) -> c_int;

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("splat_sync", C.c_int, [C.c_void_p]),
     ("splat_frames_dropped", C.c_uint64, [C.c_void_p]),
     ("splat_device_bytes", C.c_uint64, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("splat_set_frame_overlap", C.c_int, [C.c_void_p, C.c_int32]),
     ("splat_stream", C.c_void_p, [C.c_void_p]),
     ("splat_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("splat_get_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),

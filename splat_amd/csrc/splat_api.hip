@@ -169,6 +169,19 @@ struct splat_ctx {
     unsigned int fused_sort_max = 2048;    // SPLAT_FUSED_SORT: lists up to this length are sorted inside the compositor (0: off)
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
     int pipeline = 6;                      // frames in flight on the device (SPLAT_PIPELINE = 1..6, see enqueue_frame)
+    // Compositor LANES (splat_set_frame_overlap, splat_render_stream): the compositors of consecutive frames run one after
+    // the other on the context's stream (lane 0) -- unless the frames go to DIFFERENT images (a swap chain), in which case
+    // the second lane, a stream of its own, takes every other one and two compositors share the chip.  A frame that is
+    // bound by the latency of its densest tile's lone wave (small scenes, multi-GPU slabs) leaves the chip mostly idle:
+    // with two lanes C2 runs at 7.9 k instead of 5.7 k frames/s, an eighth-of-a-frame slab at 0.08 instead of 0.13 ms.
+    struct Lane { const char* lo = nullptr; const char* hi = nullptr; uint64_t seq = 0; int ring = -1; };
+    Lane lane[2];
+    hipStream_t comp2 = nullptr;           // lane 1 (lane 0 is `stream`)
+    int overlap = 1;                       // splat_set_frame_overlap / SPLAT_FRAME_OVERLAP: 2 = asynchronous frames may use lane 1
+    int last_lane = 0;                     // the lane of the most recent frame
+    uint64_t lane_seq = 0;
+    hipEvent_t pre_wait = nullptr;         // one-shot: the next frame's compositor waits for it (splat_render_stream: its image is still crossing PCIe)
+    bool lanes_once = false;               // one-shot: the next frame may take lane 1 whatever `overlap` says (splat_render_stream's own images)
     splat::CommState* comm = nullptr;      // multi-GPU: RCCL communicator + partition (splat_multi.hip)
     std::string err;
 };
@@ -176,6 +189,9 @@ struct splat_ctx {
 namespace splat {
 CommState** ctx_comm_slot(splat_ctx* c) { return &c->comm; }
 hipStream_t ctx_stream(splat_ctx* c) { return c->stream; }
+// the stream the most recent frame's compositor was enqueued on: work that must follow THAT frame (the gather of its rows,
+// the copy of its pixels) goes there -- and the next frame to the same image follows it on the same lane
+hipStream_t frame_stream(splat_ctx* c) { return (c->last_lane && c->comp2) ? c->comp2 : c->stream; }
 int ctx_device(const splat_ctx* c) { return c->cfg.device; }
 int ctx_fail(splat_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
 }  // namespace splat
@@ -322,7 +338,21 @@ int sync_all(splat_ctx* c) {
     if (c->bin_stream) HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
     if (c->sort_stream) HIP_TRY(c, hipStreamSynchronize(c->sort_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->comp2) HIP_TRY(c, hipStreamSynchronize(c->comp2));
     if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    return SPLAT_OK;
+}
+
+// The copy entry points run on the context's stream: they follow what the second lane still holds as well.
+hipError_t join_lanes(splat_ctx* c) {
+    if (!c->comp2 || c->lane[1].seq == 0 || c->lane[1].ring < 0) return hipSuccess;
+    return hipStreamWaitEvent(c->stream, c->ring[c->lane[1].ring].e[7], 0);
+}
+
+// the second compositor lane exists from the first time something may use it
+int ensure_lane(splat_ctx* c) {
+    if (c->comp2 || c->pipeline == 0) return SPLAT_OK;        // (one stream for everything: no lanes)
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->comp2, hipStreamNonBlocking));
     return SPLAT_OK;
 }
 
@@ -433,7 +463,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
 // drains its queue for a few microseconds -- nine of them per frame were ~25 us of bubbles in a
 // 590 us frame -- so untimed frames (all but every `timing_every`-th of an asynchronous run) record
 // only the one event that tells the host the frame's status has arrived.
-int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = false) {
+int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = false, bool may_overlap = false) {
     use_launch_knobs(&c->knobs);
     const int r = c->ring_next;
     EvSet& ev = c->ring[r];
@@ -520,11 +550,32 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
+    // Which lane composites?  Frames to one image stay on one lane (stream order is their write-after-write / in-out
+    // order, as always); a frame to another image takes the other lane when it may.  A frame that must not overlap
+    // (synchronous, statistics, overlap off) goes to lane 0 behind everything lane 1 still holds.
+    int li = 0;
+    const char* const img_lo = reinterpret_cast<const char*>(d_argb);
+    const char* const img_hi = img_lo + (size_t)c->fc.W * (size_t)c->fc.H * 4u;
+    if (c->comp2) {
+        bool ov[2];
+        for (int q = 0; q < 2; ++q) ov[q] = c->lane[q].seq != 0 && img_lo < c->lane[q].hi && c->lane[q].lo < img_hi;
+        if (!may_overlap) li = 0;
+        else if (ov[0] && ov[1]) li = c->lane[0].seq > c->lane[1].seq ? 0 : 1;
+        else if (ov[0] || ov[1]) li = ov[0] ? 0 : 1;
+        else li = c->lane[0].seq <= c->lane[1].seq ? 0 : 1;            // neither holds this image: the one idle for longer
+        const int other = li ^ 1;
+        // (the ring event of a lane's last frame: when the ring wraps onto it the host has waited for that frame first
+        // -- harvest -- so a re-recorded event only ever stands for a LATER frame)
+        if (c->lane[other].seq != 0 && c->lane[other].ring >= 0 && (ov[other] || !may_overlap))
+            HIP_TRY(c, hipStreamWaitEvent(li ? c->comp2 : c->stream, c->ring[c->lane[other].ring].e[7], 0));
+    }
+    hipStream_t cs = li ? c->comp2 : c->stream;
+    if (c->pre_wait) { HIP_TRY(c, hipStreamWaitEvent(cs, c->pre_wait, 0)); c->pre_wait = nullptr; }
     if (c->pipeline) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, s.ev_ready, 0));
+        HIP_TRY(c, hipStreamWaitEvent(cs, s.ev_ready, 0));
     }
-    HIP_TRY(c, mark(5, c->stream));
+    HIP_TRY(c, mark(5, cs));
     uint2* iters = nullptr;
     c->iters_valid = false;
     if (want_iters) {       // statistics frame: every compositor wave leaves its iteration counts (plain stores)
@@ -533,7 +584,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
             HIP_TRY(c, dmalloc(c, &c->d_iters, sizeof(uint2) * (size_t)m * 4u));
             c->iters_alloc = m * 4u;
         }
-        HIP_TRY(c, hipMemsetAsync(c->d_iters, 0, sizeof(uint2) * (size_t)m * 4u, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_iters, 0, sizeof(uint2) * (size_t)m * 4u, cs));
         iters = c->d_iters;
         c->iters_valid = true;
     }
@@ -541,20 +592,22 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // others (C2 316, an eighth-of-a-frame slab 92, C1 36) take the paired one; measured crossover between 316 and 737
     const bool pair_walk = c->pair_mode >= 0 ? c->pair_mode != 0
                                              : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
-    launch_composite(c->stream, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
+    launch_composite(cs, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
                      pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr);
-    HIP_TRY(c, mark(6, c->stream));
+    HIP_TRY(c, mark(6, cs));
     // the scan has already delivered this frame's status to h_status[r]; a statistics frame refreshes it with the late
     // counters (compositor retries, sort fallbacks)
-    if (want_iters) HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], d_st, sizeof(FrameStatus), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipEventRecord(ev.e[7], c->stream));
-    if (c->pipeline) HIP_TRY(c, hipEventRecord(s.ev_free, c->stream));
+    if (want_iters) HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], d_st, sizeof(FrameStatus), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(c, hipEventRecord(ev.e[7], cs));
+    if (c->pipeline) HIP_TRY(c, hipEventRecord(s.ev_free, cs));
     HIP_TRY(c, hipGetLastError());
     s.used = true;
     ev.used = true;
     ev.timed = timed;
     c->last_ring = r;
     c->last_slot = si;
+    c->lane[li].lo = img_lo; c->lane[li].hi = img_hi; c->lane[li].seq = ++c->lane_seq; c->lane[li].ring = r;
+    c->last_lane = li;
     c->last_lists_in_memory = want_iters || c->fused_sort_max == 0;
     return SPLAT_OK;
 }
@@ -775,6 +828,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
     if (const char* e11 = std::getenv("SPLAT_EARLY_SCAN8")) c->early_scan8 = std::min(8, std::max(1, std::atoi(e11)));
     if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
+    if (const char* eo = std::getenv("SPLAT_FRAME_OVERLAP")) c->overlap = std::atoi(eo) >= 2 ? 2 : 1;
     if (const char* e4 = std::getenv("SPLAT_PIPELINE")) { c->pipeline = std::atoi(e4); if (c->pipeline <= 1) c->pipeline = 0; if (c->pipeline > 6) c->pipeline = 6; }
     if (const char* e9 = std::getenv("SPLAT_TIMING_EVERY")) c->timing_every = std::max(1, std::atoi(e9));
     if (const char* e13 = std::getenv("SPLAT_FUSED_SORT")) c->fused_sort_max = std::min(2048, std::max(0, std::atoi(e13)));
@@ -809,6 +863,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         if ((e = hipStreamCreateWithPriority(&c->bin_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
         if ((e = hipStreamCreateWithPriority(&c->sort_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
     }
+    if (c->overlap >= 2 && c->pipeline && (e = hipStreamCreateWithFlags(&c->comp2, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (Slot& s : c->slots) {
         if ((e = dmalloc(c, &s.d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
         if ((e = hipMemset(s.d_status, 0, sizeof(FrameStatus))) != hipSuccess) return bail("hipMemset(status)", e);
@@ -850,6 +905,7 @@ void splat_destroy(splat_ctx* c) {
         if (c->s_copied[k]) (void)hipEventDestroy(c->s_copied[k]);
     }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->comp2) { (void)hipStreamSynchronize(c->comp2); (void)hipStreamDestroy(c->comp2); }
     if (c->h_status) (void)hipHostFree(c->h_status);
     dfree(c->d_status_ring);
     for (auto& s : c->ring)
@@ -868,6 +924,16 @@ void splat_destroy(splat_ctx* c) {
 const char* splat_last_error(const splat_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 void* splat_stream(splat_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int splat_set_frame_overlap(splat_ctx* c, int32_t n) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (n < 1 || n > 2) return fail(c, SPLAT_ERR_INVALID, "frame overlap is 1 or 2");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc = finish_quiet(c);
+    if (rc != SPLAT_OK) return rc;
+    c->overlap = n;
+    return n >= 2 ? ensure_lane(c) : SPLAT_OK;
+}
 
 int splat_set_stream(splat_ctx* c, void* stream) {
     if (!c) return SPLAT_ERR_INVALID;
@@ -1027,6 +1093,8 @@ int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int3
         unsigned int nt;
         rc = build_frame_const(c, cam, &c->fc, &nt);
         if (rc) return rc;
+        if (c->pre_wait) { HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pre_wait, 0)); c->pre_wait = nullptr; }
+        c->last_lane = 0;
         if (clear_first && c->fc.row_px1 > c->fc.row_px0) {
             HIP_TRY(c, hipMemsetAsync((uint32_t*)d_argb + (size_t)c->fc.row_px0 * c->fc.W, 0,
                                       (size_t)(c->fc.row_px1 - c->fc.row_px0) * c->fc.W * 4, c->stream));
@@ -1045,7 +1113,7 @@ int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int3
         if (rc != SPLAT_OK) return rc;
         const bool timed = stats != nullptr || c->timing_every <= 1 || (c->frame_idx % (uint64_t)c->timing_every) == 0;
         c->clear_first = clear_first;
-        rc = enqueue_frame(c, (uint32_t*)d_argb, timed, stats != nullptr);
+        rc = enqueue_frame(c, (uint32_t*)d_argb, timed, stats != nullptr, !sync && !stats && c->comp2 != nullptr && (c->overlap >= 2 || c->lanes_once));
         c->clear_first = false;
         if (rc != SPLAT_OK) return rc;
         if (!sync && !stats) return SPLAT_OK;
@@ -1123,12 +1191,22 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
         c->s_cap = bytes;
     }
     const int k = (int)(c->s_idx++ % (uint64_t)splat_ctx::S_IMGS);
-    // the image must not be cleared while its previous frame is still crossing PCIe
-    if (c->s_used[k]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->s_copied[k], 0));
+    // the image must not be cleared while its previous frame is still crossing PCIe: the compositor waits for that copy,
+    // on whichever lane it runs -- the streaming images are the library's own swap chain, so consecutive frames may
+    // composite side by side (enqueue_frame)
+    rc = ensure_lane(c);
+    if (rc != SPLAT_OK) return rc;
+    c->pre_wait = c->s_used[k] ? c->s_copied[k] : nullptr;
+    c->lanes_once = true;
     rc = splat_render_frame_device(c, cam, c->s_img[k], 0, nullptr);      // clear + render (the clear is fused into the compositor)
+    c->lanes_once = false;
+    if (c->pre_wait) {      // no frame was enqueued (an error, a target without tiles): nothing of this call may run ahead of the copy
+        (void)hipStreamWaitEvent(c->stream, c->pre_wait, 0);
+        c->pre_wait = nullptr; c->last_lane = 0;
+    }
     if (rc != SPLAT_OK) return rc;
     c->s_ring[k] = c->last_ring; c->s_cam[k] = *cam;
-    HIP_TRY(c, hipEventRecord(c->s_rendered[k], c->stream));
+    HIP_TRY(c, hipEventRecord(c->s_rendered[k], frame_stream(c)));
     HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->s_rendered[k], 0));
     HIP_TRY(c, hipMemcpyAsync(argb_out, c->s_img[k], bytes, hipMemcpyDeviceToHost, c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->s_copied[k], c->copy_stream));
@@ -1197,6 +1275,7 @@ int splat_device_upload(splat_ctx* c, void* d_dst, const void* h_src, uint64_t b
     if (!c) return SPLAT_ERR_INVALID;
     if (bytes && (!d_dst || !h_src)) return fail(c, SPLAT_ERR_INVALID, "NULL pointer");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, join_lanes(c));
     HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPLAT_OK;
@@ -1205,6 +1284,7 @@ int splat_device_download(splat_ctx* c, void* h_dst, const void* d_src, uint64_t
     if (!c) return SPLAT_ERR_INVALID;
     if (bytes && (!h_dst || !d_src)) return fail(c, SPLAT_ERR_INVALID, "NULL pointer");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, join_lanes(c));
     HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPLAT_OK;

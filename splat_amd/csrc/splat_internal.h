@@ -134,6 +134,7 @@ hipError_t init_device_kernels();   // per-device kernel attributes; call with t
 struct CommState;                              // RCCL communicator + partition of one context
 CommState** ctx_comm_slot(splat_ctx* c);
 hipStream_t ctx_stream(splat_ctx* c);
+hipStream_t frame_stream(splat_ctx* c);    // the stream the most recent frame's compositor is on (compositor lanes, splat_api.hip)
 int ctx_device(const splat_ctx* c);
 int ctx_fail(splat_ctx* c, int code, const char* msg);
 void comm_release(CommState* s);               // splat_destroy -> here

@@ -275,8 +275,10 @@ int splat_comm_gather(splat_ctx* c, void* d_argb, int32_t w, int32_t h, int32_t 
     // ... unless the loopback hook is on: the rank then moves its own slab rows through RCCL to itself (ncclSend +
     // ncclRecv to the own rank inside one group, which NCCL/RCCL permit), so that the very code path of the
     // multi-rank gather -- group, send, receive, the RCCL kernel on the context's stream -- runs on a one-GPU box.
-    if (st->n_ranks == 1) return loopback_rows(c, st, (uint32_t*)d_argb, w, h, ctx_stream(c));
-    return gather_rows(c, st, (uint32_t*)d_argb, w, h, root, ctx_stream(c));
+    // (behind the most recent frame, on the lane its compositor runs on: the next frame to ANOTHER image composites beside
+    // this gather instead of behind it -- splat_set_frame_overlap)
+    if (st->n_ranks == 1) return loopback_rows(c, st, (uint32_t*)d_argb, w, h, frame_stream(c));
+    return gather_rows(c, st, (uint32_t*)d_argb, w, h, root, frame_stream(c));
 }
 
 int splat_comm_loopback(splat_ctx* c, int32_t on) {
@@ -294,6 +296,7 @@ void splat_comm_destroy(splat_ctx* c) {
     if (*slot) {
         (void)hipSetDevice(ctx_device(c));
         (void)hipStreamSynchronize(ctx_stream(c));
+        if (frame_stream(c) != ctx_stream(c)) (void)hipStreamSynchronize(frame_stream(c));     // (a gather on the second compositor lane)
         comm_release(*slot);
         *slot = nullptr;
     }

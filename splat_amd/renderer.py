@@ -85,6 +85,11 @@ class Renderer:
                                                  n_rows))
         return out
 
+    def set_frame_overlap(self, n):
+        """2: asynchronous frames to DIFFERENT device images (a swap chain) may composite side by side (include/splat_hip.h,
+        splat_set_frame_overlap); 1 (default): one compositor at a time, in call order."""
+        self._check(self._L.splat_set_frame_overlap(self._h, int(n)))
+
     def set_stream(self, stream_ptr):
         self._check(self._L.splat_set_stream(self._h, C.c_void_p(stream_ptr)))
 
