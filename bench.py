@@ -109,6 +109,9 @@ def single_process(args, n, W, H, seed):
     # SPLAT_BENCH_SHARE_GPU=1 (testing only): every rank on device 0 (copy transport instead of RCCL)
     M = splat_amd.MultiRenderer([0] * args.gpus if os.environ.get("SPLAT_BENCH_SHARE_GPU") == "1" else list(range(args.gpus)))
     M.upload(g)
+    swap_chain = os.environ.get("SPLAT_BENCH_SWAP_CHAIN", "1") != "0"
+    if swap_chain:
+        M.set_frame_overlap(2)        # two slab images per device in turn: consecutive frames composite side by side
     slabs = M.balance(cam_c)
     for k in range(SETTLE_FRAMES):                        # setup (see main): the devices out of their idle clocks
         M.render_frame(poses[k % len(poses)])
@@ -137,7 +140,9 @@ def single_process(args, n, W, H, seed):
                                "sh_dim 15), exact mode" % (args.workload, n, W, H, seed),
                    "camera": "36-pose yaw orbit" if args.orbit else "fixed pose",
                    "partition": "ONE process, %d host threads + contexts (splat_multi_*), load-balanced tile-row slabs %s, "
-                                "grouped ncclSend/ncclRecv to rank 0" % (args.gpus, [b - a for a, b in slabs]),
+                                "grouped ncclSend/ncclRecv to rank 0%s" % (args.gpus, [b - a for a, b in slabs],
+                                                                         "; two images per device in turn (splat_multi_set_frame_overlap(2))" if swap_chain else ""),
+                   "frame_overlap": 2 if swap_chain else 1,
                    "n_pairs": int(st.n_pairs), "n_visible": int(st.n_visible)},
         "kernel_ms_slowest_rank": per,
         "multi_gpu_frame_equals_single_gpu_frame": same,

@@ -275,7 +275,14 @@ int splat_multi_render_frame(splat_multi* m, const splat_camera* cam);
  * found while it re-partitions).  Any other error: the first one a rank recorded since the last sync
  * (splat_multi_last_error names the rank). */
 int splat_multi_sync(splat_multi* m);
+/* The root's image that holds the most recent frame (read it after splat_multi_sync).  With frame overlap 2 the frames of
+ * splat_multi_render_frame alternate between two images on every device -- ask again after each frame. */
 void* splat_multi_image(splat_multi* m);
+/* splat_set_frame_overlap for every rank (default 1).  2: every device keeps two slab images and the frames of
+ * splat_multi_render_frame use them in turn, so the compositor (and the row gather) of frame N+1 runs beside frame N's on
+ * each device; the partition weighs a tile row's fixed cost for that.  Waits for the frames in flight; the next frame
+ * partitions again. */
+int splat_multi_set_frame_overlap(splat_multi* m, int32_t n);
 int splat_multi_download(splat_multi* m, uint32_t* argb_out, int32_t w, int32_t h);   /* root image -> host (after a sync) */
 splat_ctx* splat_multi_ctx(splat_multi* m, int32_t rank);  /* the rank's context (statistics, timing); not to be rendered on directly */
 

@@ -92,6 +92,7 @@ extern "C" {
     pub fn splat_multi_upload_scene(m: *mut SplatMulti, n: u64, pos4: *const f32, cov3d: *const f32,
                                     opacity: *const f32, sh: *const f32) -> c_int;
     pub fn splat_multi_balance(m: *mut SplatMulti, cam: *const SplatCamera) -> c_int;
+    pub fn splat_multi_set_frame_overlap(m: *mut SplatMulti, n: i32) -> c_int;
     pub fn splat_multi_get_slabs(m: *const SplatMulti, slabs_out: *mut i32) -> c_int;
     pub fn splat_multi_image(m: *mut SplatMulti) -> *mut c_void;
     pub fn splat_multi_ctx(m: *mut SplatMulti, rank: i32) -> *mut SplatCtx;

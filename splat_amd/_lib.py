@@ -86,6 +86,7 @@ SYMBOLS = [
     ("splat_multi_last_error", C.c_char_p, [C.c_void_p]),
     ("splat_multi_upload_scene", C.c_int, [C.c_void_p, C.c_uint64, _fp, _fp, _fp, _fp]),
     ("splat_multi_balance", C.c_int, [C.c_void_p, C.POINTER(CameraC)]),
+    ("splat_multi_set_frame_overlap", C.c_int, [C.c_void_p, C.c_int32]),
     ("splat_multi_get_slabs", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     ("splat_multi_render", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
     ("splat_multi_render_frame", C.c_int, [C.c_void_p, C.POINTER(CameraC)]),

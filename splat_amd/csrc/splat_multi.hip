@@ -309,7 +309,7 @@ void splat_comm_destroy(splat_ctx* c) {
 // from a FIFO of commands: the caller's thread only posts, so consecutive frames queue up on every device
 // (cross-frame overlap inside each context stays what it is on one GPU) and nobody shares a context.
 namespace {
-enum CmdKind { CMD_UPLOAD, CMD_FRAME, CMD_RENDER_HOST, CMD_SYNC, CMD_LOADS, CMD_SET_SLABS, CMD_ALLOC, CMD_STOP };
+enum CmdKind { CMD_UPLOAD, CMD_FRAME, CMD_RENDER_HOST, CMD_SYNC, CMD_LOADS, CMD_SET_SLABS, CMD_ALLOC, CMD_OVERLAP, CMD_STOP };
 struct Cmd {
     CmdKind kind = CMD_SYNC;
     splat_camera cam{};
@@ -327,8 +327,13 @@ struct Cmd {
 struct Worker {
     int rank = 0, device = 0;
     splat_ctx* ctx = nullptr;
-    uint32_t* img = nullptr;          // this rank's w x h image (device)
+    // this rank's w x h image (device).  With frame overlap 2 (splat_multi_set_frame_overlap) there are two, used in turn
+    // by the frames of splat_multi_render_frame -- every rank counts the same frames, so frame N is in image N & 1
+    // everywhere -- and the compositors of consecutive frames share the chip (splat_set_frame_overlap, splat_api.hip)
+    uint32_t* imgs[2] = {nullptr, nullptr};
     size_t img_px = 0;
+    uint64_t n_frames = 0;            // frames of splat_multi_render_frame so far
+    std::atomic<int> cur{0};          // the image that holds the most recent frame
     hipEvent_t ev_rows = nullptr;     // peer transport: this rank's rows have landed in the root's image
     hipEvent_t ev_root = nullptr;     // peer transport: the root has finished with the previous frame's image (unused so far)
     std::thread th;
@@ -347,6 +352,7 @@ struct splat_multi {
     std::vector<std::unique_ptr<Worker>> w;
     std::vector<int32_t> slabs;
     bool peer = false;                // rows travel as device copies + events instead of RCCL
+    int overlap = 1;                  // splat_multi_set_frame_overlap
     std::mutex abort_mu;
     int img_w = 0, img_h = 0;
     std::string err;
@@ -381,28 +387,34 @@ void worker_main(splat_multi* m, Worker* me) {
     };
     auto ensure_image = [&](int w, int h) -> bool {
         const size_t px = (size_t)w * h;
-        if (px <= me->img_px) return true;
+        const int want = m->overlap >= 2 ? 2 : 1;
+        if (px <= me->img_px && me->imgs[want - 1] != nullptr) return true;
         (void)splat_sync(me->ctx);
-        if (me->img) (void)hipFree(me->img);
-        me->img = nullptr; me->img_px = 0;
-        hipError_t e = hipMalloc(&me->img, px * 4);
-        if (e != hipSuccess) { note(SPLAT_ERR_HIP, std::string("hipMalloc(image): ") + hipGetErrorString(e)); return false; }
-        me->img_px = px;
+        const size_t npx = std::max(px, me->img_px);
+        for (int k = 0; k < 2; ++k) { if (me->imgs[k]) (void)hipFree(me->imgs[k]); me->imgs[k] = nullptr; }
+        me->img_px = 0;
+        for (int k = 0; k < want; ++k) {
+            hipError_t e = hipMalloc(&me->imgs[k], npx * 4);
+            if (e != hipSuccess) { note(SPLAT_ERR_HIP, std::string("hipMalloc(image): ") + hipGetErrorString(e)); return false; }
+        }
+        me->img_px = npx;
         return true;
     };
     // this rank's rows -> the root's image (stream order)
-    auto gather = [&](int w, int h) {
+    auto gather = [&](int w, int h, int k) {
         Worker* root = m->w[0].get();
-        hipStream_t st = (hipStream_t)splat_stream(me->ctx);
-        if (!m->peer) { (void)check(splat_comm_gather(me->ctx, me->img, w, h, 0), "splat_comm_gather"); return; }
+        hipStream_t st = frame_stream(me->ctx);              // behind the frame just enqueued, on its compositor's lane
+        uint32_t* const mine = me->imgs[k];
+        uint32_t* const roots = root->imgs[k];
+        if (!m->peer) { (void)check(splat_comm_gather(me->ctx, mine, w, h, 0), "splat_comm_gather"); return; }
         if (me->rank == 0) return;
         int a, b;
         slab_px(&m->slabs[2 * me->rank], h, &a, &b);
         if (b > a) {
             const size_t off = (size_t)a * w, bytes = (size_t)(b - a) * w * 4;
             hipError_t e = (root->device == me->device)
-                               ? hipMemcpyAsync(root->img + off, me->img + off, bytes, hipMemcpyDeviceToDevice, st)
-                               : hipMemcpyPeerAsync(root->img + off, root->device, me->img + off, me->device, bytes, st);
+                               ? hipMemcpyAsync(roots + off, mine + off, bytes, hipMemcpyDeviceToDevice, st)
+                               : hipMemcpyPeerAsync(roots + off, root->device, mine + off, me->device, bytes, st);
             if (e != hipSuccess) note(SPLAT_ERR_HIP, std::string("row copy to the root: ") + hipGetErrorString(e));
         }
         (void)hipEventRecord(me->ev_rows, st);
@@ -423,6 +435,9 @@ void worker_main(splat_multi* m, Worker* me) {
             case CMD_ALLOC:      // images exist on every rank before any rank's gather addresses the root's
                 (void)ensure_image((int)c.cam.w, (int)c.cam.h);
                 break;
+            case CMD_OVERLAP:
+                (void)check(splat_set_frame_overlap(me->ctx, m->overlap), "splat_set_frame_overlap");
+                break;
             case CMD_LOADS:
                 (void)check(splat_tile_row_loads(me->ctx, &c.cam, c.row_pairs, c.n_rows), "splat_tile_row_loads");
                 break;
@@ -432,8 +447,11 @@ void worker_main(splat_multi* m, Worker* me) {
                 // color.clear(0) + render_to_buffer of src/main.rs:73-74, on this rank's rows only (the clear is fused
                 // into the compositor).  A render that failed still takes part in the gather -- the peers have
                 // enqueued their halves of it -- with whatever its rows hold; the error is reported by the sync.
-                (void)check(splat_render_frame_device(me->ctx, &c.cam, me->img, 0, nullptr), "splat_render_frame_device");
-                gather(w, h);
+                const int k = m->overlap >= 2 ? (int)(me->n_frames & 1ull) : 0;
+                me->n_frames++;
+                (void)check(splat_render_frame_device(me->ctx, &c.cam, me->imgs[k], 0, nullptr), "splat_render_frame_device");
+                gather(w, h, k);
+                me->cur.store(k);
                 break;
             }
             case CMD_RENDER_HOST: {
@@ -444,10 +462,13 @@ void worker_main(splat_multi* m, Worker* me) {
                 const size_t off = (size_t)a * w, bytes = (size_t)std::max(0, b - a) * w * 4;
                 // the slab's rows of the caller's in/out image; the render is synchronous so that a frame that
                 // outgrew its storage is redone here (splat_render_device retries its own frame)
-                if (bytes) (void)hip_ok(hipMemcpyAsync(me->img + off, c.host + off, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync(slab rows in)");
+                // (the synchronous in/out frame always uses image 0: every rank agrees without counting)
+                (void)splat_sync(me->ctx);                   // (frames in flight on the other lane: the copy below is on the context's stream)
+                if (bytes) (void)hip_ok(hipMemcpyAsync(me->imgs[0] + off, c.host + off, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync(slab rows in)");
                 std::memset(&me->stats, 0, sizeof me->stats);
-                (void)check(splat_render_device(me->ctx, &c.cam, me->img, 1, c.want_stats ? &me->stats : nullptr), "splat_render_device");
-                gather(w, h);        // (also after a failure: see CMD_FRAME)
+                (void)check(splat_render_device(me->ctx, &c.cam, me->imgs[0], 1, c.want_stats ? &me->stats : nullptr), "splat_render_device");
+                gather(w, h, 0);     // (also after a failure: see CMD_FRAME)
+                me->cur.store(0);
                 break;
             }
             case CMD_SYNC: {
@@ -586,7 +607,7 @@ void splat_multi_destroy(splat_multi* m) {
     for (auto& w : m->w) {
         (void)hipSetDevice(w->device);
         splat_destroy(w->ctx);        // releases the communicator too
-        if (w->img) (void)hipFree(w->img);
+        for (int k = 0; k < 2; ++k) if (w->imgs[k]) (void)hipFree(w->imgs[k]);
         if (w->ev_rows) (void)hipEventDestroy(w->ev_rows);
     }
     delete m;
@@ -628,8 +649,10 @@ int splat_multi_balance(splat_multi* m, const splat_camera* cam) {
         if (rc != SPLAT_OK) return rc;
         have_loads = true;
     }
-    // row_overhead: a tile row costs something even when it is empty (scan, launch of its tiles); 2000 pairs' worth
-    rc = splat_slab_partition(have_loads ? loads.data() : nullptr, n_rows, k, 2000.0, m->slabs.data());
+    // row_overhead: a tile row costs something even when it is empty (scan, launch of its tiles); 2000 pairs' worth -- and
+    // 100 000 when the compositors of consecutive frames share the chip (frame overlap 2): a slab's frame then costs
+    // its work rather than its densest tile's latency (tools/slab_try.py auto:8:<overhead>)
+    rc = splat_slab_partition(have_loads ? loads.data() : nullptr, n_rows, k, m->overlap >= 2 ? 100000.0 : 2000.0, m->slabs.data());
     if (rc != SPLAT_OK) return mfail(m, rc, "splat_slab_partition");
     m->img_w = (int)cam->w; m->img_h = (int)cam->h;
     Cmd c; c.kind = CMD_SET_SLABS;
@@ -664,7 +687,22 @@ int splat_multi_render_frame(splat_multi* m, const splat_camera* cam) {
 
 int splat_multi_sync(splat_multi* m) { return m ? sync_all_ranks(m) : SPLAT_ERR_INVALID; }
 
-void* splat_multi_image(splat_multi* m) { return (m && !m->w.empty()) ? m->w[0]->img : nullptr; }
+void* splat_multi_image(splat_multi* m) { return (m && !m->w.empty()) ? m->w[0]->imgs[m->w[0]->cur.load()] : nullptr; }
+
+int splat_multi_set_frame_overlap(splat_multi* m, int32_t n) {
+    if (!m) return SPLAT_ERR_INVALID;
+    if (n < 1 || n > 2) return mfail(m, SPLAT_ERR_INVALID, "frame overlap is 1 or 2");
+    int rc = sync_all_ranks(m);
+    if (rc != SPLAT_OK) return rc;
+    if (n == m->overlap) return SPLAT_OK;
+    m->overlap = n;
+    Cmd c; c.kind = CMD_OVERLAP;
+    post_all(m, c);
+    rc = drain(m);
+    if (rc != SPLAT_OK) return rc;
+    m->img_w = 0; m->img_h = 0;          // the next frame partitions again (the balance weighs rows differently) and allocates the second image
+    return SPLAT_OK;
+}
 
 splat_ctx* splat_multi_ctx(splat_multi* m, int32_t rank) {
     return (m && rank >= 0 && rank < (int)m->w.size()) ? m->w[rank]->ctx : nullptr;
@@ -675,9 +713,10 @@ int splat_multi_download(splat_multi* m, uint32_t* out, int32_t w, int32_t h) {
     int rc = sync_all_ranks(m);
     if (rc != SPLAT_OK) return rc;
     Worker* root = m->w[0].get();
-    if (!root->img || (size_t)w * h > root->img_px) return mfail(m, SPLAT_ERR_INVALID, "no frame of that size has been rendered");
+    uint32_t* const img = root->imgs[root->cur.load()];
+    if (!img || (size_t)w * h > root->img_px) return mfail(m, SPLAT_ERR_INVALID, "no frame of that size has been rendered");
     (void)hipSetDevice(root->device);
-    hipError_t e = hipMemcpy(out, root->img, (size_t)w * h * 4, hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(out, img, (size_t)w * h * 4, hipMemcpyDeviceToHost);
     return e == hipSuccess ? SPLAT_OK : mfail(m, SPLAT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
 }
 

@@ -65,6 +65,10 @@ class MultiRenderer:
                                                      _fp(g.sh)))
         self.n = len(g)
 
+    def set_frame_overlap(self, n):
+        """2: every device renders into two slab images in turn, consecutive frames composite side by side (splat_multi_set_frame_overlap)"""
+        self._check(self._L.splat_multi_set_frame_overlap(self._h, int(n)))
+
     def balance(self, cam_c):
         self._check(self._L.splat_multi_balance(self._h, C.byref(cam_c)))
         return self.slabs()

@@ -70,6 +70,20 @@ def test_multi_frame_equals_single_context_frame(devices):
             M.render_frame(cam_c)
         M.sync()
         assert np.array_equal(M.download(392, 520), clear)
+        # ... and with two slab images per rank in turn (splat_multi_set_frame_overlap: consecutive frames composite side
+        # by side on every device, the partition weighs rows for that); an odd number of frames: the other image is current
+        M.set_frame_overlap(2)
+        for _ in range(5):
+            M.render_frame(cam_c)
+        M.sync()
+        assert np.array_equal(M.download(392, 520), clear)
+        M.render_frame(cam_c)
+        M.sync()
+        assert np.array_equal(M.download(392, 520), clear)
+        multi = init.copy()
+        M.render(cam_c, multi)                       # the host in/out form between overlapped frames
+        assert np.array_equal(multi, single)
+        M.set_frame_overlap(1)
         # another target size re-partitions by itself
         cam2 = make_camera(200, 300)
         img2 = np.zeros((200, 300), np.uint32)

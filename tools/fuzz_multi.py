@@ -34,6 +34,7 @@ for case in range(ncases):
     M = splat_amd.MultiRenderer([0] * k)
     try:
         M.upload(g)
+        if case % 2: M.set_frame_overlap(2)               # every other case: two slab images per rank in turn, frames side by side
         if rng.integers(0, 2): M.balance(poses[0])
         got = init.copy(); M.render(poses[0], got)
         if not np.array_equal(got, want_onto):
