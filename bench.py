@@ -429,6 +429,25 @@ def main():
                         R.render_frame_device(cam_c, image.data_ptr())
                     torch.cuda.synchronize()
                     legs["steady_state_400_frames_device_resident_fps"] = 400 / (time.perf_counter() - t1)
+            # (1c) a two-image swap chain (splat_set_frame_overlap(2)): the compositors of consecutive frames share the chip.
+            # Nothing for a frame that fills the chip (C3, C5); a frame bound by its densest tile's lone wave (C1, C2, a
+            # multi-GPU slab) runs a third faster.  Both images must hold the frame `value` rendered.
+            image2 = torch.zeros_like(image)
+            R.set_frame_overlap(2)
+            pair = (image, image2)
+            for k in range(20):
+                R.render_frame_device(last_pose, pair[k % 2].data_ptr())
+            torch.cuda.synchronize()
+            with counted("swap_chain_two_device_images_fps"):
+                t1 = time.perf_counter()
+                for k in range(200):
+                    R.render_frame_device(last_pose, pair[k % 2].data_ptr())
+                settle(R)
+                torch.cuda.synchronize()
+                legs["swap_chain_two_device_images_fps"] = 200 / (time.perf_counter() - t1)
+            legs["swap_chain_frames_equal_value_frame"] = bool(torch.equal(image, final) and torch.equal(image2, final))
+            R.set_frame_overlap(1)
+            del image2
             # (2) host-visible: the literal render_to_buffer -- host image in and out, synchronous (src/main.rs:71-75)
             himg = np.zeros((H, W), np.uint32)
             R.render(cam_c, himg)
@@ -674,6 +693,8 @@ def main():
         for leg in (out.get("extra_legs", {}).get("c3s_surface_scene", {}) or {}).values():
             if isinstance(leg, dict) and "parity" in leg and not (leg["parity"]["max_channel_diff_lsb"] <= 1 and leg["parity"]["pairs_equal"]):
                 parity_ok = False
+        if out.get("extra_legs", {}).get("swap_chain_frames_equal_value_frame") is False:
+            parity_ok = False                  # (frames composited side by side must be the frame composited alone)
         print(json.dumps(out))
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY MISS against the oracle: %s\n" % json.dumps(out["parity"]))

@@ -181,8 +181,9 @@ uint64_t splat_device_bytes(const splat_ctx* ctx, uint64_t* peak);
  * keep their call order (stream order on one lane: in/out blending and clear+render behave as before), synchronous
  * frames order themselves behind everything in flight, splat_comm_gather follows the frame rendered last.  What changes:
  * an overlapped frame is no longer ordered against work the CALLER enqueues on splat_stream() -- use splat_sync (or a
- * synchronous frame) before touching a target image from a stream of your own.  splat_render_stream overlaps the
- * frames of its own images whatever this setting says. */
+ * synchronous frame) before touching a target image from a stream of your own.  splat_render_stream's frames are not
+ * overlapped (the second compositor stream is the one their copies to the host travel on: a stream more would share a
+ * hardware queue with a busy one). */
 int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */
 /* Run on a caller-owned hipStream_t (e.g. the stream a device image / RCCL gather lives on). */

@@ -180,8 +180,8 @@ struct splat_ctx {
     int overlap = 1;                       // splat_set_frame_overlap / SPLAT_FRAME_OVERLAP: 2 = asynchronous frames may use lane 1
     int last_lane = 0;                     // the lane of the most recent frame
     uint64_t lane_seq = 0;
+    bool streamed_call = false;            // splat_render_stream is rendering: its frames stay on lane 0 (lane 1's stream carries their copies)
     hipEvent_t pre_wait = nullptr;         // one-shot: the next frame's compositor waits for it (splat_render_stream: its image is still crossing PCIe)
-    bool lanes_once = false;               // one-shot: the next frame may take lane 1 whatever `overlap` says (splat_render_stream's own images)
     splat::CommState* comm = nullptr;      // multi-GPU: RCCL communicator + partition (splat_multi.hip)
     std::string err;
 };
@@ -338,9 +338,19 @@ int sync_all(splat_ctx* c) {
     if (c->bin_stream) HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
     if (c->sort_stream) HIP_TRY(c, hipStreamSynchronize(c->sort_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->comp2) HIP_TRY(c, hipStreamSynchronize(c->comp2));
-    if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));      // (lane 1 is this stream too)
     return SPLAT_OK;
+}
+
+// the stream (and events) of splat_render_stream's device -> host copies
+hipError_t ensure_copy_stream(splat_ctx* c) {
+    if (c->copy_stream) return hipSuccess;
+    hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    for (int k = 0; k < splat_ctx::S_IMGS && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&c->s_rendered[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->s_copied[k], hipEventDisableTiming);
+    }
+    return e;
 }
 
 // The copy entry points run on the context's stream: they follow what the second lane still holds as well.
@@ -352,7 +362,13 @@ hipError_t join_lanes(splat_ctx* c) {
 // the second compositor lane exists from the first time something may use it
 int ensure_lane(splat_ctx* c) {
     if (c->comp2 || c->pipeline == 0) return SPLAT_OK;        // (one stream for everything: no lanes)
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->comp2, hipStreamNonBlocking));
+    // Lane 1 IS the copy stream of splat_render_stream.  HIP multiplexes its streams onto four hardware queues, and the
+    // context already has four (the caller's, two binning chains, the copy stream): a fifth shares a queue with a busy
+    // one -- measured both ways round, whichever of the two was created later lost a third of its rate (streamed C3
+    // 2570 -> 1840 frames/s, or the swap chain on C2 8100 -> 6060).  The two are never busy together: streamed frames
+    // stay on lane 0 (render_device_impl), so the copy stream carries either copies or lane-1 compositors.
+    HIP_TRY(c, ensure_copy_stream(c));
+    c->comp2 = c->copy_stream;
     return SPLAT_OK;
 }
 
@@ -863,7 +879,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         if ((e = hipStreamCreateWithPriority(&c->bin_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
         if ((e = hipStreamCreateWithPriority(&c->sort_stream, hipStreamNonBlocking, prio)) != hipSuccess) return bail("hipStreamCreate", e);
     }
-    if (c->overlap >= 2 && c->pipeline && (e = hipStreamCreateWithFlags(&c->comp2, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if (c->overlap >= 2 && c->pipeline) { if ((e = ensure_copy_stream(c)) != hipSuccess) return bail("hipStreamCreate", e); c->comp2 = c->copy_stream; }
     for (Slot& s : c->slots) {
         if ((e = dmalloc(c, &s.d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
         if ((e = hipMemset(s.d_status, 0, sizeof(FrameStatus))) != hipSuccess) return bail("hipMemset(status)", e);
@@ -905,7 +921,6 @@ void splat_destroy(splat_ctx* c) {
         if (c->s_copied[k]) (void)hipEventDestroy(c->s_copied[k]);
     }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
-    if (c->comp2) { (void)hipStreamSynchronize(c->comp2); (void)hipStreamDestroy(c->comp2); }
     if (c->h_status) (void)hipHostFree(c->h_status);
     dfree(c->d_status_ring);
     for (auto& s : c->ring)
@@ -932,7 +947,11 @@ int splat_set_frame_overlap(splat_ctx* c, int32_t n) {
     int rc = finish_quiet(c);
     if (rc != SPLAT_OK) return rc;
     c->overlap = n;
-    return n >= 2 ? ensure_lane(c) : SPLAT_OK;
+    if (n >= 2) return ensure_lane(c);
+    c->comp2 = nullptr;                    // (the stream stays: it is the copy stream)
+    c->lane[0] = splat_ctx::Lane{}; c->lane[1] = splat_ctx::Lane{};
+    c->last_lane = 0;
+    return SPLAT_OK;
 }
 
 int splat_set_stream(splat_ctx* c, void* stream) {
@@ -1113,7 +1132,7 @@ int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int3
         if (rc != SPLAT_OK) return rc;
         const bool timed = stats != nullptr || c->timing_every <= 1 || (c->frame_idx % (uint64_t)c->timing_every) == 0;
         c->clear_first = clear_first;
-        rc = enqueue_frame(c, (uint32_t*)d_argb, timed, stats != nullptr, !sync && !stats && c->comp2 != nullptr && (c->overlap >= 2 || c->lanes_once));
+        rc = enqueue_frame(c, (uint32_t*)d_argb, timed, stats != nullptr, !sync && !stats && c->comp2 != nullptr && c->overlap >= 2 && !c->streamed_call);
         c->clear_first = false;
         if (rc != SPLAT_OK) return rc;
         if (!sync && !stats) return SPLAT_OK;
@@ -1173,13 +1192,7 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
     int rc = build_frame_const(c, cam, &fc, &nt);
     if (rc != SPLAT_OK) return rc;
     const size_t bytes = (size_t)fc.W * fc.H * 4;
-    if (!c->copy_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int k = 0; k < splat_ctx::S_IMGS; ++k) {
-            HIP_TRY(c, hipEventCreateWithFlags(&c->s_rendered[k], hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->s_copied[k], hipEventDisableTiming));
-        }
-    }
+    HIP_TRY(c, ensure_copy_stream(c));
     if (bytes > c->s_cap) {
         rc = sync_all(c);
         if (rc != SPLAT_OK) return rc;
@@ -1191,15 +1204,12 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
         c->s_cap = bytes;
     }
     const int k = (int)(c->s_idx++ % (uint64_t)splat_ctx::S_IMGS);
-    // the image must not be cleared while its previous frame is still crossing PCIe: the compositor waits for that copy,
-    // on whichever lane it runs -- the streaming images are the library's own swap chain, so consecutive frames may
-    // composite side by side (enqueue_frame)
-    rc = ensure_lane(c);
-    if (rc != SPLAT_OK) return rc;
+    // the image must not be cleared while its previous frame is still crossing PCIe: the compositor waits for that copy.
+    // (Streamed frames stay on lane 0 whatever the frame overlap: lane 1's stream is the one their copies travel on.)
     c->pre_wait = c->s_used[k] ? c->s_copied[k] : nullptr;
-    c->lanes_once = true;
+    c->streamed_call = true;
     rc = splat_render_frame_device(c, cam, c->s_img[k], 0, nullptr);      // clear + render (the clear is fused into the compositor)
-    c->lanes_once = false;
+    c->streamed_call = false;
     if (c->pre_wait) {      // no frame was enqueued (an error, a target without tiles): nothing of this call may run ahead of the copy
         (void)hipStreamWaitEvent(c->stream, c->pre_wait, 0);
         c->pre_wait = nullptr; c->last_lane = 0;
