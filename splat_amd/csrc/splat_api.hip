@@ -805,6 +805,11 @@ void free_scene(splat_ctx* c) {
 
 }  // namespace
 
+namespace splat {
+// wait for everything this context has enqueued; a frame found skipped stays pending for the next splat_sync to report
+int ctx_quiesce(splat_ctx* c) { return finish_quiet(c); }
+}  // namespace splat
+
 extern "C" {
 
 void splat_default_config(splat_config* cfg) {

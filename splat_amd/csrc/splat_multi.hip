@@ -463,7 +463,9 @@ void worker_main(splat_multi* m, Worker* me) {
                 // the slab's rows of the caller's in/out image; the render is synchronous so that a frame that
                 // outgrew its storage is redone here (splat_render_device retries its own frame)
                 // (the synchronous in/out frame always uses image 0: every rank agrees without counting)
-                (void)splat_sync(me->ctx);                   // (frames in flight on the other lane: the copy below is on the context's stream)
+                // (frames in flight on the other lane: the copy below is on the context's stream; a loss found while
+                // waiting stays pending for the caller's next splat_multi_sync, as before)
+                if (m->overlap >= 2) (void)check(ctx_quiesce(me->ctx), "waiting for the frames in flight");
                 if (bytes) (void)hip_ok(hipMemcpyAsync(me->imgs[0] + off, c.host + off, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync(slab rows in)");
                 std::memset(&me->stats, 0, sizeof me->stats);
                 (void)check(splat_render_device(me->ctx, &c.cam, me->imgs[0], 1, c.want_stats ? &me->stats : nullptr), "splat_render_device");
