@@ -174,8 +174,14 @@ struct splat_ctx {
     // the second lane, a stream of its own, takes every other one and two compositors share the chip.  A frame that is
     // bound by the latency of its densest tile's lone wave (small scenes, multi-GPU slabs) leaves the chip mostly idle:
     // with two lanes C2 runs at 7.9 k instead of 5.7 k frames/s, an eighth-of-a-frame slab at 0.08 instead of 0.13 ms.
-    struct Lane { const char* lo = nullptr; const char* hi = nullptr; uint64_t seq = 0; int ring = -1; };
+    // lane[q]: its most recent frame (sequence number, event-ring entry).  img_tab: the most recent frame of every image
+    // seen lately (address range, lane, ring entry) -- hazards are decided per IMAGE: with three images in rotation the
+    // earlier frame to an image is not its lane's last one.
+    struct Lane { uint64_t seq = 0; int ring = -1; };
     Lane lane[2];
+    struct ImgRec { const char* lo = nullptr; const char* hi = nullptr; uint64_t seq = 0; int ring = -1; int lane = 0; };
+    static constexpr int N_IMG_TAB = 8;
+    ImgRec img_tab[N_IMG_TAB];
     hipStream_t comp2 = nullptr;           // lane 1 (lane 0 is `stream`)
     int overlap = 1;                       // splat_set_frame_overlap / SPLAT_FRAME_OVERLAP: 2 = asynchronous frames may use lane 1
     int last_lane = 0;                     // the lane of the most recent frame
@@ -573,17 +579,33 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const char* const img_lo = reinterpret_cast<const char*>(d_argb);
     const char* const img_hi = img_lo + (size_t)c->fc.W * (size_t)c->fc.H * 4u;
     if (c->comp2) {
-        bool ov[2];
-        for (int q = 0; q < 2; ++q) ov[q] = c->lane[q].seq != 0 && img_lo < c->lane[q].hi && c->lane[q].lo < img_hi;
+        auto touches = [&](const splat_ctx::ImgRec& e) { return e.seq != 0 && img_lo < e.hi && e.lo < img_hi; };
+        const splat_ctx::ImgRec* newest = nullptr;        // the most recent frame to (a part of) this image
+        for (const auto& e : c->img_tab)
+            if (touches(e) && (!newest || e.seq > newest->seq)) newest = &e;
         if (!may_overlap) li = 0;
-        else if (ov[0] && ov[1]) li = c->lane[0].seq > c->lane[1].seq ? 0 : 1;
-        else if (ov[0] || ov[1]) li = ov[0] ? 0 : 1;
-        else li = c->lane[0].seq <= c->lane[1].seq ? 0 : 1;            // neither holds this image: the one idle for longer
-        const int other = li ^ 1;
-        // (the ring event of a lane's last frame: when the ring wraps onto it the host has waited for that frame first
-        // -- harvest -- so a re-recorded event only ever stands for a LATER frame)
-        if (c->lane[other].seq != 0 && c->lane[other].ring >= 0 && (ov[other] || !may_overlap))
-            HIP_TRY(c, hipStreamWaitEvent(li ? c->comp2 : c->stream, c->ring[c->lane[other].ring].e[7], 0));
+        else if (newest) li = newest->lane;
+        else li = c->lane[0].seq <= c->lane[1].seq ? 0 : 1;            // an image nobody holds: the lane idle for longer
+        hipStream_t mine = li ? c->comp2 : c->stream;
+        // Frames to this image on the OTHER lane come first.  (Ring events: when the ring wraps onto an entry the host
+        // has waited for that frame -- harvest -- so a re-recorded event only ever stands for a LATER frame.)
+        for (const auto& e : c->img_tab)
+            if (touches(e) && e.lane != li && e.ring >= 0) HIP_TRY(c, hipStreamWaitEvent(mine, c->ring[e.ring].e[7], 0));
+        if (!may_overlap && li == 0 && c->lane[1].seq != 0 && c->lane[1].ring >= 0)
+            HIP_TRY(c, hipStreamWaitEvent(mine, c->ring[c->lane[1].ring].e[7], 0));
+        // this frame's entry: the image's own one, else a free one, else the oldest -- whose frame this one then follows
+        // (an image that drops out of the table must not be in flight any more)
+        splat_ctx::ImgRec* slot = nullptr;
+        for (auto& e : c->img_tab) if (e.seq != 0 && e.lo == img_lo && e.hi == img_hi) { slot = &e; break; }
+        if (!slot) for (auto& e : c->img_tab) if (e.seq == 0) { slot = &e; break; }
+        if (!slot) {
+            for (auto& e : c->img_tab) if (!slot || e.seq < slot->seq) slot = &e;
+            if (slot->ring >= 0) {      // (both lanes: whichever lane the forgotten image's next frame takes, it follows)
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ring[slot->ring].e[7], 0));
+                HIP_TRY(c, hipStreamWaitEvent(c->comp2, c->ring[slot->ring].e[7], 0));
+            }
+        }
+        slot->lo = img_lo; slot->hi = img_hi; slot->seq = c->lane_seq + 1; slot->ring = r; slot->lane = li;
     }
     hipStream_t cs = li ? c->comp2 : c->stream;
     if (c->pre_wait) { HIP_TRY(c, hipStreamWaitEvent(cs, c->pre_wait, 0)); c->pre_wait = nullptr; }
@@ -622,7 +644,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     ev.timed = timed;
     c->last_ring = r;
     c->last_slot = si;
-    c->lane[li].lo = img_lo; c->lane[li].hi = img_hi; c->lane[li].seq = ++c->lane_seq; c->lane[li].ring = r;
+    c->lane[li].seq = ++c->lane_seq; c->lane[li].ring = r;
     c->last_lane = li;
     c->last_lists_in_memory = want_iters || c->fused_sort_max == 0;
     return SPLAT_OK;
@@ -955,6 +977,7 @@ int splat_set_frame_overlap(splat_ctx* c, int32_t n) {
     if (n >= 2) return ensure_lane(c);
     c->comp2 = nullptr;                    // (the stream stays: it is the copy stream)
     c->lane[0] = splat_ctx::Lane{}; c->lane[1] = splat_ctx::Lane{};
+    for (auto& e : c->img_tab) e = splat_ctx::ImgRec{};
     c->last_lane = 0;
     return SPLAT_OK;
 }

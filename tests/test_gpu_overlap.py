@@ -124,6 +124,47 @@ def test_frames_to_one_image_keep_their_order_with_overlap_on(scene):
         r.close()
 
 
+def test_three_images_in_rotation_with_a_long_frame_in_front(scene):
+    """triple buffering: X (from inside the cloud: a long binning chain, so its compositor starts late), W (from far away:
+    the cloud on a few tiles, a long compositor), Y, X again.  The second frame to X must not start before the first has
+    finished although two other frames were enqueued in between -- the hazard is decided per image, not from each lane's
+    last frame only (a build that did the latter left the first frame's pixels in tens of thousands of places: the empty
+    tiles of the second frame are written at once, the first frame's tail lands on top).  Inside and far poses alternate, so
+    that every frame's tile regions come from a frame of its own kind two frames earlier and none is skipped."""
+    seq = [make_camera(H, W, (0.1, 0.1, 0.6), yaw=0.4).to_c(0.01), make_camera(H, W, (0.0, 0.0, 9.0)).to_c(0.01),
+           make_camera(H, W, (0.11, 0.1, 0.61), yaw=0.4).to_c(0.01), make_camera(H, W, (0.02, 0.0, 9.05)).to_c(0.01)]
+    init = np.zeros((H, W), np.uint32)
+    scene = splat_amd.synthetic_scene(700000, 92)           # (long lists from inside: the first frame's compositor outlasts two whole short frames)
+    r = splat_amd.Renderer()
+    scene.compute_cov3d(r)
+    r.close()
+    want = serial_frames(scene, seq, init, clear=True)
+    r = splat_amd.Renderer()
+    try:
+        r.upload(scene)
+        r.set_frame_overlap(2)
+        x, w, y = r.device_image(init), r.device_image(init), r.device_image(init)
+        checked = 0
+        for rep in range(8):
+            for c in seq * 2:                                 # (synchronous frames: every repetition starts from the same lanes)
+                r.render_frame_device(c, x, sync=True)
+            r.render_frame_device(seq[0], x)
+            r.render_frame_device(seq[1], w)
+            r.render_frame_device(seq[2], y)
+            r.render_frame_device(seq[3], x)
+            if not settled(r):
+                continue
+            assert np.array_equal(r.device_download(x, H, W), want[3]), rep
+            assert np.array_equal(r.device_download(w, H, W), want[1]), rep
+            assert np.array_equal(r.device_download(y, H, W), want[2]), rep
+            checked += 1
+        assert checked >= 4, checked
+        for d in (x, w, y):
+            r.device_free(d)
+    finally:
+        r.close()
+
+
 def test_overlap_setting_is_validated_and_can_be_switched_back(scene):
     r = splat_amd.Renderer()
     try:

@@ -43,9 +43,11 @@ for case in range(ncases):
     tot_dropped += dropped; tot_frames += len(poses)
     got = [R.device_download(im, H, W) for im in imgs]
     wrong = 0
+    refs = []
     for k, p in enumerate(poses):
         ref = np.zeros((H, W), np.uint32)
         R.render(p, ref)
+        refs.append(ref)
         if not np.array_equal(got[k], ref):
             if np.array_equal(got[k], garbage): wrong += 1           # skipped: untouched
             else:
@@ -54,6 +56,30 @@ for case in range(ncases):
     if wrong > dropped:
         bad += 1
         print("CASE %d seed %d: %d frames untouched but only %d reported dropped" % (case, seed0 + case, wrong, dropped))
+    # the same frames into THREE images in rotation (a swap chain: with SPLAT_FRAME_OVERLAP=2 consecutive frames composite
+    # side by side, and a frame must still follow the earlier frames to ITS image): every image ends up holding the last
+    # frame rendered to it -- or an earlier one of its frames / nothing, if later ones were skipped and reported
+    rot = [R.device_image(garbage) for _ in range(3)]
+    d1 = R.frames_dropped()
+    for k, p in enumerate(poses):
+        R.render_frame_device(p, rot[k % 3])
+    try:
+        R.sync()
+    except SplatError:
+        pass
+    dropped_rot = R.frames_dropped() - d1
+    tot_dropped += dropped_rot; tot_frames += len(poses)
+    stale = 0
+    for j in range(3):
+        mine = [k for k in range(len(poses)) if k % 3 == j]
+        have = R.device_download(rot[j], H, W)
+        if np.array_equal(have, refs[mine[-1]]): continue
+        if np.array_equal(have, garbage) or any(np.array_equal(have, refs[k]) for k in mine[:-1]): stale += 1
+        else:
+            bad += 1; print("CASE %d seed %d: image %d of the rotation holds none of its frames (%d px off its last one)" % (case, seed0 + case, j, int((have != refs[mine[-1]]).sum())))
+    if stale > dropped_rot:
+        bad += 1; print("CASE %d seed %d: %d images of the rotation hold an older frame but only %d frames were reported dropped" % (case, seed0 + case, stale, dropped_rot))
+    for im in rot: R.device_free(im)
     # slabs == full frame
     p = poses[int(rng.integers(0, len(poses)))]
     full = np.zeros((H, W), np.uint32); R.render(p, full)
