@@ -807,6 +807,16 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
                         held += 4.0 * mx;
                     }
                     std::fprintf(stderr, "compositor wave imbalance: sum of wave costs / (4 x slowest wave per tile) = %.3f\n", held > 0 ? sum / held : 1.0);
+                    // ... and what the early-out scan bought: waves that scanned, split by whether the exact walk then took
+                    // about as many steps as the scan (it found its start) or at least twice as many (it gave up half way)
+                    uint64_t sc_ok = 0, bl_ok = 0, sc_no = 0, bl_no = 0, w_ok = 0, w_no = 0, bl_none = 0;
+                    for (const uint2& v : it) {
+                        if (v.x == 0) { bl_none += v.y; continue; }
+                        if ((uint64_t)v.y * 10u >= (uint64_t)v.x * 18u) { sc_no += v.x; bl_no += v.y; ++w_no; } else { sc_ok += v.x; bl_ok += v.y; ++w_ok; }
+                    }
+                    std::fprintf(stderr, "early-out scan: %llu waves found a start (scan %llu, blend %llu steps), %llu did not (scan %llu, blend %llu); waves without a scan: blend %llu\n",
+                                 (unsigned long long)w_ok, (unsigned long long)sc_ok, (unsigned long long)bl_ok, (unsigned long long)w_no, (unsigned long long)sc_no,
+                                 (unsigned long long)bl_no, (unsigned long long)bl_none);
                 }
             }
         }
