@@ -169,9 +169,9 @@ struct splat_ctx {
     unsigned int fused_sort_max = 2048;    // SPLAT_FUSED_SORT: lists up to this length are sorted inside the compositor (0: off)
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
     int pipeline = 6;                      // frames in flight on the device (SPLAT_PIPELINE = 1..6, see enqueue_frame)
-    // Compositor LANES (splat_set_frame_overlap, splat_render_stream): the compositors of consecutive frames run one after
-    // the other on the context's stream (lane 0) -- unless the frames go to DIFFERENT images (a swap chain), in which case
-    // the second lane, a stream of its own, takes every other one and two compositors share the chip.  A frame that is
+    // Compositor LANES (splat_set_frame_overlap): the compositors of consecutive frames run one after the other on the
+    // context's stream (lane 0) -- unless overlap is on and the frames go to DIFFERENT images (a swap chain), in which case
+    // the second lane (the copy stream: ensure_lane) takes every other one and two compositors share the chip.  A frame that is
     // bound by the latency of its densest tile's lone wave (small scenes, multi-GPU slabs) leaves the chip mostly idle:
     // with two lanes C2 runs at 7.9 k instead of 5.7 k frames/s, an eighth-of-a-frame slab at 0.08 instead of 0.13 ms.
     // lane[q]: its most recent frame (sequence number, event-ring entry).  img_tab: the most recent frame of every image
@@ -351,12 +351,15 @@ int sync_all(splat_ctx* c) {
 // the stream (and events) of splat_render_stream's device -> host copies
 hipError_t ensure_copy_stream(splat_ctx* c) {
     if (c->copy_stream) return hipSuccess;
-    hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     for (int k = 0; k < splat_ctx::S_IMGS && e == hipSuccess; ++k) {
-        e = hipEventCreateWithFlags(&c->s_rendered[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->s_copied[k], hipEventDisableTiming);
+        if (!c->s_rendered[k]) e = hipEventCreateWithFlags(&c->s_rendered[k], hipEventDisableTiming);
+        if (e == hipSuccess && !c->s_copied[k]) e = hipEventCreateWithFlags(&c->s_copied[k], hipEventDisableTiming);
     }
-    return e;
+    if (e != hipSuccess) { if (st) (void)hipStreamDestroy(st); return e; }      // (events made so far are reused by the next attempt, destroyed with the context)
+    c->copy_stream = st;
+    return hipSuccess;
 }
 
 // The copy entry points run on the context's stream: they follow what the second lane still holds as well.
