@@ -11,9 +11,11 @@ cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0)); cam.update_camera_pose(); cam_c =
 R.upload(g)
 import os
 img = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-imgs = [img, torch.zeros((H, W), dtype=torch.int32, device="cuda")] if os.environ.get("SLAB_SWAP") == "1" else [img]
-if len(imgs) == 2:
-    R.set_frame_overlap(2)        # a two-image swap chain: consecutive frames composite side by side
+n_imgs = int(os.environ.get("SLAB_SWAP", "0") or 0)
+n_imgs = 2 if n_imgs == 1 else n_imgs          # SLAB_SWAP=1: two images; SLAB_SWAP=n: n images in rotation
+imgs = [img] + [torch.zeros((H, W), dtype=torch.int32, device="cuda") for _ in range(max(0, n_imgs - 1))]
+if len(imgs) >= 2 and os.environ.get("SLAB_NO_OVERLAP") != "1":
+    R.set_frame_overlap(2)        # a swap chain: consecutive frames composite side by side
 
 
 def slab_time(slab, reps=60):
