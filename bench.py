@@ -457,6 +457,21 @@ def main():
                     himg[:] = 0
                     R.render(cam_c, himg)
                 legs["host_visible_splat_render_fps"] = 20 / (time.perf_counter() - t1)
+            # (2b) the same with the caller's image page-locked once (splat_host_register: what a host would do with the
+            # reference's long-lived `color` buffer, src/main.rs:62): the copies run at the PCIe rate instead of through
+            # the driver's staging buffers
+            try:
+                splat_amd.Renderer.host_register(himg)
+                R.render(cam_c, himg)
+                with counted("host_visible_splat_render_registered_fps"):
+                    t1 = time.perf_counter()
+                    for _ in range(20):
+                        himg[:] = 0
+                        R.render(cam_c, himg)
+                    legs["host_visible_splat_render_registered_fps"] = 20 / (time.perf_counter() - t1)
+                splat_amd.Renderer.host_unregister(himg)
+            except Exception as e:      # (a driver that will not pin this allocation: the leg is informative only)
+                legs["host_visible_splat_render_registered_fps"] = "unavailable: %s" % e
             # (3) host-visible: the viewer loop (clear, render, present) with pinned frames in flight: frame k is presented
             # (waited for) while frames k+1.. render and cross PCIe.  Two buffers are what a double-buffered window has;
             # four keep the device's frame pipeline (two binning chains + a compositor) full

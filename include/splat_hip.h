@@ -141,6 +141,12 @@ int splat_render_stream(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb_
 int splat_stream_wait(splat_ctx* ctx, const uint32_t* argb_out);
 void* splat_host_alloc(uint64_t bytes);      /* page-locked host memory (hipHostMalloc); NULL on failure */
 void splat_host_free(void* p);
+/* Page-lock a host image the CALLER owns (hipHostRegister) -- the reference's `color` buffer lives as long as the window
+ * (src/main.rs:62), so it is pinned once: splat_render's copies of a pageable image go through the driver's staging
+ * buffers at a fraction of the PCIe rate (C3, synchronous host in/out frame: 850 -> 990 frames/s).  Unregister before the
+ * memory is freed.  SPLAT_ERR_HIP when the driver refuses (memory it cannot map). */
+int splat_host_register(void* p, uint64_t bytes);
+int splat_host_unregister(void* p);
 
 /* Device images for callers without a HIP toolchain of their own (a Rust/C host using
  * splat_render_device): plain allocations on the context's GPU, and copies ordered on the context's

@@ -80,6 +80,8 @@ extern "C" {
     pub fn splat_stream_wait(ctx: *mut SplatCtx, argb_out: *const u32) -> c_int;
     pub fn splat_host_alloc(bytes: u64) -> *mut c_void;
     pub fn splat_host_free(p: *mut c_void);
+    pub fn splat_host_register(p: *mut c_void, bytes: u64) -> c_int;      // pin a buffer the caller owns (e.g. Buffer2d's storage), once
+    pub fn splat_host_unregister(p: *mut c_void) -> c_int;
     // device images for a host without a HIP toolchain of its own
     pub fn splat_device_alloc(ctx: *mut SplatCtx, bytes: u64) -> *mut c_void;
     pub fn splat_device_free(ctx: *mut SplatCtx, d_ptr: *mut c_void);

@@ -73,6 +73,8 @@ SYMBOLS = [
     ("splat_device_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     ("splat_host_alloc", C.c_void_p, [C.c_uint64]),
     ("splat_host_free", None, [C.c_void_p]),
+    ("splat_host_register", C.c_int, [C.c_void_p, C.c_uint64]),
+    ("splat_host_unregister", C.c_int, [C.c_void_p]),
     # multi-GPU
     ("splat_slab_partition", C.c_int, [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_int32)]),
     ("splat_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),

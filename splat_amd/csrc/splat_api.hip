@@ -1346,6 +1346,14 @@ void* splat_host_alloc(uint64_t bytes) {
     return hipHostMalloc(&p, (size_t)bytes) == hipSuccess ? p : nullptr;
 }
 void splat_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int splat_host_register(void* p, uint64_t bytes) {
+    if (!p || !bytes) return SPLAT_ERR_INVALID;
+    return hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) == hipSuccess ? SPLAT_OK : SPLAT_ERR_HIP;
+}
+int splat_host_unregister(void* p) {
+    if (!p) return SPLAT_ERR_INVALID;
+    return hipHostUnregister(p) == hipSuccess ? SPLAT_OK : SPLAT_ERR_HIP;
+}
 
 int splat_sync(splat_ctx* c) {
     if (!c) return SPLAT_ERR_INVALID;

@@ -179,6 +179,18 @@ class Renderer:
         return int(self._L.splat_frames_dropped(self._h))
 
     # ---- viewer-loop streaming (src/main.rs:69-78): cleared frame -> async copy into a host buffer
+    @staticmethod
+    def host_register(arr):
+        """page-lock a numpy image the caller owns (splat_host_register): render() then copies it at the PCIe rate;
+        call host_unregister(arr) before the array goes away"""
+        rc = _lib.lib().splat_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes)
+        if rc != 0:
+            raise SplatError(rc, "splat_host_register")
+
+    @staticmethod
+    def host_unregister(arr):
+        _lib.lib().splat_host_unregister(C.c_void_p(arr.ctypes.data))
+
     def host_image(self, h, w):
         """a pinned (page-locked) h x w uint32 image; keep the Renderer alive while it is in use"""
         p = self._L.splat_host_alloc(int(h) * int(w) * 4)

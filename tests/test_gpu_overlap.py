@@ -219,3 +219,27 @@ def test_gather_follows_its_frame_on_either_lane(scene):
             r.device_free(d)
     finally:
         r.close()
+
+
+def test_render_into_a_registered_host_image(scene):
+    """splat_host_register: the caller's own (pageable) image page-locked once -- render_to_buffer's host in/out form
+    (src/gaussians.rs:359-372) gives the same frame, and the registration can be dropped and made again"""
+    cam = poses()[0]
+    rng = np.random.default_rng(11)
+    init = rng.integers(0, 2**32, (H, W), dtype=np.uint64).astype(np.uint32)
+    r = splat_amd.Renderer()
+    try:
+        r.upload(scene)
+        plain = init.copy()
+        r.render(cam, plain)
+        pinned = init.copy()
+        splat_amd.Renderer.host_register(pinned)
+        try:
+            r.render(cam, pinned)
+            assert np.array_equal(pinned, plain)
+        finally:
+            splat_amd.Renderer.host_unregister(pinned)
+        splat_amd.Renderer.host_register(pinned)
+        splat_amd.Renderer.host_unregister(pinned)
+    finally:
+        r.close()
