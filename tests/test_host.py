@@ -24,6 +24,21 @@ def test_abi_exports_every_declared_symbol():
     assert declared == {s[0] for s in _lib.SYMBOLS}
 
 
+def test_null_handles_are_refused_without_touching_the_device():
+    """entry points called with a NULL context / multi handle / pointer return SPLAT_ERR_INVALID (-1 ... never a crash, never a
+    HIP call): runs without a GPU"""
+    L = _lib.lib()
+    inv = _lib.ERR_INVALID
+    assert L.splat_set_frame_overlap(None, 2) == inv
+    assert L.splat_multi_set_frame_overlap(None, 2) == inv
+    assert L.splat_host_register(None, 16) == inv
+    assert L.splat_host_unregister(None) == inv
+    assert L.splat_sync(None) == inv
+    assert L.splat_set_slab(None, 0, 1) == inv
+    assert L.splat_frames_dropped(None) == 0
+    assert L.splat_stream(None) is None
+
+
 def test_struct_sizes_match_header():
     # layouts are plain C; sizes computed by hand from include/splat_hip.h
     assert C.sizeof(_lib.CameraC) == 4 * (16 + 16 + 2 + 3 + 3 + 1 + 1)
