@@ -8,13 +8,13 @@ import numpy as np
 import splat_amd
 from oracle import oracle as O
 from helpers import scene_dict, oracle_camera, image_diff
-from bench import WORKLOADS
+from bench import WORKLOADS, make_scene
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 out = sys.argv[2] if len(sys.argv) > 2 else None
 n, W, H, seed = WORKLOADS[wl]
 R = splat_amd.Renderer(mode=splat_amd.MODE_LIBM_EXP if (len(sys.argv) > 3 and sys.argv[3] == "libm") else 0)
-g = splat_amd.synthetic_scene(n, seed); g.compute_cov3d(R)
+g = make_scene(wl, via_ply=False); g.compute_cov3d(R)        # (C3s: the trained-like surface scene)
 R.upload(g)
 sd = scene_dict(g)
 poses = [((0, 0, 5.0), 0.0, 0.0), ((0, 0, 5.0), math.radians(70), 0.0), ((0, 0, 5.0), math.radians(160), 0.0),
