@@ -60,7 +60,9 @@ struct Slot {                  // everything one frame writes before the image
     FrameStatus* d_status = nullptr;
     hipEvent_t ev_binned = nullptr;        // bin stream -> sort stream: buckets and lengths are final
     hipEvent_t ev_ready = nullptr;         // sort stream -> caller's stream: lists are sorted
-    hipEvent_t ev_free = nullptr;          // caller's stream -> bin stream: compositor is done with the slot
+    int free_ring = -1;                    // compositor's stream -> bin stream: the slot is free when the frame that used it last has
+                                           // ended -- that frame's ring event (an event of the slot's own would be a second barrier
+                                           // packet behind every compositor: ~3 us of queue drain per frame)
     bool used = false;
 };
 }  // namespace
@@ -515,7 +517,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         // order this frame's binning after whatever the caller queued before the call (it may have
         // written the scene-independent inputs we read? no -- but it keeps stream semantics intact
         // for a caller that interleaves uploads), and after the compositor that last used the slot
-        if (s.used) HIP_TRY(c, hipStreamWaitEvent(bs, s.ev_free, 0));
+        if (s.used && s.free_ring >= 0) HIP_TRY(c, hipStreamWaitEvent(bs, c->ring[s.free_ring].e[7], 0));
     }
     if (!c->fc.bucket_cap)                                 // two-pass binning: K1 counts visible Gaussians into the status before the scan
         HIP_TRY(c, hipMemsetAsync(d_st, 0, sizeof(FrameStatus), bs));
@@ -640,7 +642,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // counters (compositor retries, sort fallbacks)
     if (want_iters) HIP_TRY(c, hipMemcpyAsync(&c->h_status[r], d_st, sizeof(FrameStatus), hipMemcpyDeviceToHost, cs));
     HIP_TRY(c, hipEventRecord(ev.e[7], cs));
-    if (c->pipeline) HIP_TRY(c, hipEventRecord(s.ev_free, cs));
+    s.free_ring = r;
     HIP_TRY(c, hipGetLastError());
     s.used = true;
     ev.used = true;
@@ -925,7 +927,6 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         if ((e = hipMemset(s.d_status, 0, sizeof(FrameStatus))) != hipSuccess) return bail("hipMemset(status)", e);
         if ((e = hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_binned, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     if ((e = dmalloc(c, &c->d_status_ring, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMalloc(status ring)", e);
     if ((e = hipMemset(c->d_status_ring, 0, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMemset(status ring)", e);
@@ -952,7 +953,6 @@ void splat_destroy(splat_ctx* c) {
         dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
         if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);
-        if (s.ev_free) (void)hipEventDestroy(s.ev_free);
     }
     dfree(c->d_img); dfree(c->d_iters);
     for (int k = 0; k < splat_ctx::S_IMGS; ++k) {
