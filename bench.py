@@ -121,17 +121,22 @@ def single_process(args, n, W, H, seed):
     M.sync()
     for r in range(args.gpus):
         M.rank_timing(r, reset=True)
+    dropped0 = [M.rank_frames_dropped(r) for r in range(args.gpus)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         M.render_frame(poses[k % len(poses)])
     M.sync()
     dt = time.perf_counter() - t0
     kern = [M.rank_timing(r, reset=True) for r in range(args.gpus)]
+    dropped = [M.rank_frames_dropped(r) - dropped0[r] for r in range(args.gpus)]     # frames a rank's device skipped inside the timed region
     M.render_frame(cam_c)
     M.sync()
     same = bool(np.array_equal(M.download(H, W), full))
     M.close()
     per = {k: max(ms[k] / max(fr, 1) for ms, fr in kern) for k in kern[0][0]}
+    per_rank = [dict({k: v / max(fr, 1) for k, v in ms.items()}, rank=r, tile_rows=slabs[r][1] - slabs[r][0], frames_dropped=int(dropped[r]))
+                for r, (ms, fr) in enumerate(kern)]
+    t_frame = dt / args.steps * 1e3
     out = {
         "metric": "frames_per_sec", "value": args.steps / dt, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "setup_frames_before_warmup": SETTLE_FRAMES, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -144,15 +149,45 @@ def single_process(args, n, W, H, seed):
                                                                          "; two images per device in turn (splat_multi_set_frame_overlap(2))" if swap_chain else ""),
                    "frame_overlap": 2 if swap_chain else 1,
                    "n_pairs": int(st.n_pairs), "n_visible": int(st.n_visible)},
+        "roofline_frame": {"bytes_algorithmic": int(st.bytes_algorithmic), "t_frame_ms": t_frame,
+                           "achieved": int(st.bytes_algorithmic) / (t_frame * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * args.gpus, "unit": "GB/s",
+                           "frac": int(st.bytes_algorithmic) / (t_frame * 1e-3) / 1e9 / (HBM_PEAK_GBS * args.gpus),
+                           "note": "the FRAME's algorithmic bytes (one copy of the scene read, not one per rank) / wall time per frame, "
+                                   "against the ranks' HBM peaks together"},
         "kernel_ms_slowest_rank": per,
+        "kernel_ms_per_rank": per_rank,
+        "frames_dropped": int(sum(dropped)),
         "multi_gpu_frame_equals_single_gpu_frame": same,
         "setup_s": time.perf_counter() - t_setup - dt,
     }
     print(json.dumps(out))
-    sys.exit(0 if same else 3)
+    sys.exit(3 if not same else (4 if sum(dropped) else 0))
 
 
 SETTLE_FRAMES = 200     # see the timed loop
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE): re-execute this very command line as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`
+    -- one rank per GPU over RCCL, the same processes the driver's own torchrun line starts.  A box with fewer GPUs than
+    N runs only with SPLAT_BENCH_SHARE_GPU=1 (every rank on device 0, gloo: the decomposition, not a measurement)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("SPLAT_BENCH_SHARE_GPU") != "1":
+        sys.exit("bench.py --gpus %d: this box has %d GPU(s) (SPLAT_BENCH_SHARE_GPU=1 runs the %d ranks on device 0 "
+                 "over gloo, to exercise the decomposition)" % (args.gpus, have, args.gpus))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def surface_leg(R0, image, stream, device, args, counted, leg_drops):
@@ -242,9 +277,7 @@ def main():
         return single_process(args, n, W, H, seed)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...   (or add --single-process)"
-                     % (args.gpus, args.gpus))
+            return self_launch(args)          # plain `python bench.py --gpus N`: become the torchrun launch of N ranks
         args.gpus = world
     # SPLAT_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0 over gloo, to exercise the N>1 code
     # path on a single-GPU box (RCCL refuses ranks that share a device); the real run is one rank per GPU over RCCL
@@ -522,6 +555,16 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(comp, op=dist.ReduceOp.MAX)
 
+    # every rank's per-kernel averages (HIP events on its own streams) travel to rank 0 for the line
+    per_rank = None
+    if world > 1:
+        mine = {k: v / max(frames, 1) for k, v in kern_ms.items()}
+        mine.update(rank=rank, tile_rows=slabs[rank][1] - slabs[rank][0], n_pairs=int(st.n_pairs), n_visible=int(st.n_visible),
+                    k1_blocks_culled=int(st.n_blocks_culled), frames_dropped=int(dropped_timed))
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        per_rank = box
+
     slab_check = None
     exit_code, parity_ok = 0, True
     if world > 1 and rank == 0:
@@ -605,15 +648,20 @@ def main():
             "roofline_frame": {"bytes_algorithmic": int(tot[2]), "t_frame_ms": t_frame,
                                "sum_of_kernel_ms": t_gpu,
                                "achieved": int(tot[2]) / (t_frame * 1e-3) / 1e9,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": int(tot[2]) / (t_frame * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                               "frac": int(tot[2]) / (t_frame * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
                                "note": "B_alg / wall time per frame; kernels of consecutive frames overlap, so the sum of "
-                                       "their durations exceeds the frame time"},
+                                       "their durations exceeds the frame time"
+                                       + ("; N > 1: the ranks' algorithmic bytes summed (every rank reads the whole scene in its "
+                                          "K1) against the ranks' HBM peaks together" if world > 1 else "")},
             "kernel_ms": per,
             "kernel_ms_isolated": iso,
         }
         if legs:
             out["extra_legs"] = legs
+        if per_rank is not None:
+            out["kernel_ms_per_rank"] = per_rank
+            out["kernel_ms_slowest_rank"] = {k: max(r[k] for r in per_rank) for k in per}
         if slab_check is not None:
             out["multi_gpu_frame_equals_single_gpu_frame"] = slab_check
             if not slab_check:

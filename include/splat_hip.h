@@ -191,6 +191,45 @@ uint64_t splat_device_bytes(const splat_ctx* ctx, uint64_t* peak);
  * overlapped (the second compositor stream is the one their copies to the host travel on: a stream more would share a
  * hardware queue with a busy one). */
 int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
+/* Tuning options of a context, for hosts that cannot (or should not) reach them through the environment -- a Rust or C
+ * application sets them after splat_create.  None of them changes a pixel: they choose between equivalent schedules
+ * and storage sizes.  The SPLAT_* environment variable of the same purpose, when set, is read at splat_create and
+ * PINS the option: a later splat_set_option on it leaves the operator's value in force and returns SPLAT_OK
+ * (splat_get_option tells what is in force).  splat_set_option waits for the frames in flight; options that size
+ * storage (pipeline depth, key buffer bytes, one-pass binning) take effect with the next frame, which re-allocates.
+ * SPLAT_ERR_INVALID: unknown option or value out of range (the range is in the comment of each). */
+#define SPLAT_OPT_PIPELINE_DEPTH 1       /* frames in flight on the device, 1..6 (default 6; SPLAT_PIPELINE): 1 = one stream, no
+                                            cross-frame overlap; 2 = binning + sort of frame N+1 under the compositor of frame N;
+                                            6 = four frame slots, two binning chains in flight                                   */
+#define SPLAT_OPT_FUSED_SORT_MAX 2       /* lists up to this many keys are sorted by their tile's compositor workgroup, 0..2048
+                                            (default 2048; SPLAT_FUSED_SORT); 0 = every list goes through the sort launches      */
+#define SPLAT_OPT_REGION_SPARE 3         /* one-pass binning: how far a tile's key region may grow into the buffer's spare room,
+                                            >= 1 (default 4; SPLAT_REGION_SPARE): larger tolerates larger camera jumps           */
+#define SPLAT_OPT_EARLY_OUT_EPS 4        /* transmittance below which the compositor's near-to-far scan stops, 0..1 (default
+                                            1e-6, 2e-3 in SPLAT_MODE_FAST; SPLAT_EARLY_EPS); 0 switches the early-out off       */
+#define SPLAT_OPT_EARLY_OUT_MIN_LIST 5   /* shortest tile list that gets the early-out scan, >= 0 (default 768, 384 in
+                                            SPLAT_MODE_FAST; SPLAT_EARLY_MIN)                                                    */
+#define SPLAT_OPT_EARLY_OUT_SCAN_EIGHTHS 6 /* the scan gives up after this many eighths of the list, 1..8 (default 4;
+                                            SPLAT_EARLY_SCAN8)                                                                   */
+#define SPLAT_OPT_SORT_IN_COMPOSITOR 7   /* who sorts lists of more than 2048 keys: 0 = sort launches, 1 = the tile's compositor
+                                            workgroup, -1 = chosen per frame from the previous frame (default; SPLAT_SORT_IN_COMP) */
+#define SPLAT_OPT_PAIR_WALK 8            /* the exact walk takes two records per step with packed math: 0 / 1, -1 = per frame
+                                            from the previous frame's statistics (default; SPLAT_PAIR_BLEND)                     */
+#define SPLAT_OPT_TIMING_EVERY 9         /* per-kernel timing events ride on every n-th asynchronous frame, >= 1 (default 8;
+                                            SPLAT_TIMING_EVERY)                                                                  */
+#define SPLAT_OPT_BLOCK_CULLING 10       /* K1 skips 256-Gaussian blocks whose bounds cannot reach the slab / target: 0 / 1
+                                            (default 1; SPLAT_CULL)                                                              */
+#define SPLAT_OPT_ONE_PASS_BINNING 11    /* per-tile key regions filled by K1 itself (no count / emit passes): 0 / 1 (default 1;
+                                            SPLAT_BUCKETS)                                                                       */
+#define SPLAT_OPT_KEY_BUFFER_BYTES 12    /* ceiling on the key buffers of all frame slots together for one-pass binning, bytes
+                                            (default 128 GiB; SPLAT_BUCKET_BYTES): beyond it the two-pass path is used          */
+#define SPLAT_OPT_FAST_CLOSE_WIDTH 13    /* SPLAT_MODE_FAST: the bracket counts as closed at hi - lo <= 1 or 2 (default 2;
+                                            SPLAT_FAST_WIDTH)                                                                    */
+#define SPLAT_OPT_PRIORITY_LIST_LEN 14   /* compositor waves of lists at least this long (x2, x4) run at raised priority, >= 1
+                                            (default: off; SPLAT_PRIO_LEN)                                                       */
+#define SPLAT_OPT_FRAME_OVERLAP 15       /* = splat_set_frame_overlap: 1 / 2 (default 1; SPLAT_FRAME_OVERLAP)                     */
+int splat_set_option(splat_ctx* ctx, int32_t option, double value);
+int splat_get_option(const splat_ctx* ctx, int32_t option, double* value);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */
 /* Run on a caller-owned hipStream_t (e.g. the stream a device image / RCCL gather lives on). */
 int splat_set_stream(splat_ctx* ctx, void* hip_stream);

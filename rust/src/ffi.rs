@@ -13,6 +13,22 @@ pub const SPLAT_MODE_EXACT: i32 = 0;
 pub const SPLAT_MODE_CORRECTED_PROJECTION: i32 = 1;
 pub const SPLAT_MODE_LIBM_EXP: i32 = 2;
 pub const SPLAT_MODE_FAST: i32 = 4;
+// tuning options (splat_set_option / splat_get_option): equivalent schedules and storage sizes, never pixels
+pub const SPLAT_OPT_PIPELINE_DEPTH: i32 = 1;
+pub const SPLAT_OPT_FUSED_SORT_MAX: i32 = 2;
+pub const SPLAT_OPT_REGION_SPARE: i32 = 3;
+pub const SPLAT_OPT_EARLY_OUT_EPS: i32 = 4;
+pub const SPLAT_OPT_EARLY_OUT_MIN_LIST: i32 = 5;
+pub const SPLAT_OPT_EARLY_OUT_SCAN_EIGHTHS: i32 = 6;
+pub const SPLAT_OPT_SORT_IN_COMPOSITOR: i32 = 7;
+pub const SPLAT_OPT_PAIR_WALK: i32 = 8;
+pub const SPLAT_OPT_TIMING_EVERY: i32 = 9;
+pub const SPLAT_OPT_BLOCK_CULLING: i32 = 10;
+pub const SPLAT_OPT_ONE_PASS_BINNING: i32 = 11;
+pub const SPLAT_OPT_KEY_BUFFER_BYTES: i32 = 12;
+pub const SPLAT_OPT_FAST_CLOSE_WIDTH: i32 = 13;
+pub const SPLAT_OPT_PRIORITY_LIST_LEN: i32 = 14;
+pub const SPLAT_OPT_FRAME_OVERLAP: i32 = 15;
 
 #[repr(C)] pub struct SplatCtx { _private: [u8; 0] }
 #[repr(C)] pub struct SplatMulti { _private: [u8; 0] }
@@ -70,6 +86,8 @@ extern "C" {
     pub fn splat_device_bytes(ctx: *const SplatCtx, peak: *mut u64) -> u64;
     pub fn splat_binning_mode(ctx: *mut SplatCtx) -> i64;
     pub fn splat_set_frame_overlap(ctx: *mut SplatCtx, n: i32) -> c_int;   // 2: frames to different images composite side by side
+    pub fn splat_set_option(ctx: *mut SplatCtx, option: i32, value: f64) -> c_int;   // SPLAT_OPT_*: what the SPLAT_* environment variables set, from code
+    pub fn splat_get_option(ctx: *const SplatCtx, option: i32, value: *mut f64) -> c_int;
     pub fn splat_stream(ctx: *mut SplatCtx) -> *mut c_void;               // the hipStream_t the kernels run on
     pub fn splat_set_stream(ctx: *mut SplatCtx, hip_stream: *mut c_void) -> c_int;
     pub fn splat_get_timing(ctx: *mut SplatCtx, ms: *mut f64 /* [6] */, frames: *mut u64, reset: i32) -> c_int;

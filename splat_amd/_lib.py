@@ -58,6 +58,8 @@ SYMBOLS = [
     ("splat_frames_dropped", C.c_uint64, [C.c_void_p]),
     ("splat_device_bytes", C.c_uint64, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("splat_set_frame_overlap", C.c_int, [C.c_void_p, C.c_int32]),
+    ("splat_set_option", C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    ("splat_get_option", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     ("splat_stream", C.c_void_p, [C.c_void_p]),
     ("splat_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("splat_get_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]),
@@ -98,6 +100,22 @@ SYMBOLS = [
     ("splat_multi_ctx", C.c_void_p, [C.c_void_p, C.c_int32]),
 ]
 UNIQUE_ID_BYTES = 128
+# SPLAT_OPT_* (include/splat_hip.h): tuning options of a context
+OPT_PIPELINE_DEPTH = 1
+OPT_FUSED_SORT_MAX = 2
+OPT_REGION_SPARE = 3
+OPT_EARLY_OUT_EPS = 4
+OPT_EARLY_OUT_MIN_LIST = 5
+OPT_EARLY_OUT_SCAN_EIGHTHS = 6
+OPT_SORT_IN_COMPOSITOR = 7
+OPT_PAIR_WALK = 8
+OPT_TIMING_EVERY = 9
+OPT_BLOCK_CULLING = 10
+OPT_ONE_PASS_BINNING = 11
+OPT_KEY_BUFFER_BYTES = 12
+OPT_FAST_CLOSE_WIDTH = 13
+OPT_PRIORITY_LIST_LEN = 14
+OPT_FRAME_OVERLAP = 15
 
 _LIB = None
 

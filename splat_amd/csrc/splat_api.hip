@@ -190,6 +190,7 @@ struct splat_ctx {
     uint64_t lane_seq = 0;
     bool streamed_call = false;            // splat_render_stream is rendering: its frames stay on lane 0 (lane 1's stream carries their copies)
     hipEvent_t pre_wait = nullptr;         // one-shot: the next frame's compositor waits for it (splat_render_stream: its image is still crossing PCIe)
+    uint32_t env_pinned = 0;               // bit k: SPLAT_OPT_k was set from the environment at splat_create (splat_set_option leaves it alone)
     splat::CommState* comm = nullptr;      // multi-GPU: RCCL communicator + partition (splat_multi.hip)
     std::string err;
 };
@@ -200,6 +201,15 @@ hipStream_t ctx_stream(splat_ctx* c) { return c->stream; }
 // the stream the most recent frame's compositor was enqueued on: work that must follow THAT frame (the gather of its rows,
 // the copy of its pixels) goes there -- and the next frame to the same image follows it on the same lane
 hipStream_t frame_stream(splat_ctx* c) { return (c->last_lane && c->comp2) ? c->comp2 : c->stream; }
+// Work enqueued BEHIND the most recent frame on its lane that later frames / copies must also follow (the gather of its
+// rows): the frame's ring event -- the one every cross-lane hazard wait, join_lanes, the slot-reuse wait and the image
+// table use -- is recorded again behind it, so "the frame has ended" includes that work from now on.
+int frame_tail(splat_ctx* c) {
+    if (c->last_ring < 0 || !c->ring[c->last_ring].used) return SPLAT_OK;
+    hipError_t e = hipEventRecord(c->ring[c->last_ring].e[7], frame_stream(c));
+    if (e != hipSuccess) { c->err = std::string("hipEventRecord(frame tail): ") + hipGetErrorString(e); return SPLAT_ERR_HIP; }
+    return SPLAT_OK;
+}
 int ctx_device(const splat_ctx* c) { return c->cfg.device; }
 int ctx_fail(splat_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
 }  // namespace splat
@@ -842,6 +852,73 @@ void free_scene(splat_ctx* c) {
 
 }  // namespace
 
+namespace {
+// One option, validated and stored (include/splat_hip.h SPLAT_OPT_*).  The caller has quiesced the context where that
+// matters.  false: unknown option or value out of range.
+bool store_option(splat_ctx* c, int opt, double v) {
+    if (!(v == v)) return false;
+    switch (opt) {
+        case SPLAT_OPT_PIPELINE_DEPTH: {
+            if (v < 1.0 || v > 6.0) return false;
+            const int p = (int)v <= 1 ? 0 : (int)v;
+            if (p != c->pipeline) {
+                // another number of frame slots: the key buffers exist per slot in use and are made again by the next frame
+                for (Slot& sl : c->slots) { dfree(sl.keys); dfree(sl.keys2); sl.layout_valid = false; sl.flip = 0; sl.used = false; sl.free_ring = -1; }
+                c->cap = 0; c->have_keys2 = false; c->frame_idx = 0;
+                c->pipeline = p;
+                if (p == 0) { c->comp2 = nullptr; c->overlap = 1; }
+            }
+            return true;
+        }
+        case SPLAT_OPT_FUSED_SORT_MAX: if (v < 0.0 || v > 2048.0) return false; c->fused_sort_max = (unsigned int)v; return true;
+        case SPLAT_OPT_REGION_SPARE: if (v < 1.0) return false; c->region_spare = (float)v; return true;
+        case SPLAT_OPT_EARLY_OUT_EPS: if (v < 0.0 || v > 1.0) return false; c->early_eps = (float)v; return true;
+        case SPLAT_OPT_EARLY_OUT_MIN_LIST: if (v < 0.0 || v > 1e9) return false; c->early_min = (int)v; return true;
+        case SPLAT_OPT_EARLY_OUT_SCAN_EIGHTHS: if (v < 1.0 || v > 8.0) return false; c->early_scan8 = (int)v; return true;
+        case SPLAT_OPT_SORT_IN_COMPOSITOR: if (v < -1.0 || v > 1.0) return false; c->sort_in_comp = v < 0.0 ? -1 : (v != 0.0 ? 1 : 0); return true;
+        case SPLAT_OPT_PAIR_WALK: if (v < -1.0 || v > 1.0) return false; c->pair_mode = v < 0.0 ? -1 : (v != 0.0 ? 1 : 0); return true;
+        case SPLAT_OPT_TIMING_EVERY: if (v < 1.0 || v > 1e9) return false; c->timing_every = (int)v; return true;
+        case SPLAT_OPT_BLOCK_CULLING: if (v != 0.0 && v != 1.0) return false; c->cull_blocks = v != 0.0; return true;
+        case SPLAT_OPT_ONE_PASS_BINNING: if (v != 0.0 && v != 1.0) return false; c->use_buckets = v != 0.0; return true;
+        case SPLAT_OPT_KEY_BUFFER_BYTES: if (v < 0.0 || v > 1.8e19) return false; c->bucket_bytes = (uint64_t)v; c->bucket_failed = false; return true;
+        case SPLAT_OPT_FAST_CLOSE_WIDTH: if (v != 1.0 && v != 2.0) return false; c->fast_width = (float)v; return true;
+        case SPLAT_OPT_PRIORITY_LIST_LEN: if (v < 1.0 || v > 1073741823.0) return false; c->prio_len = (int)v; return true;
+        case SPLAT_OPT_FRAME_OVERLAP: if (v != 1.0 && v != 2.0) return false; c->overlap = (int)v; return true;    // (lanes: splat_set_option / splat_create make them)
+        default: return false;
+    }
+}
+bool load_option(const splat_ctx* c, int opt, double* v) {
+    switch (opt) {
+        case SPLAT_OPT_PIPELINE_DEPTH: *v = c->pipeline ? c->pipeline : 1; return true;
+        case SPLAT_OPT_FUSED_SORT_MAX: *v = c->fused_sort_max; return true;
+        case SPLAT_OPT_REGION_SPARE: *v = c->region_spare; return true;
+        case SPLAT_OPT_EARLY_OUT_EPS: *v = c->early_eps; return true;
+        case SPLAT_OPT_EARLY_OUT_MIN_LIST: *v = c->early_min; return true;
+        case SPLAT_OPT_EARLY_OUT_SCAN_EIGHTHS: *v = c->early_scan8; return true;
+        case SPLAT_OPT_SORT_IN_COMPOSITOR: *v = c->sort_in_comp; return true;
+        case SPLAT_OPT_PAIR_WALK: *v = c->pair_mode; return true;
+        case SPLAT_OPT_TIMING_EVERY: *v = c->timing_every; return true;
+        case SPLAT_OPT_BLOCK_CULLING: *v = c->cull_blocks ? 1 : 0; return true;
+        case SPLAT_OPT_ONE_PASS_BINNING: *v = c->use_buckets ? 1 : 0; return true;
+        case SPLAT_OPT_KEY_BUFFER_BYTES: *v = (double)c->bucket_bytes; return true;
+        case SPLAT_OPT_FAST_CLOSE_WIDTH: *v = c->fast_width; return true;
+        case SPLAT_OPT_PRIORITY_LIST_LEN: *v = c->prio_len; return true;
+        case SPLAT_OPT_FRAME_OVERLAP: *v = c->overlap; return true;
+        default: return false;
+    }
+}
+// The environment's say, at splat_create: the variable of an option, when set, stores it (clamped into the option's
+// range as the variables always were) and pins it.
+void option_from_env(splat_ctx* c, int opt, const char* name, double lo, double hi) {
+    const char* e = std::getenv(name);
+    if (!e || !*e) return;
+    double v = std::atof(e);
+    if (!(v == v)) return;
+    v = std::min(hi, std::max(lo, v));
+    if (store_option(c, opt, v)) c->env_pinned |= 1u << opt;
+}
+}  // namespace
+
 namespace splat {
 // wait for everything this context has enqueued; a frame found skipped stays pending for the next splat_sync to report
 int ctx_quiesce(splat_ctx* c) { return finish_quiet(c); }
@@ -880,22 +957,23 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         c->early_eps = 2e-3f;      // hi - lo <= 2 needs a contraction of ~1/128, not of ~1e-5 ...
         c->early_min = 384;        // ... which lists of a few hundred keys reach too (C3: 2960 -> 3125 frames/s; exact mode: 768 is best)
     }
-    if (const char* es = std::getenv("SPLAT_SORT_IN_COMP")) c->sort_in_comp = std::atoi(es) < 0 ? -1 : (std::atoi(es) != 0 ? 1 : 0);
-    if (const char* e0 = std::getenv("SPLAT_FAST_WIDTH")) c->fast_width = std::atoi(e0) <= 1 ? 1.0f : 2.0f;
-    if (const char* e1 = std::getenv("SPLAT_EARLY_EPS")) c->early_eps = (float)std::atof(e1);
-    if (const char* e2 = std::getenv("SPLAT_EARLY_MIN")) c->early_min = std::atoi(e2);
-    if (const char* e11 = std::getenv("SPLAT_EARLY_SCAN8")) c->early_scan8 = std::min(8, std::max(1, std::atoi(e11)));
-    if (const char* e3 = std::getenv("SPLAT_PRIO_LEN")) c->prio_len = std::atoi(e3);
-    if (const char* eo = std::getenv("SPLAT_FRAME_OVERLAP")) c->overlap = std::atoi(eo) >= 2 ? 2 : 1;
-    if (const char* e4 = std::getenv("SPLAT_PIPELINE")) { c->pipeline = std::atoi(e4); if (c->pipeline <= 1) c->pipeline = 0; if (c->pipeline > 6) c->pipeline = 6; }
-    if (const char* e9 = std::getenv("SPLAT_TIMING_EVERY")) c->timing_every = std::max(1, std::atoi(e9));
-    if (const char* e13 = std::getenv("SPLAT_FUSED_SORT")) c->fused_sort_max = std::min(2048, std::max(0, std::atoi(e13)));
-    if (const char* e5 = std::getenv("SPLAT_BUCKETS")) c->use_buckets = std::atoi(e5) != 0;
-    if (const char* e7 = std::getenv("SPLAT_CULL")) c->cull_blocks = std::atoi(e7) != 0;
+    // the options a host reaches through splat_set_option; their environment variables pin them (include/splat_hip.h)
+    option_from_env(c, SPLAT_OPT_SORT_IN_COMPOSITOR, "SPLAT_SORT_IN_COMP", -1, 1);
+    if (const char* e0 = std::getenv("SPLAT_FAST_WIDTH")) { c->fast_width = std::atoi(e0) <= 1 ? 1.0f : 2.0f; c->env_pinned |= 1u << SPLAT_OPT_FAST_CLOSE_WIDTH; }
+    option_from_env(c, SPLAT_OPT_EARLY_OUT_EPS, "SPLAT_EARLY_EPS", 0, 1);
+    option_from_env(c, SPLAT_OPT_EARLY_OUT_MIN_LIST, "SPLAT_EARLY_MIN", 0, 1e9);
+    option_from_env(c, SPLAT_OPT_EARLY_OUT_SCAN_EIGHTHS, "SPLAT_EARLY_SCAN8", 1, 8);
+    option_from_env(c, SPLAT_OPT_PRIORITY_LIST_LEN, "SPLAT_PRIO_LEN", 1, 1073741823.0);
+    option_from_env(c, SPLAT_OPT_FRAME_OVERLAP, "SPLAT_FRAME_OVERLAP", 1, 2);
+    option_from_env(c, SPLAT_OPT_PIPELINE_DEPTH, "SPLAT_PIPELINE", 1, 6);
+    option_from_env(c, SPLAT_OPT_TIMING_EVERY, "SPLAT_TIMING_EVERY", 1, 1e9);
+    option_from_env(c, SPLAT_OPT_FUSED_SORT_MAX, "SPLAT_FUSED_SORT", 0, 2048);
+    if (const char* e5 = std::getenv("SPLAT_BUCKETS")) { c->use_buckets = std::atoi(e5) != 0; c->env_pinned |= 1u << SPLAT_OPT_ONE_PASS_BINNING; }
+    if (const char* e7 = std::getenv("SPLAT_CULL")) { c->cull_blocks = std::atoi(e7) != 0; c->env_pinned |= 1u << SPLAT_OPT_BLOCK_CULLING; }
     if (const char* e8 = std::getenv("SPLAT_DBG_TIGHT_GRIDS")) c->tight_grids = std::atoi(e8) != 0;
-    if (const char* e10 = std::getenv("SPLAT_PAIR_BLEND")) c->pair_mode = std::atoi(e10) < 0 ? -1 : (std::atoi(e10) != 0 ? 1 : 0);
-    if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) c->bucket_bytes = std::strtoull(e6, nullptr, 10);
-    if (const char* e12 = std::getenv("SPLAT_REGION_SPARE")) c->region_spare = std::max(1.0f, (float)std::atof(e12));
+    option_from_env(c, SPLAT_OPT_PAIR_WALK, "SPLAT_PAIR_BLEND", -1, 1);
+    if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) { c->bucket_bytes = std::strtoull(e6, nullptr, 10); c->env_pinned |= 1u << SPLAT_OPT_KEY_BUFFER_BYTES; }
+    option_from_env(c, SPLAT_OPT_REGION_SPARE, "SPLAT_REGION_SPARE", 1, 1e9);
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
@@ -945,6 +1023,7 @@ void splat_destroy(splat_ctx* c) {
     if (c->bin_stream) (void)hipStreamSynchronize(c->bin_stream);
     if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);      // lane 1: compositors and gathers that use the buffers / the communicator released below
     if (c->comm) { comm_release(c->comm); c->comm = nullptr; }
     free_scene(c);
     dfree(c->zero_layout);
@@ -993,6 +1072,28 @@ int splat_set_frame_overlap(splat_ctx* c, int32_t n) {
     for (auto& e : c->img_tab) e = splat_ctx::ImgRec{};
     c->last_lane = 0;
     return SPLAT_OK;
+}
+
+int splat_set_option(splat_ctx* c, int32_t option, double value) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (option < 1 || option > 31) return fail(c, SPLAT_ERR_INVALID, "unknown option");
+    double cur;
+    if (!load_option(c, option, &cur)) return fail(c, SPLAT_ERR_INVALID, "unknown option");
+    if (c->env_pinned & (1u << option)) return SPLAT_OK;      // the operator's environment variable stays in force
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc = finish_quiet(c);
+    if (rc != SPLAT_OK) return rc;
+    if (option == SPLAT_OPT_FRAME_OVERLAP) {
+        if (value != 1.0 && value != 2.0) return fail(c, SPLAT_ERR_INVALID, "frame overlap is 1 or 2");
+        return splat_set_frame_overlap(c, (int32_t)value);
+    }
+    if (!store_option(c, option, value)) return fail(c, SPLAT_ERR_INVALID, "option value out of range");
+    return SPLAT_OK;
+}
+
+int splat_get_option(const splat_ctx* c, int32_t option, double* value) {
+    if (!c || !value) return SPLAT_ERR_INVALID;
+    return load_option(c, option, value) ? SPLAT_OK : SPLAT_ERR_INVALID;
 }
 
 int splat_set_stream(splat_ctx* c, void* stream) {
@@ -1087,8 +1188,20 @@ int splat_compute_cov3d(splat_ctx* c, uint64_t n, const float* scales3, const fl
 int splat_set_slab(splat_ctx* c, int32_t tile_row0, int32_t tile_row1) {
     if (!c) return SPLAT_ERR_INVALID;
     if (tile_row0 < 0 || (tile_row1 >= 0 && tile_row1 < tile_row0)) return fail(c, SPLAT_ERR_INVALID, "bad slab");
+    if (tile_row0 == c->slab0 && tile_row1 == c->slab1) return SPLAT_OK;
+    // another slab: the slots' region layouts (sized from the lists of the OLD slab's tile rows -- a partition that keeps
+    // the tile count would keep them otherwise) and the sort launch sizes describe other tiles.  The next frame counts its
+    // pairs first (bootstrap) instead of being binned against them, overflowing and getting dropped on the device.
+    int rc = SPLAT_OK;
+    if (c->frame_idx != 0) {
+        (void)hipSetDevice(c->cfg.device);
+        rc = finish_quiet(c);
+    }
+    for (Slot& sl : c->slots) sl.layout_valid = false;
+    c->sort_hint = false;
+    c->hint_pairs = 0; c->hint_maxlen = 0;
     c->slab0 = tile_row0; c->slab1 = tile_row1;
-    return SPLAT_OK;
+    return rc;
 }
 
 int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pairs, int32_t n_rows) {

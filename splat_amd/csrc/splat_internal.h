@@ -136,6 +136,7 @@ CommState** ctx_comm_slot(splat_ctx* c);
 hipStream_t ctx_stream(splat_ctx* c);
 hipStream_t frame_stream(splat_ctx* c);    // the stream the most recent frame's compositor is on (compositor lanes, splat_api.hip)
 int ctx_device(const splat_ctx* c);
+int frame_tail(splat_ctx* c);                // re-record the most recent frame's "ended" event behind work enqueued on its lane (a row gather)
 int ctx_quiesce(splat_ctx* c);               // wait for everything enqueued; a skipped frame stays pending for splat_sync
 int ctx_fail(splat_ctx* c, int code, const char* msg);
 void comm_release(CommState* s);               // splat_destroy -> here

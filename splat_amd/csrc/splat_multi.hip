@@ -91,6 +91,7 @@ struct CommState {
     std::atomic<bool> aborted{false}; // ncclCommAbort has run on `comm` (a peer could not take part in a gather): it
                                       // is gone, later gathers fail instead of blocking
     bool loopback = false;            // test hook (splat_comm_loopback): see splat_comm_gather
+    std::mutex mu;                    // held by a gather from its `aborted` check to the end of its enqueue (see abort_all_comms)
 };
 void comm_release(CommState* s) {
     if (!s) return;
@@ -268,6 +269,7 @@ int splat_comm_gather(splat_ctx* c, void* d_argb, int32_t w, int32_t h, int32_t 
     CommState* st = *ctx_comm_slot(c);
     if (!st || st->slabs.empty()) return ctx_fail(c, SPLAT_ERR_INVALID, "no communicator / partition on this context");
     if (!d_argb || w < 1 || h < 1 || root < 0 || root >= st->n_ranks) return ctx_fail(c, SPLAT_ERR_INVALID, "bad gather arguments");
+    std::lock_guard<std::mutex> in_gather(st->mu);       // check-then-use of the communicator is one step for abort_all_comms
     if (st->aborted.load()) return ctx_fail(c, SPLAT_ERR_HIP, "the communicator was aborted after a rank failed; create it again");
     if (hipSetDevice(ctx_device(c)) != hipSuccess) return ctx_fail(c, SPLAT_ERR_HIP, "hipSetDevice");
     // A single rank has nobody to exchange rows with ...
@@ -277,8 +279,12 @@ int splat_comm_gather(splat_ctx* c, void* d_argb, int32_t w, int32_t h, int32_t 
     // multi-rank gather -- group, send, receive, the RCCL kernel on the context's stream -- runs on a one-GPU box.
     // (behind the most recent frame, on the lane its compositor runs on: the next frame to ANOTHER image composites beside
     // this gather instead of behind it -- splat_set_frame_overlap)
-    if (st->n_ranks == 1) return loopback_rows(c, st, (uint32_t*)d_argb, w, h, frame_stream(c));
-    return gather_rows(c, st, (uint32_t*)d_argb, w, h, root, frame_stream(c));
+    int rc = (st->n_ranks == 1) ? loopback_rows(c, st, (uint32_t*)d_argb, w, h, frame_stream(c))
+                                : gather_rows(c, st, (uint32_t*)d_argb, w, h, root, frame_stream(c));
+    // "this frame has ended" now includes its gather: a later frame to the image on the other lane, a download / upload
+    // on the context's stream and the reuse of the frame's slot all wait for the rows to have left / landed
+    const int rt = frame_tail(c);
+    return rc != SPLAT_OK ? rc : rt;
 }
 
 int splat_comm_loopback(splat_ctx* c, int32_t on) {
@@ -401,7 +407,7 @@ void worker_main(splat_multi* m, Worker* me) {
         return true;
     };
     // this rank's rows -> the root's image (stream order)
-    auto gather = [&](int w, int h, int k) {
+    auto gather = [&](int w, int h, int k, bool rendered) {
         Worker* root = m->w[0].get();
         hipStream_t st = frame_stream(me->ctx);              // behind the frame just enqueued, on its compositor's lane
         uint32_t* const mine = me->imgs[k];
@@ -410,7 +416,9 @@ void worker_main(splat_multi* m, Worker* me) {
         if (me->rank == 0) return;
         int a, b;
         slab_px(&m->slabs[2 * me->rank], h, &a, &b);
-        if (b > a) {
+        // (a render that failed ships nothing: the copy has no peer waiting for it -- unlike the grouped send / recv above
+        // -- and its rows are stale or half cleared; the root keeps what it had, the sync reports the error)
+        if (b > a && rendered) {
             const size_t off = (size_t)a * w, bytes = (size_t)(b - a) * w * 4;
             hipError_t e = (root->device == me->device)
                                ? hipMemcpyAsync(roots + off, mine + off, bytes, hipMemcpyDeviceToDevice, st)
@@ -418,6 +426,7 @@ void worker_main(splat_multi* m, Worker* me) {
             if (e != hipSuccess) note(SPLAT_ERR_HIP, std::string("row copy to the root: ") + hipGetErrorString(e));
         }
         (void)hipEventRecord(me->ev_rows, st);
+        (void)frame_tail(me->ctx);
     };
     // One command.  Every path through it ends in the bookkeeping below (done++): nothing in here may leave the
     // thread -- drain(), sync_all_ranks and splat_multi_destroy wait for done == posted.
@@ -449,8 +458,8 @@ void worker_main(splat_multi* m, Worker* me) {
                 // enqueued their halves of it -- with whatever its rows hold; the error is reported by the sync.
                 const int k = m->overlap >= 2 ? (int)(me->n_frames & 1ull) : 0;
                 me->n_frames++;
-                (void)check(splat_render_frame_device(me->ctx, &c.cam, me->imgs[k], 0, nullptr), "splat_render_frame_device");
-                gather(w, h, k);
+                const bool ok = check(splat_render_frame_device(me->ctx, &c.cam, me->imgs[k], 0, nullptr), "splat_render_frame_device");
+                gather(w, h, k, ok);
                 me->cur.store(k);
                 break;
             }
@@ -468,8 +477,8 @@ void worker_main(splat_multi* m, Worker* me) {
                 if (m->overlap >= 2) (void)check(ctx_quiesce(me->ctx), "waiting for the frames in flight");
                 if (bytes) (void)hip_ok(hipMemcpyAsync(me->imgs[0] + off, c.host + off, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync(slab rows in)");
                 std::memset(&me->stats, 0, sizeof me->stats);
-                (void)check(splat_render_device(me->ctx, &c.cam, me->imgs[0], 1, c.want_stats ? &me->stats : nullptr), "splat_render_device");
-                gather(w, h, 0);     // (also after a failure: see CMD_FRAME)
+                const bool ok = check(splat_render_device(me->ctx, &c.cam, me->imgs[0], 1, c.want_stats ? &me->stats : nullptr), "splat_render_device");
+                gather(w, h, 0, ok);     // (also after a failure: see CMD_FRAME)
                 me->cur.store(0);
                 break;
             }
@@ -504,8 +513,15 @@ void abort_all_comms(splat_multi* m) {
     std::lock_guard<std::mutex> g(m->abort_mu);
     for (auto& w : m->w) {
         CommState* st = *ctx_comm_slot(w->ctx);
-        if (!st || !st->comm || st->aborted.exchange(true)) continue;
-        if (rccl()->CommAbort) (void)rccl()->CommAbort(st->comm);
+        if (!st || !st->comm || st->aborted.exchange(true)) continue;      // (from here on no gather STARTS on this communicator)
+        if (!rccl()->CommAbort) continue;
+        // A gather that is past its `aborted` check holds st->mu until its enqueue has returned.  If none is in flight the
+        // communicator is aborted under the lock: no thread can be between the check and the use.  If one is, it may be
+        // blocked INSIDE RCCL waiting for this very rank (connection set-up of a grouped send / recv) -- waiting for its
+        // lock would deadlock -- and aborting a communicator under a call in progress on another thread is what
+        // ncclCommAbort is for.
+        std::unique_lock<std::mutex> lk(st->mu, std::try_to_lock);
+        (void)rccl()->CommAbort(st->comm);
     }
 }
 

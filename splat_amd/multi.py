@@ -108,3 +108,8 @@ class MultiRenderer:
             raise SplatError(rc, (self._L.splat_last_error(C.c_void_p(ctx)) or b"").decode())
         names = ("preprocess", "scan", "emit", "sort", "composite", "status")
         return {k: ms[i] for i, k in enumerate(names)}, frames.value
+
+    def rank_frames_dropped(self, rank):
+        """frames one rank's device skipped since creation (splat_frames_dropped of its context)"""
+        ctx = self._L.splat_multi_ctx(self._h, int(rank))
+        return int(self._L.splat_frames_dropped(C.c_void_p(ctx)))

@@ -90,6 +90,15 @@ class Renderer:
         splat_set_frame_overlap); 1 (default): one compositor at a time, in call order."""
         self._check(self._L.splat_set_frame_overlap(self._h, int(n)))
 
+    def set_option(self, option, value):
+        """splat_set_option: a tuning option (_lib.OPT_*) from code instead of from the environment; never changes a pixel"""
+        self._check(self._L.splat_set_option(self._h, int(option), float(value)))
+
+    def get_option(self, option):
+        v = C.c_double()
+        self._check(self._L.splat_get_option(self._h, int(option), C.byref(v)))
+        return v.value
+
     def set_stream(self, stream_ptr):
         self._check(self._L.splat_set_stream(self._h, C.c_void_p(stream_ptr)))
 

@@ -125,7 +125,6 @@ def test_naive_scene_both_pipelines(R):
     p1 = splat_amd.GaussianSplatPipeline01(g, cam, renderer=R)
     img = np.zeros((600, 800), np.uint32)
     p1.render_to_buffer(img)
-    assert not img.any() or True
     # Pipeline01 with cov3d never computed: cov3d = 0 -> cov2d = 0.01 I (main.rs:24-26 is the caller's job)
     ref, _ = O.render(scene_dict(g), oracle_camera(cam, 0.01))
     assert image_diff(img, ref)[0] <= TOL_LSB
@@ -667,6 +666,94 @@ def test_bench_multirank_path_on_shared_gpu():
         assert d["n_gpus"] == n and d["scaling"] == "strong"
         assert d["multi_gpu_frame_equals_single_gpu_frame"] is True
         assert d["config"]["n_pairs"] == 946132          # the slabs partition the frame's pairs exactly
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` WITHOUT a launcher around it (how the driver's N=1 command line looks with another N)
+    must print the line itself: bench.py re-executes as the torchrun launch of N ranks.  C3 -- BASELINE config 4 at
+    workload size -- as 8 ranks sharing this GPU (gloo transport), and the one-process form (splat_multi_*) as 4."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPLAT_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    for extra, n in ((["--gpus", "8"], 8), (["--gpus", "4", "--single-process"], 4)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "C3"] + extra,
+                           capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == n and d["scaling"] == "strong" and d["metric"] == "frames_per_sec"
+        assert d["multi_gpu_frame_equals_single_gpu_frame"] is True
+        assert d["config"]["n_pairs"] == 8025623                      # the slabs partition the C3 frame's pairs exactly
+        assert len(d["kernel_ms_per_rank"]) == n and all("composite" in k for k in d["kernel_ms_per_rank"])
+        assert "roofline_frame" in d and d["roofline_frame"]["bytes_algorithmic"] > 0
+        drops = d["config"]["frames_dropped"] if "frames_dropped" in d["config"] else d["frames_dropped"]
+        assert drops == 0
+
+
+def test_options_set_from_code_change_the_schedule_not_the_pixels():
+    """splat_set_option: what the SPLAT_* environment variables choose, set through the ABI by a host that cannot reach
+    its environment.  Every setting must render the frame the defaults render, byte for byte; the
+    getter reports what is in force; a value out of range is refused; an option pinned by its environment variable
+    stays the operator's."""
+    import os
+    from splat_amd import _lib as L
+    g = splat_amd.synthetic_scene(90000, 52)
+    g.positions[:, :3] *= 0.3                                  # dense: lists beyond 2048 keys, early-out in play
+    cam = make_camera(200, 296, (0.0, 0.1, 3.0), yaw=0.3)
+    cam_c = cam.to_c(0.01)
+    r = splat_amd.Renderer()
+    try:
+        g.compute_cov3d(r)
+        r.upload(g)
+        base = np.zeros((200, 296), np.uint32)
+        st = r.render(cam_c, base)
+        assert st.max_tile_len > 2048 and base.any()
+        assert r.get_option(L.OPT_PIPELINE_DEPTH) == 6 and r.get_option(L.OPT_FUSED_SORT_MAX) == 2048
+        settings = [[(L.OPT_PIPELINE_DEPTH, 1)], [(L.OPT_PIPELINE_DEPTH, 2)], [(L.OPT_PIPELINE_DEPTH, 4), (L.OPT_FUSED_SORT_MAX, 0)],
+                    [(L.OPT_PIPELINE_DEPTH, 6), (L.OPT_FUSED_SORT_MAX, 512), (L.OPT_SORT_IN_COMPOSITOR, 1)],
+                    [(L.OPT_SORT_IN_COMPOSITOR, 0), (L.OPT_EARLY_OUT_EPS, 0.0)],
+                    [(L.OPT_EARLY_OUT_EPS, 1e-4), (L.OPT_EARLY_OUT_MIN_LIST, 128), (L.OPT_EARLY_OUT_SCAN_EIGHTHS, 8)],
+                    [(L.OPT_PAIR_WALK, 1), (L.OPT_BLOCK_CULLING, 0), (L.OPT_REGION_SPARE, 1.0)],
+                    [(L.OPT_PAIR_WALK, 0), (L.OPT_ONE_PASS_BINNING, 0), (L.OPT_TIMING_EVERY, 1)],
+                    [(L.OPT_ONE_PASS_BINNING, 1), (L.OPT_KEY_BUFFER_BYTES, 1 << 20)],            # too small for regions: two-pass
+                    [(L.OPT_KEY_BUFFER_BYTES, float(128 << 30)), (L.OPT_PRIORITY_LIST_LEN, 512), (L.OPT_FRAME_OVERLAP, 2)]]
+        for opts in settings:
+            for o, v in opts:
+                r.set_option(o, v)
+                assert r.get_option(o) == pytest.approx(v), (o, v)
+            img = np.zeros((200, 296), np.uint32)
+            r.render(cam_c, img)
+            assert np.array_equal(img, base), (opts, int((img != base).sum()))
+            for _ in range(3):                                  # asynchronous frames through the same settings
+                buf = r.host_image(200, 296)
+                r.render_stream(cam_c, buf)
+                r.stream_wait(buf)
+                assert np.array_equal(buf, base), opts
+        for o, v in ((L.OPT_PIPELINE_DEPTH, 7), (L.OPT_FUSED_SORT_MAX, 4096), (L.OPT_REGION_SPARE, 0.5), (L.OPT_FRAME_OVERLAP, 3), (99, 1), (0, 1)):
+            with pytest.raises(splat_amd.renderer.SplatError):
+                r.set_option(o, v)
+    finally:
+        r.close()
+    saved = os.environ.get("SPLAT_FUSED_SORT")
+    os.environ["SPLAT_FUSED_SORT"] = "256"
+    try:
+        r = splat_amd.Renderer()
+        try:
+            r.set_option(L.OPT_FUSED_SORT_MAX, 1024)            # accepted, not applied: the environment pins it
+            assert r.get_option(L.OPT_FUSED_SORT_MAX) == 256
+            r.upload(g)
+            img = np.zeros((200, 296), np.uint32)
+            r.render(cam_c, img)
+            assert np.array_equal(img, base)
+        finally:
+            r.close()
+    finally:
+        os.environ.pop("SPLAT_FUSED_SORT", None)
+        if saved is not None:
+            os.environ["SPLAT_FUSED_SORT"] = saved
 
 
 def test_paired_walk_gives_the_same_bytes():

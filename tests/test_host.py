@@ -37,6 +37,22 @@ def test_null_handles_are_refused_without_touching_the_device():
     assert L.splat_set_slab(None, 0, 1) == inv
     assert L.splat_frames_dropped(None) == 0
     assert L.splat_stream(None) is None
+    import ctypes as C
+    v = C.c_double()
+    assert L.splat_set_option(None, _lib.OPT_PIPELINE_DEPTH, 2.0) == inv
+    assert L.splat_get_option(None, _lib.OPT_PIPELINE_DEPTH, C.byref(v)) == inv
+
+
+def test_option_constants_follow_the_header():
+    """the ctypes binding's OPT_* are include/splat_hip.h's SPLAT_OPT_*, one for one"""
+    hdr = open(os.path.join(ROOT, "include", "splat_hip.h")).read()
+    opts = dict((n, int(v)) for n, v in re.findall(r"#define SPLAT_(OPT_[A-Z0-9_]+) (\d+)", hdr))
+    assert len(opts) >= 15 and sorted(opts.values()) == list(range(1, len(opts) + 1))
+    for n, v in opts.items():
+        assert getattr(_lib, n) == v, n
+    ffi = open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read()
+    for n, v in opts.items():
+        assert re.search(r"pub const SPLAT_%s: i32 = %d;" % (n, v), ffi), n
 
 
 def test_struct_sizes_match_header():
