@@ -239,6 +239,139 @@ def surface_leg(R0, image, stream, device, args, counted, leg_drops):
     return out
 
 
+def live_pmc_traffic(args):
+    """HBM bytes per launch of every kernel of THIS workload on THIS box: two short rocprofv3 passes of bench.py itself
+    (--pmc FETCH_SIZE, then --pmc WRITE_SIZE -- separate passes, no trace domain beside them, as MI355X_MICROARCH.md's
+    HBM section prescribes), corrected as that section says (both counters are KiB; gfx950's FETCH_SIZE tallies the
+    128-B requests of a wide coalesced stream at 64 B: doubled; calibration in this repo's access pattern:
+    profiles/README.md).  Returns ({kernel: bytes}, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 is not on this box"
+    work = tempfile.mkdtemp(prefix="splat_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sub = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--settle", "5", "--no-cpu-baseline",
+           "--no-extra-legs", "--no-live-pmc", "--workload", args.workload, "--mode", args.mode]
+    if args.scene:
+        sub += ["--scene", os.path.abspath(args.scene)]
+    if args.orbit:
+        sub += ["--orbit"]
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            try:
+                r = subprocess.run([exe, "--pmc", counter, "--kernel-include-regex", "splat", "--output-format", "csv", "-d", d, "--"] + sub,
+                                   cwd=work, env=env, capture_output=True, text=True, timeout=420)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s timed out" % counter
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s: rc %d, %d counter files: %s" % (counter, r.returncode, len(files), (r.stderr or "")[-300:])
+            acc = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name", counter) != counter:
+                        continue
+                    name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("splat::", "").strip()
+                    acc.setdefault(name, []).append(float(row["Counter_Value"]))
+            for name, vals in acc.items():
+                per.setdefault(name, {})[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out, detail = {}, {}
+    for name, c in per.items():
+        f, nf = c.get("FETCH_SIZE", (0.0, 0))
+        w, nw = c.get("WRITE_SIZE", (0.0, 0))
+        out[name] = int(f * 1024.0 * 2.0 + w * 1024.0)
+        detail[name] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w, "read_bytes_corrected": int(f * 2048.0),
+                        "write_bytes": int(w * 1024.0), "launches_averaged": [nf, nw]}
+    if args.pmc_json:
+        json.dump({"workload": args.workload, "bytes_per_launch": out, "detail": detail}, open(args.pmc_json, "w"), indent=1, sort_keys=True)
+    return out, detail
+
+
+def cold_and_incoherent_legs(g, W, H, cam_c, device, stream, mode):
+    """What the headline never shows (it runs one pose after 200 settled frames): a context's FIRST frame, frames at
+    uncorrelated poses, and the first frame after the camera jumps.  One-pass binning sizes every tile's key region
+    from the lists of earlier frames; a frame that outgrows them is skipped on the device and -- synchronous frames,
+    as here -- redone inside the call with rebuilt regions, so these legs pay for every redo (`frames_redone`).
+    Reference loop: src/main.rs:43-78 (one synchronous render_to_buffer per pose change)."""
+    import torch
+    import splat_amd
+    out = {}
+    R = splat_amd.Renderer(device=device, mode=mode)
+    try:
+        image = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.upload(g)
+        R.set_stream(stream.cuda_stream)
+        # (1) first frame after splat_upload_scene: key buffers are allocated, every slot counts its pairs first
+        t0 = time.perf_counter()
+        R.render_frame_device(cam_c, image.data_ptr(), sync=True)
+        out["first_frame_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        R.render_frame_device(cam_c, image.data_ptr(), sync=True)
+        out["second_frame_ms"] = (time.perf_counter() - t0) * 1e3
+        # (2) 36 uncorrelated poses, a third of them inside the cloud, each a synchronous frame
+        rng = np.random.default_rng(36)
+        poses = []
+        for k in range(36):
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            radius = rng.uniform(0.2, 1.2) if k % 3 == 0 else rng.uniform(2.5, 7.0)
+            cam = splat_amd.Camera(H, W, tuple(float(v) for v in d * radius))
+            cam.update_yaw_angle(float(rng.uniform(0.0, 2.0 * np.pi)))
+            cam.update_pitch_angle(float(rng.uniform(-0.6, 0.6)))
+            cam.update_camera_pose()
+            poses.append(cam.to_c(0.01, 15))
+        order = rng.permutation(36)
+        d0 = R.frames_dropped()
+        per = []
+        t0 = time.perf_counter()
+        for k in order:
+            t1 = time.perf_counter()
+            R.render_frame_device(poses[k], image.data_ptr(), sync=True)
+            per.append((time.perf_counter() - t1) * 1e3)
+        dt = time.perf_counter() - t0
+        out["random_pose_sync_fps"] = 36 / dt
+        out["random_pose_sync"] = {"frames": 36, "frames_redone": int(R.frames_dropped() - d0), "ms_mean": float(np.mean(per)),
+                                   "ms_median": float(np.median(per)), "ms_max": float(np.max(per)),
+                                   "what": "36 poses in random order: positions uniform in direction, radius 0.2-1.2 (every third pose: "
+                                           "inside the cloud) or 2.5-7, random yaw and pitch; every frame synchronous "
+                                           "(clear + render + wait), so a frame the device skipped is redone inside its call"}
+        # (3) steady state at the bench pose, then the camera jumps (to the first inside pose, and back)
+        for _ in range(40):
+            R.render_frame_device(cam_c, image.data_ptr())
+        try:
+            R.sync()
+        except Exception:
+            pass
+        torch.cuda.synchronize()
+        d0 = R.frames_dropped()
+        inside = poses[0]
+        t0 = time.perf_counter()
+        R.render_frame_device(inside, image.data_ptr(), sync=True)
+        out["pose_jump_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        R.render_frame_device(inside, image.data_ptr(), sync=True)
+        after = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        R.render_frame_device(cam_c, image.data_ptr(), sync=True)
+        back = (time.perf_counter() - t0) * 1e3
+        out["pose_jump"] = {"to_inside_ms": out["pose_jump_ms"], "same_pose_again_ms": after, "back_to_bench_pose_ms": back,
+                            "frames_redone": int(R.frames_dropped() - d0),
+                            "what": "40 asynchronous frames at the bench pose, then ONE synchronous frame from inside the cloud "
+                                    "(radius %.2f): wall time until the complete frame" % float(np.linalg.norm(list(inside.cam_pos)))}
+    finally:
+        R.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +389,11 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"],
                     help="exact (default, what `value` is quoted on): the reference's frame; fast: SPLAT_MODE_FAST, every colour "
                          "byte within 1 of the exact frame's by construction")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this workload after the timed "
+                         "region; roofline.traffic then comes from the committed profiles/traffic.json, labelled so")
+    ap.add_argument("--pmc-json", default=None, help="also write the live counter passes' per-kernel bytes to this file")
+    ap.add_argument("--settle", type=int, default=SETTLE_FRAMES, help=argparse.SUPPRESS)
     ap.add_argument("--scene", default=None,
                     help="an INRIA 3DGS .ply (e.g. the real 'truck' / 'bicycle' / plush_sledge scene: none is in the repo, "
                          "src/main.rs:21 loads one): rendered at --workload's resolution and camera instead of the synthetic "
@@ -407,7 +545,7 @@ def main():
         st = R.render_device(cam_c, image.data_ptr(), sync=True, want_stats=True)
     # setup, untimed and not counted as warm-up steps: the same frames until the device is out of its idle clocks and
     # every lazily created queue exists (a GPU fresh from idle runs its first few dozen frames ~10 % slower)
-    for _ in range(0 if share else SETTLE_FRAMES):       # (not on the CPU-transport test path: nothing to settle there)
+    for _ in range(0 if share else args.settle):         # (not on the CPU-transport test path: nothing to settle there)
         step()
     fence()
     for _ in range(args.warmup):
@@ -532,6 +670,8 @@ def main():
             # write_ply -> load_from_ply, bench pose and a pose inside the sphere: fps, counters, parity
             if args.workload == "C3" and not args.scene:
                 legs["c3s_surface_scene"] = surface_leg(R, image, stream, local, args, counted, leg_drops)
+            # (5) cold and incoherent frames: first frame, 36 uncorrelated poses, a pose jump
+            legs.update(cold_and_incoherent_legs(g, W, H, cam_c, local, stream, main_mode))
             legs["frames_dropped"] = dict(leg_drops)
             legs["what"] = ("host-visible = pixels delivered to host memory (PCIe inclusive); never `value`.  %d frames each "
                             "(splat_render: 20).  frames_dropped = frames the device skipped inside each leg's timed loop "
@@ -599,9 +739,22 @@ def main():
                 prof_src = tj.get(args.workload + ":source")
             except Exception:
                 traffic = None
+        traffic_live, traffic_note, live_all = False, None, None
+        if world == 1 and not args.no_live_pmc:
+            # bytes measured in THIS run: the context is idle now (the timed region and the legs are over); the two counter
+            # passes are processes of their own on the same GPU
+            live, detail = live_pmc_traffic(args)
+            if live is None:
+                traffic_note = "live counter passes unavailable (%s): committed profile used" % detail
+            else:
+                kname = next((k for k in sorted(live) if k.startswith("composite_exact_kernel")), None)
+                if kname:
+                    traffic, traffic_live, live_all = live[kname], True, live
+                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench.py on this box, after the timed "
+                                    "region (3 steps each; KiB -> bytes, FETCH_SIZE doubled: MI355X_MICROARCH.md HBM section)")
         out = {
             "metric": "frames_per_sec", "value": args.steps / dt, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_frames_before_warmup": SETTLE_FRAMES,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_frames_before_warmup": args.settle,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": data_kind,
             "config": {"workload": "%s: %d Gaussians @%dx%d, %s, Camera(0,0,5), Pipeline01 "
@@ -628,11 +781,14 @@ def main():
                                        "what": "the same kernel with a sync after every frame: in the timed region it shares "
                                                "the chip with the next frame's preprocess/scan/sort (cross-frame overlap)"}
                                       if iso and iso["composite"] > 0 else None),
-                         "from_committed_profile": {"traffic": traffic is not None, "valu_issue_util": valu_util,
+                         "traffic_source": traffic_note,
+                         "traffic_all_kernels": live_all,
+                         "from_committed_profile": {"traffic": (traffic is not None) and not traffic_live, "valu_issue_util": valu_util,
                                                     "counters": ("profiles/%s_pmc_*.csv" % prof_src) if prof_src else None,
-                                                    "what": "HBM bytes per launch and VALU issue utilisation come from the committed "
-                                                            "rocprofv3 --pmc passes of this build (counters cannot be read inside "
-                                                            "bench.py); everything else in this object is measured in this run"},
+                                                    "what": "VALU issue utilisation (and the HBM bytes per launch when the live counter "
+                                                            "passes could not run: `traffic` true here) come from the committed "
+                                                            "rocprofv3 --pmc passes of this build; everything else in this object is "
+                                                            "measured in this run"},
                          "compositor_work": {"flops_alg": int(tot[3]),
                                              "gflops_alg_per_s": (int(tot[3]) / (per["composite"] * 1e-3) / 1e9) if per["composite"] > 0 else None,
                                              "wave_record_iterations_scan": int(tot[4]), "wave_record_iterations_blend": int(tot[5]),
