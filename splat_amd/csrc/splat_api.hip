@@ -813,6 +813,25 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
             std::vector<uint2> it(m * 4u);
             if (hipMemcpy(it.data(), c->d_iters, sizeof(uint2) * it.size(), hipMemcpyDeviceToHost) == hipSuccess)
             {
+                if (c->knobs.dbg_starts) {
+                    // (debug: the words are (list length, nearest keys the wave's walk needed) -- how much of every list had to
+                    // be in order at all, by list length class)
+                    const unsigned int edges[6] = {0u, 768u, 2048u, 8192u, 16384u, 0xffffffffu};
+                    for (int cls = 0; cls < 5; ++cls) {
+                        uint64_t tiles = 0, keys = 0, need = 0, need2k = 0, full = 0;
+                        for (size_t t = 0; t < m; ++t) {
+                            const unsigned int len = std::max(std::max(it[4 * t].x, it[4 * t + 1].x), std::max(it[4 * t + 2].x, it[4 * t + 3].x));
+                            if (len == 0 || len <= edges[cls] || len > edges[cls + 1]) continue;
+                            unsigned int nd = 0;
+                            for (int w = 0; w < 4; ++w) nd = std::max(nd, it[4 * t + w].y);
+                            ++tiles; keys += len; need += nd; need2k += nd <= 2048u ? 1u : 0u; full += nd >= len ? 1u : 0u;
+                        }
+                        std::fprintf(stderr, "lists of %u < len <= %u keys: %llu tiles, %llu keys, deepest wave start needs %llu of them (%.1f %%); "
+                                     "%llu tiles need <= 2048 keys, %llu need the whole list\n", edges[cls], edges[cls + 1],
+                                     (unsigned long long)tiles, (unsigned long long)keys, (unsigned long long)need, keys ? 100.0 * need / keys : 0.0,
+                                     (unsigned long long)need2k, (unsigned long long)full);
+                    }
+                } else
                 for (const uint2& v : it) { st->n_iter_scan += v.x; st->n_iter_blend += v.y; }
                 if (std::getenv("SPLAT_DBG_IMBALANCE")) {      // how much of a tile's four wave slots its slowest wave leaves idle
                     double sum = 0, held = 0;
@@ -977,6 +996,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
+    if (const char* k5 = std::getenv("SPLAT_DBG_STARTS")) c->knobs.dbg_starts = std::atoi(k5) != 0 ? 1u : 0u;
     if (const char* k4 = std::getenv("SPLAT_COMP_LDS_PAD")) c->knobs.comp_lds_pad = (unsigned int)std::max(0, std::atoi(k4));
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);

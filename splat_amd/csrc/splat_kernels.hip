@@ -717,6 +717,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     if constexpr (BUCKET) {
         // Block culling rides on the barrier the table reset needs anyway: wave 0 alone runs the bounds test (a
         // few hundred instructions that used to be issued by all four waves) while the others clear the table.
+#if SPLAT_EXP & 4
+        // every wave runs the (wave-uniform) test itself: a culled block's waves leave at once -- no table reset, no barrier
+        if (fc.cull_blocks) {
+            const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
+            if (threadIdx.x == 0) blockinfo[blockIdx.x] = reach ? 0u : 0x80000000u;
+            if (!reach) return;
+        }
+        bin_preinit(sh);
+        __syncthreads();
+#else
         if (fc.cull_blocks && threadIdx.x < 64u) {
             const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
             // (the flag is a plain store: thousands of culled blocks retire within microseconds, and that
@@ -726,6 +736,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         bin_preinit(sh);
         __syncthreads();
         if (fc.cull_blocks && sreach == 0u) return;          // whole block off this context's slab / target: nothing to read
+#endif
         STAMPF(1);
     } else if (fc.cull_blocks) {
         const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
@@ -2136,7 +2147,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 L.a[slot] = make_float4(r.a.x, r.a.y, __uint_as_float(base + lane), 0.0f);
                 L.b[slot] = make_float4(-0.5f * L2E * r.b.x, -L2E * r.b.y, -0.5f * L2E * r.b.z, __log2f(r.b.w));
             } else {
+#if SPLAT_EXP & 2
+                L.a[slot] = r.a; L.b[slot] = make_float4(-0.5f * r.b.x, r.b.y, -0.5f * r.b.z, r.b.w);
+#else
                 L.a[slot] = r.a; L.b[slot] = r.b;
+#endif
                 L.c[slot] = make_float4(r.c.x, r.c.y, r.c.z, __uint_as_float(base + lane));   // .w: list position
             }
         }
@@ -2260,7 +2275,19 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     auto shade = [&](auto BRt, const float4& a, const float4& b, const float4& c) {
         constexpr bool BR = decltype(BRt)::value;
         bool cov;
+#if SPLAT_EXP & 2
+        float alpha;
+        {
+            float dx = sxm - a.x, dy = a.y - sym;
+            cov = (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
+            float power = (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+            float al = fminf(0.99f, b.w * expv(power));
+            bool accept = cov & !(power > 0.0f) & !(al < 1.0f / 255.0f);
+            alpha = accept ? al : 0.0f;
+        }
+#else
         const float alpha = frag_alpha(a, b, expv, cov);
+#endif
         const float ia = 1.0f - alpha;
         const float ar = alpha * c.x, ag = alpha * c.y, ab = alpha * c.z;
         R = blend_channel(R, ia, ar);
@@ -2329,7 +2356,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 for (unsigned int j = 0; j < (k + 1u) / 2u; ++j)
                     shade_pair(BRt, P4[6 * j], P4[6 * j + 1], P4[6 * j + 2], P4[6 * j + 3], P4[6 * j + 4], P4[6 * j + 5]);
             } else {
+#if SPLAT_EXP & 1
+                for (unsigned int j = 0; j < k; ++j) { const float4 cc = L.c[j]; asm volatile("" :: "v"(cc.w)); shade(BRt, L.a[j], L.b[j], cc); }
+#else
                 for (unsigned int j = 0; j < k; ++j) shade(BRt, L.a[j], L.b[j], L.c[j]);
+#endif
             }
             itB += k;
             if (BR && __builtin_amdgcn_ballot_w64(inside & ((R2 - R > cw) | (G2 - G > cw) | (B2 - B > cw))) == 0ull) return bsN;
@@ -2362,7 +2393,9 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     const float A = (alast < 0.0f) ? (float)(old >> 24) : truncf(alast * 255.0f);   // alpha in {0} U [1/255, .99]
     // statistics frames only (iters != nullptr): this wave's (scan, blend) iteration counts as one plain store
     // (atomics on two frame-wide counters cost ~0.2 ms per frame)
-    if (iters != nullptr && lane == 0) iters[item * 4u + wave] = make_uint2(itA, itB);
+    // (keep_keys bit 1, SPLAT_DBG_STARTS: the list's length and how many of its nearest keys this wave's walk needed instead)
+    if (iters != nullptr && lane == 0)
+        iters[item * 4u + wave] = (keep_keys & 2u) ? make_uint2(end - beg, end - max(start, beg)) : make_uint2(itA, itB);
     if (inside)
         argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
 }
@@ -2510,7 +2543,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     const unsigned int pad = g_knobs->comp_lds_pad;
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                           sort_radix_min(), iters, keep_keys ? 1u : 0u, orig, clear_first ? 1u : 0u, keys2);
+                           sort_radix_min(), iters, (keep_keys ? 1u : 0u) | (g_knobs->dbg_starts ? 2u : 0u), orig, clear_first ? 1u : 0u, keys2);
     };
     if (keys2 != nullptr) {
         if (libm_exp) go(composite_exact_kernel<false, true, true>);
