@@ -1,0 +1,48 @@
+"""The HIP path under every euc convention setting (-m gpu): for each of the four frames rust/examples/dump_frames.rs
+writes, and each of the 16 settings of (y_up, sample_half, z-clip range, raster rule), the committed candidate
+(tests/golden/pin_candidates.npz, the oracle's frame under that setting) against the frame the library renders with the
+matching splat_config.  With the exponential computed as libm does the analytic-rectangle candidates must come out BIT
+FOR BIT; the default exponential stays within 1 LSB; the two-triangle candidates (an oracle-only variant of the raster
+rule: barycentric interpolation of coordxy) within 1 LSB on a few pixels.  So whichever candidate a run of the reference
+turns out to equal (tools/pin_euc.py --against-candidates), the product already renders it under that configuration --
+parity flips to "pinned" with a change of defaults, not of code.  Reference: src/pipelines.rs:7-14, 80-84; SURVEY
+appendix B."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import splat_amd
+from helpers import image_diff
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+import pin_euc as P  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_path_reproduces_every_candidate_under_the_matching_config():
+    cand, st = P.load_candidates()
+    with tempfile.TemporaryDirectory() as d:
+        fr = P.frames(P.c1_scene_ply(os.path.join(d, "c1.ply")))
+    assert sorted(fr) == sorted(cand)
+    for si, k in enumerate(st):
+        conv = dict(y_up=k["y_up"], sample_half=k["sample_half"], zclip=k["zclip"], zmin=k["zmin"], zmax=k["zmax"])
+        for mode in (splat_amd.MODE_LIBM_EXP, splat_amd.MODE_EXACT):
+            R = splat_amd.Renderer(mode=mode, **conv)
+            try:
+                for name, (scene, cam, lowpass, (h, w)) in fr.items():
+                    R.upload(scene)
+                    img = np.zeros((h, w), np.uint32)
+                    R.render(cam.to_c(lowpass, 15), img)
+                    want = cand[name][si]
+                    mx, cnt = image_diff(img, want)
+                    if k["raster"] == 0 and mode == splat_amd.MODE_LIBM_EXP:
+                        assert np.array_equal(img, want), (name, P.label(k), mx, cnt)
+                    else:
+                        assert mx <= 1 and cnt <= max(64, h * w // 500), (name, P.label(k), mode, mx, cnt)
+                    assert want.any() == img.any()
+            finally:
+                R.close()

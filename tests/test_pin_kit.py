@@ -49,3 +49,36 @@ def test_pin_euc_selftest_identifies_a_hidden_setting():
                        timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "selftest ok" in r.stdout
+
+
+def _pin():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_euc
+    return pin_euc
+
+
+def test_committed_candidates_are_what_the_oracle_renders():
+    """tests/golden/pin_candidates.npz = the four dump frames of rust/examples/dump_frames.rs as the oracle renders them
+    under all 16 convention settings (tools/pin_euc.py --write-candidates).  The moment ONE run of the reference exists,
+    `tools/pin_euc.py --against-candidates DIR` names euc's setting from this file alone."""
+    import tempfile
+    import numpy as np
+    P = _pin()
+    cand, st = P.load_candidates()
+    assert len(st) == 16 and [P.label(a) for a in st] == [P.label(b) for b in P.SETTINGS]
+    assert sorted(cand) == ["c1_256x256_p01.raw", "naive_1280x720_p01_identity.raw", "naive_1280x720_p02.raw", "naive_800x600_p01.raw"]
+    with tempfile.TemporaryDirectory() as d:
+        fr = P.frames(P.c1_scene_ply(os.path.join(d, "c1.ply")))
+        for name, (scene, cam, lowpass, (h, w)) in fr.items():
+            for si, k in enumerate(P.SETTINGS):
+                assert np.array_equal(P.render(scene, cam, lowpass, k), cand[name][si]), (name, P.label(k))
+        # ... and dumps written under a hidden setting come back as that setting, from the file alone
+        hidden = 6
+        for name in cand:
+            cand[name][hidden].astype("<u4").tofile(os.path.join(d, name))
+        best = P.against_candidates(d, out=open(os.devnull, "w"))
+        for name, si in best.items():
+            assert np.array_equal(cand[name][si], cand[name][hidden]), (name, si)
+    # the settings are not all the same picture: the file can tell them apart where the scene lets it
+    c1 = cand["c1_256x256_p01.raw"]
+    assert len({c.tobytes() for c in c1}) >= 8

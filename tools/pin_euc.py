@@ -4,6 +4,9 @@
     python tools/pin_euc.py DIR            # DIR holds the dumps written by rust/examples/dump_frames.rs
     python tools/pin_euc.py --write-c1 c1.ply      # the 10k synthetic C1 scene as an INRIA PLY, for dump_frames' 4th frame
     python tools/pin_euc.py --selftest     # dumps made by the oracle itself under a hidden setting must be identified
+    python tools/pin_euc.py --write-candidates tests/golden/pin_candidates.npz   # the oracle's four frames under all 16 settings
+    python tools/pin_euc.py --against-candidates DIR [tests/golden/pin_candidates.npz]   # dumps vs the committed candidates: no
+                                           # oracle, no GPU, one file comparison -- names the setting that IS euc's
 
 Every frame is rendered by oracle/ (CPU, test infrastructure) under all 2 x 2 x 2 x 2 settings of
 (y_up, sample_half, z-clip [0,1] | [-1,1], analytic rectangle | two-triangle raster) and compared with the dump:
@@ -93,6 +96,97 @@ def compare(dump_dir, c1_ply=None, out=sys.stdout):
     return results
 
 
+CANDIDATES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "pin_candidates.npz")
+
+
+def c1_scene_ply(path):
+    """the 10k synthetic C1 scene as the INRIA PLY dump_frames' fourth frame loads (seeded: the same file everywhere)"""
+    G.write_ply(path, G.synthetic_raw(10000, 1), 10000)
+    return path
+
+
+def write_candidates(out_path):
+    """The four dump frames as the ORACLE renders them under each of the 16 settings.  Stored compactly: every candidate
+    as the pixels in which it differs from an earlier candidate of the same frame (or from the empty image), or dense
+    when that is smaller -- settings that only move the z-clip plane or the raster rule change a handful of pixels."""
+    data = {}
+    with tempfile.TemporaryDirectory() as d:
+        fr = frames(c1_scene_ply(os.path.join(d, "c1.ply")))
+        assert len(fr) == 4
+        for name, (scene, cam, lowpass, (h, w)) in fr.items():
+            done = []
+            for si, k in enumerate(SETTINGS):
+                img = render(scene, cam, lowpass, k).reshape(-1).astype(np.uint32)
+                best_ref, best_idx = -1, np.flatnonzero(img)
+                for ri, ref in enumerate(done):
+                    idx = np.flatnonzero(img != ref)
+                    if idx.size < best_idx.size:
+                        best_ref, best_idx = ri, idx
+                if 8 * best_idx.size > 4 * img.size:
+                    data["%s|%d|dense" % (name, si)] = img
+                else:
+                    data["%s|%d|ref" % (name, si)] = np.array([best_ref], np.int32)
+                    data["%s|%d|idx" % (name, si)] = best_idx.astype(np.uint32)
+                    data["%s|%d|val" % (name, si)] = img[best_idx]
+                done.append(img)
+            data["%s|shape" % name] = np.array([h, w], np.int32)
+    data["settings"] = np.array([[k["y_up"], k["sample_half"], k["zclip"], k["zmin"], k["zmax"], k["raster"]] for k in SETTINGS], np.float32)
+    np.savez_compressed(out_path, **data)
+    print("wrote %s (%d bytes)" % (out_path, os.path.getsize(out_path)))
+
+
+def load_candidates(path=CANDIDATES):
+    """-> {frame name: [image under setting 0, ..., 15]}, settings as the dicts of SETTINGS"""
+    z = np.load(path)
+    st = [dict(y_up=int(r[0]), sample_half=int(r[1]), zclip=int(r[2]), zmin=float(r[3]), zmax=float(r[4]), raster=int(r[5])) for r in z["settings"]]
+    out = {}
+    for key in z.files:
+        if key.endswith("|shape"):
+            name = key[:-6]
+            h, w = (int(v) for v in z[key])
+            imgs = []
+            for si in range(len(st)):
+                if "%s|%d|dense" % (name, si) in z.files:
+                    img = z["%s|%d|dense" % (name, si)].astype(np.uint32)
+                else:
+                    ri = int(z["%s|%d|ref" % (name, si)][0])
+                    img = imgs[ri].reshape(-1).copy() if ri >= 0 else np.zeros(h * w, np.uint32)
+                    img[z["%s|%d|idx" % (name, si)]] = z["%s|%d|val" % (name, si)]
+                imgs.append(img.reshape(h, w))
+            out[name] = imgs
+    return out, st
+
+
+def against_candidates(dump_dir, path=CANDIDATES, out=sys.stdout):
+    """The reference's dumps against the COMMITTED candidates: which setting is euc's?  -> {frame: best setting index}"""
+    cand, st = load_candidates(path)
+    best = {}
+    for name in sorted(cand):
+        f = os.path.join(dump_dir, name)
+        if not os.path.exists(f):
+            out.write("%-34s (no dump)\n" % name)
+            continue
+        h, w = cand[name][0].shape
+        ref = np.fromfile(f, "<u4")
+        if ref.size != h * w:
+            out.write("%-34s wrong size: %d pixels, expected %d\n" % (name, ref.size, h * w))
+            continue
+        ref = ref.reshape(h, w)
+        rows = sorted(((image_diff(img, ref)[1], image_diff(img, ref)[0], si) for si, img in enumerate(cand[name])))
+        best[name] = rows[0][2]
+        out.write("%s\n" % name)
+        for cnt, mx, si in rows[:4]:
+            out.write("    pixels differing %8d  max diff %3d   %s\n" % (cnt, mx, label(st[si])))
+    if best:
+        votes = {}
+        for si in best.values():
+            votes[label(st[si])] = votes.get(label(st[si]), 0) + 1
+        out.write("best setting per frame: %s\n" % votes)
+        out.write("(a row with 0 pixels differing -- or a handful at 1 through expf's last place -- pins the conventions: put that\n"
+                  " setting into orc_default_conventions / splat_default_config and `parity` is against the reference itself)\n")
+    return best
+
+
 def selftest():
     """the oracle's own frames under a hidden setting, written as dumps, must come back as that setting"""
     hidden = dict(y_up=0, sample_half=1, zclip=1, zmin=-1.0, zmax=1.0, raster=1)
@@ -119,6 +213,10 @@ if __name__ == "__main__":
         print("wrote", a[1])
     elif a[:1] == ["--selftest"]:
         sys.exit(selftest())
+    elif a[:1] == ["--write-candidates"]:
+        write_candidates(a[1] if len(a) > 1 else CANDIDATES)
+    elif a[:1] == ["--against-candidates"]:
+        against_candidates(a[1], a[2] if len(a) > 2 else CANDIDATES)
     elif a:
         compare(a[0], a[1] if len(a) > 1 else os.path.join(a[0], "c1.ply"))
     else:
