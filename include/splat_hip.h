@@ -91,6 +91,8 @@ typedef struct {
     uint64_t n_iter_blend; /* ... and in exact blending (both measured on the frame the stats belong to)     */
     uint64_t n_blocks_culled; /* 256-Gaussian blocks K1 skipped: bounds cannot reach the slab / target      */
     uint64_t flops_algorithmic; /* sum over pixels of (its tile's list length) * 25  */
+    uint64_t n_near_tiles;    /* tiles whose list of more than 2048 keys was served by its selected nearest keys       */
+    uint64_t n_near_fallback; /* ... of which the whole list had to be sorted after all (a walk reached the selection's far end) */
 } splat_stats;
 
 /* Projected per-Gaussian record as the kernels keep it (debug / stage parity). */
@@ -228,6 +230,11 @@ int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
 #define SPLAT_OPT_PRIORITY_LIST_LEN 14   /* compositor waves of lists at least this long (x2, x4) run at raised priority, >= 1
                                             (default: off; SPLAT_PRIO_LEN)                                                       */
 #define SPLAT_OPT_FRAME_OVERLAP 15       /* = splat_set_frame_overlap: 1 / 2 (default 1; SPLAT_FRAME_OVERLAP)                     */
+#define SPLAT_OPT_NEAR_SELECT_KEYS 16    /* near selection: of a tile list of more than 2048 keys only the nearest <= this many are
+                                            selected (by depth, no sort) and put in order -- the exact early-out never looks
+                                            farther on all but a few tiles, which sort their whole list after all (stats:
+                                            n_near_tiles, n_near_fallback); 64..2048, 0 = off: every long list is sorted in full
+                                            (default 2048; SPLAT_NEAR_KEYS)                                                      */
 int splat_set_option(splat_ctx* ctx, int32_t option, double value);
 int splat_get_option(const splat_ctx* ctx, int32_t option, double* value);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */

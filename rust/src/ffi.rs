@@ -29,6 +29,7 @@ pub const SPLAT_OPT_KEY_BUFFER_BYTES: i32 = 12;
 pub const SPLAT_OPT_FAST_CLOSE_WIDTH: i32 = 13;
 pub const SPLAT_OPT_PRIORITY_LIST_LEN: i32 = 14;
 pub const SPLAT_OPT_FRAME_OVERLAP: i32 = 15;
+pub const SPLAT_OPT_NEAR_SELECT_KEYS: i32 = 16;
 
 #[repr(C)] pub struct SplatCtx { _private: [u8; 0] }
 #[repr(C)] pub struct SplatMulti { _private: [u8; 0] }
@@ -55,6 +56,7 @@ pub struct SplatStats {
     pub ms_composite: f32, pub ms_total: f32,
     pub n_fallback: u64, pub n_sort_fallback: u64, pub n_iter_scan: u64, pub n_iter_blend: u64,
     pub n_blocks_culled: u64, pub flops_algorithmic: u64,
+    pub n_near_tiles: u64, pub n_near_fallback: u64,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]

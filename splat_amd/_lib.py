@@ -27,7 +27,8 @@ class Stats(C.Structure):
                 ("ms_preprocess", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float),
                 ("ms_sort", C.c_float), ("ms_composite", C.c_float), ("ms_total", C.c_float),
                 ("n_fallback", C.c_uint64), ("n_sort_fallback", C.c_uint64), ("n_iter_scan", C.c_uint64), ("n_iter_blend", C.c_uint64),
-                ("n_blocks_culled", C.c_uint64), ("flops_algorithmic", C.c_uint64)]
+                ("n_blocks_culled", C.c_uint64), ("flops_algorithmic", C.c_uint64),
+                ("n_near_tiles", C.c_uint64), ("n_near_fallback", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -116,6 +117,7 @@ OPT_KEY_BUFFER_BYTES = 12
 OPT_FAST_CLOSE_WIDTH = 13
 OPT_PRIORITY_LIST_LEN = 14
 OPT_FRAME_OVERLAP = 15
+OPT_NEAR_SELECT_KEYS = 16
 
 _LIB = None
 

@@ -53,6 +53,8 @@ struct Slot {                  // everything one frame writes before the image
     unsigned int* cursor = nullptr;
     unsigned int* order = nullptr;
     unsigned int* lens = nullptr;           // list length per tile (the list starts at offsets[tile])
+    unsigned int* repair_mask = nullptr;    // near selection: per tile, the waves whose walk needed more than the selected keys
+    unsigned int* repair_list = nullptr;    // ... and the tiles (slots of `order`) the repair launch takes again
     unsigned long long* keys = nullptr;
     unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
     unsigned int* blockinfo = nullptr;     // per K1 block: the info word this slot's last K1 wrote (see launch_preprocess);
@@ -169,6 +171,11 @@ struct splat_ctx {
     int early_scan8 = 4;                   // SPLAT_EARLY_SCAN8
     int prio_len = 0x3fffffff;             // SPLAT_PRIO_LEN
     unsigned int fused_sort_max = 2048;    // SPLAT_FUSED_SORT: lists up to this length are sorted inside the compositor (0: off)
+    // Near selection (SPLAT_NEAR_KEYS / SPLAT_OPT_NEAR_SELECT_KEYS; 0 = off): a list of more than 2048 keys is not sorted; its
+    // tile's compositor workgroup selects the nearest <= near_cap keys by depth and sorts those -- the exact early-out never
+    // looks farther on all but a few tiles, which then sort their whole list after all.  No sort launches in such frames.
+    unsigned int near_cap = 2048;
+    bool last_near = false;                // the most recent frame ran with near selection: its long lists are unordered in memory
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
     int pipeline = 6;                      // frames in flight on the device (SPLAT_PIPELINE = 1..6, see enqueue_frame)
     // Compositor LANES (splat_set_frame_overlap): the compositors of consecutive frames run one after the other on the
@@ -404,7 +411,10 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     HIP_TRY(c, hipMemset(c->zero_layout, 0, sizeof(unsigned int) * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
+        dfree(s.repair_mask); dfree(s.repair_list);
         s.layout_valid = false; s.flip = 0;
+        HIP_TRY(c, dmalloc(c, &s.repair_mask, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.repair_list, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.counts_b, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.lay_a, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.lay_b, sizeof(unsigned int) * (size_t)(m + 1)));
@@ -446,8 +456,20 @@ uint64_t default_pair_capacity(const splat_ctx* c) {
 }
 
 // Who sorts the lists of more than 2048 keys (see splat_ctx::sort_in_comp).
+// Near selection needs the early-out (a walk that must start at the list's first key needs the whole list in order) and the
+// compositor's own sort of the lists up to 2048 keys.
+bool near_selection(const splat_ctx* c) {
+    return c->near_cap != 0u && c->fused_sort_max >= 2048u && c->early_eps > 0.0f && c->sort_in_comp != 0;
+}
+// ... and is only worth its repair launch on frames that have such lists at all (the previous harvested frame's longest
+// list; nothing known yet: assume so).  A frame without the selection falls back on the sort launches / the compositor's
+// full sort as before.
+bool near_selection_for_frame(const splat_ctx* c) {
+    return near_selection(c) && (!c->sort_hint || c->hint_maxlen == 0u || c->hint_maxlen > 2048u);
+}
 bool compositor_sorts_long_lists(const splat_ctx* c, unsigned int m) {
     if (c->fused_sort_max < 2048u) return false;
+    if (near_selection_for_frame(c)) return true;
     // auto: the average list is longer than 2048 keys (the sort launches would carry most of the frame) AND the frame is
     // not the chain of its longest list (more than 1500 pairs per key of that list: C5 3100; the four centre tile rows
     // of C3 as a slab: average 2300 keys but 100 pairs per key of the 10 892-key list, whose sort must not move in
@@ -572,8 +594,10 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         next_layout = into ? nx.lay_b : nx.lay_a; next_counts = into ? nx.counts_b : nx.counts;
         nx.flip = into; nx.layout_valid = true;
     }
+    const bool comp_sorts_frame = compositor_sorts_long_lists(c, m) && s.keys2 != nullptr;
+    const unsigned int near_cap = (comp_sorts_frame && near_selection_for_frame(c)) ? c->near_cap : 0u;
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
-                next_layout, next_counts, c->region_spare);
+                next_layout, next_counts, c->region_spare, near_cap ? s.repair_mask : nullptr);
     HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
         HIP_TRY(c, hipEventRecord(s.ev_binned, bs));
@@ -583,7 +607,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     if (!c->fc.bucket_cap)      // one-pass binning placed the keys in K1
         launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, d_st);
     HIP_TRY(c, mark(3, ss));
-    const bool comp_sorts = compositor_sorts_long_lists(c, m) && s.keys2 != nullptr;
+    const bool comp_sorts = comp_sorts_frame;
     if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
@@ -646,7 +670,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const bool pair_walk = c->pair_mode >= 0 ? c->pair_mode != 0
                                              : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
     launch_composite(cs, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
-                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr);
+                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr, near_cap,
+                     s.repair_mask, s.repair_list);
+    c->last_near = near_cap != 0u;
     HIP_TRY(c, mark(6, cs));
     // the scan has already delivered this frame's status to h_status[r]; a statistics frame refreshes it with the late
     // counters (compositor retries, sort fallbacks)
@@ -778,6 +804,7 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
     st->n_fallback = c->last.n_fallback;
     st->n_sort_fallback = c->last.n_sort_fallback;
     st->n_iter_scan = 0; st->n_iter_blend = 0;
+    st->n_near_tiles = c->last.n_near_tiles; st->n_near_fallback = c->last.n_near_fallback;
     st->n_blocks_culled = 0;
     const unsigned int* binfo = c->last_slot >= 0 ? c->slots[c->last_slot].blockinfo : nullptr;
     if (binfo && c->last_ring >= 0 && (c->fc.cull_blocks || c->fc.bucket_cap)) {   // the frame has finished: sum its block words
@@ -903,6 +930,7 @@ bool store_option(splat_ctx* c, int opt, double v) {
         case SPLAT_OPT_FAST_CLOSE_WIDTH: if (v != 1.0 && v != 2.0) return false; c->fast_width = (float)v; return true;
         case SPLAT_OPT_PRIORITY_LIST_LEN: if (v < 1.0 || v > 1073741823.0) return false; c->prio_len = (int)v; return true;
         case SPLAT_OPT_FRAME_OVERLAP: if (v != 1.0 && v != 2.0) return false; c->overlap = (int)v; return true;    // (lanes: splat_set_option / splat_create make them)
+        case SPLAT_OPT_NEAR_SELECT_KEYS: if (v != 0.0 && (v < 64.0 || v > 2048.0)) return false; c->near_cap = (unsigned int)v; return true;
         default: return false;
     }
 }
@@ -923,6 +951,7 @@ bool load_option(const splat_ctx* c, int opt, double* v) {
         case SPLAT_OPT_FAST_CLOSE_WIDTH: *v = c->fast_width; return true;
         case SPLAT_OPT_PRIORITY_LIST_LEN: *v = c->prio_len; return true;
         case SPLAT_OPT_FRAME_OVERLAP: *v = c->overlap; return true;
+        case SPLAT_OPT_NEAR_SELECT_KEYS: *v = c->near_cap; return true;
         default: return false;
     }
 }
@@ -993,6 +1022,11 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     option_from_env(c, SPLAT_OPT_PAIR_WALK, "SPLAT_PAIR_BLEND", -1, 1);
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) { c->bucket_bytes = std::strtoull(e6, nullptr, 10); c->env_pinned |= 1u << SPLAT_OPT_KEY_BUFFER_BYTES; }
     option_from_env(c, SPLAT_OPT_REGION_SPARE, "SPLAT_REGION_SPARE", 1, 1e9);
+    if (const char* en = std::getenv("SPLAT_NEAR_KEYS")) {
+        const int v = std::atoi(en);
+        c->near_cap = v <= 0 ? 0u : (unsigned int)std::min(2048, std::max(64, v));
+        c->env_pinned |= 1u << SPLAT_OPT_NEAR_SELECT_KEYS;
+    }
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
@@ -1049,6 +1083,7 @@ void splat_destroy(splat_ctx* c) {
     dfree(c->zero_layout);
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
+        dfree(s.repair_mask); dfree(s.repair_list);
         dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
         if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);
@@ -1580,6 +1615,15 @@ int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offset
     const Slot& s = c->slots[c->last_slot];
     if (n_offsets != (uint64_t)c->n_tiles + 1 || n_order != c->last.n_pairs)
         return fail(c, SPLAT_ERR_INVALID, "tile list size mismatch");
+    if (c->last_near && c->last.overflow == 0) {
+        // the frame's compositor selected the nearest keys of every list of more than 2048 keys and left the list itself
+        // as K1 had written it: put those lists in order now (the sort launches, every tile in their grids)
+        use_launch_knobs(&c->knobs);
+        launch_sort(c->stream, c->n_tiles, c->n_tiles, c->n_tiles, c->n_tiles, s.offsets, s.order, s.lens, s.keys, s.keys2, c->slots[c->last_slot].d_status, c->orig, 2048u);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->last_near = false;
+    }
     const size_t m = c->n_tiles;
     std::vector<unsigned int> beg(m + 1), len(m + 1);
     HIP_TRY(c, hipMemcpy(beg.data(), s.offsets, sizeof(unsigned int) * (m + 1), hipMemcpyDeviceToHost));

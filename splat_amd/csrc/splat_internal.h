@@ -58,7 +58,8 @@ struct FrameStatus {
                              // sort grids were sized for.  Emit/sort/composite skipped
     unsigned long long n_fallback;   // waves whose early-out bracket did not close (redone in full)
     unsigned long long n_sort_fallback; // tiles whose radix-by-depth order failed the 64-bit check (depth ties): bitonic redo
-    unsigned long long n_iter_scan;  // compositor (wave, record) iterations: phase A (front-to-back scan)
+    unsigned int n_near_tiles;       // tiles whose long list (> 2048 keys) was served by its selected nearest keys (select_near) ...
+    unsigned int n_near_fallback;    // ... and those among them that needed the whole list sorted after all
     unsigned long long n_iter_blend; //                                       phase B (exact blend)
     unsigned int n_ge8192, n_ge2048;    // tiles whose list has >= 8192 / >= 2048 keys: in `order` they are a prefix
     unsigned int n_ge16384, pad_;       // likewise >= 16384 (the lists sorted as several runs and merged)
@@ -102,7 +103,8 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  const unsigned int* layout = nullptr /* one-pass binning: the regions the frame was binned into */,
                  unsigned int* next_layout = nullptr, unsigned int* next_counts = nullptr /* both given: a second workgroup of
                      the launch builds the regions + cursors of the next frame on this stream (see launch_layout) */,
-                 float spare_max = 4.0f /* how far a region may grow into the buffer's spare room */);
+                 float spare_max = 4.0f /* how far a region may grow into the buffer's spare room */,
+                 unsigned int* repair_mask = nullptr /* near selection: per-tile words the scan zeroes for the compositor */);
 // the regions (and cursors) of the slot's next one-pass frame from this frame's lists; an all-zero `layout` with cursors
 // counted from zero is the bootstrap
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
@@ -128,7 +130,12 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       bool clear_first = false /* the frame starts from a cleared image: old pixels are not read, tiles
                                                   nothing covers are zeroed (color.clear(0) of src/main.rs:73, fused) */,
                       unsigned long long* keys2 = nullptr /* != nullptr: no sort launch ran; lists of more than 2048 keys
-                                                             are sorted by their tile's workgroup through this buffer */);
+                                                             are sorted by their tile's workgroup through this buffer */,
+                      unsigned int near_cap = 0 /* != 0 (with keys2): near selection -- of a list of more than 2048 keys only the
+                                                   nearest <= near_cap (<= 2048) are selected and sorted; the whole list only if a
+                                                   walk turns out to need it (select_near, composite_tile) */,
+                      unsigned int* repair_mask = nullptr /* per tile: waves whose walk needed more than the selection (zeroed by the scan) */,
+                      unsigned int* repair_list = nullptr /* n_tiles entries: the tiles the repair launch takes again */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 // ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)

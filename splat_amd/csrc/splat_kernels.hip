@@ -717,16 +717,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     if constexpr (BUCKET) {
         // Block culling rides on the barrier the table reset needs anyway: wave 0 alone runs the bounds test (a
         // few hundred instructions that used to be issued by all four waves) while the others clear the table.
-#if SPLAT_EXP & 4
-        // every wave runs the (wave-uniform) test itself: a culled block's waves leave at once -- no table reset, no barrier
-        if (fc.cull_blocks) {
-            const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
-            if (threadIdx.x == 0) blockinfo[blockIdx.x] = reach ? 0u : 0x80000000u;
-            if (!reach) return;
-        }
-        bin_preinit(sh);
-        __syncthreads();
-#else
         if (fc.cull_blocks && threadIdx.x < 64u) {
             const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
             // (the flag is a plain store: thousands of culled blocks retire within microseconds, and that
@@ -736,7 +726,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         bin_preinit(sh);
         __syncthreads();
         if (fc.cull_blocks && sreach == 0u) return;          // whole block off this context's slab / target: nothing to read
-#endif
         STAMPF(1);
     } else if (fc.cull_blocks) {
         const bool reach = block_may_reach_slab(bounds[blockIdx.x], fc);
@@ -957,7 +946,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
                                                     FrameStatus* __restrict__ status,
                                                     unsigned long long capacity, unsigned int bucket_cap,
                                                     unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
-                                                    FrameStatus* __restrict__ host_status) {
+                                                    FrameStatus* __restrict__ host_status, unsigned int* __restrict__ repair_mask) {
     constexpr int NCLS = 64;
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int hist[NCLS];
@@ -995,6 +984,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
             cursor[k] = excl;
             const unsigned int len = bucket_cap ? min(c, bucket_cap) : c;
             lens[k] = len;
+            if (repair_mask) repair_mask[k] = 0u;
             atomicAdd(&hist[cls_of(len)], 1u);
         }
         carry += total;
@@ -1021,7 +1011,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         const unsigned int ge16384 = start[cls_of(16384u)] + hist[cls_of(16384u)];
         status->n_ge8192 = ge8192; status->n_ge2048 = ge2048; status->n_ge16384 = ge16384;
         if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid || ge16384 > grid_long)) status->overflow = 3u;
-        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_iter_scan = 0; status->n_iter_blend = 0;
+        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
         if (host_status) *host_status = *status;      // (n_visible / n_singular: K1's atomics, complete before this kernel)
     }
     __syncthreads();   // lens[] written above by this workgroup are visible to it
@@ -1139,7 +1129,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
                                                            unsigned int cls_in_lds, FrameStatus* __restrict__ host_status,
                                                            unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
-                                                           unsigned int key_entries, float spare_max) {
+                                                           unsigned int key_entries, float spare_max, unsigned int* __restrict__ repair_mask) {
     constexpr int NCLS = 64;
     // Workgroup 1 of the launch (when there is one) builds the regions of the next frame on this binning stream from
     // the same cursors, beside the scan: no launch of its own, nothing added to the chain K1 -> scan -> sort.
@@ -1188,6 +1178,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                 c[u] = raw;
                 lens[k] = len;
                 offsets[k] = l0[u];
+                if (repair_mask) repair_mask[k] = 0u;          // near selection: no wave of this tile has asked for the whole list yet
                 sum += c[u]; mx = max(mx, c[u]);
                 const unsigned int cls = cls_of(len);
                 if (cls_in_lds) cls_lds[k] = (unsigned char)cls;
@@ -1229,7 +1220,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         status->overflow = (mx & 0x80000000u) ? 2u : ((ge[1] > grid_big || ge[2] > grid_mid || ge[0] > grid_long) ? 3u : 0u);
         // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
         status->n_visible = 0; status->n_singular = 0;
-        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_iter_scan = 0; status->n_iter_blend = 0;
+        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
         status->pad_ = 0; status->n_blocks_culled = 0;
         // ... and delivers it to the host: everything an asynchronous frame reports is decided here (layout_total, the
         // last word, belongs to the workgroup that builds the layout: both copies are its to write)
@@ -1555,11 +1546,14 @@ constexpr unsigned int sort_lds_bytes() { return CAP * 8 + ((NT / 64) * 256 + 25
 // idx_out != nullptr (the compositor's own short list): the sorted ORDER -- the keys' index halves -- is left in LDS
 // at idx_out (which may overlap the workspace) for the workgroup that is about to walk the list; the keys go back
 // to global memory only if write_back is set (statistics / debug frames read the lists from there).
+// gin == nullptr: the keys are in LDS already (s[0 .. n), complete behind a barrier the CALLER has passed -- the nearest
+// keys of a long list, select_near); pre_mn / pre_mx then bound their depth halves (any bounds do: they only size the digits).
 template <int NT, int CAP>
 __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, const unsigned long long* gin, unsigned long long* gout,
                                                  unsigned int n, unsigned int radix_min, FrameStatus* __restrict__ status,
                                                  const unsigned int* __restrict__ orig,
-                                                 unsigned int* idx_out = nullptr, bool write_back = true, unsigned int reserve = 0u) {
+                                                 unsigned int* idx_out = nullptr, bool write_back = true, unsigned int reserve = 0u,
+                                                 unsigned int pre_mn = 0xffffffffu, unsigned int pre_mx = 0u) {
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
     // histograms live right behind the keys in use: a list that leaves room gets 512 bins
     constexpr unsigned int NW = NT / 64;
@@ -1568,7 +1562,8 @@ __device__ __forceinline__ void sort_list_in_lds(unsigned char* smem, const unsi
     unsigned int* hist = reinterpret_cast<unsigned int*>(smem + keys_bytes);
     unsigned int* tot = hist + (NW << lb);
     unsigned int* dbase = tot;             // in place (see sort_lds_bytes)
-    unsigned int mn = 0xffffffffu, mx = 0u;
+    unsigned int mn = pre_mn, mx = pre_mx;
+    if (gin != nullptr)
     for (unsigned int t0 = threadIdx.x; t0 < n; t0 += 8u * NT) {     // eight loads in flight per thread
         unsigned long long k[8];
 #pragma unroll
@@ -1728,6 +1723,112 @@ __device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem,
     if (tid == 0u) pstart[P] = n;
     __syncthreads();                                   // h is complete (this workgroup's own global writes) and bins / cur are free
     return P;
+}
+
+// The NEAREST keys of a long list, selected without sorting it.  The compositor's exact walk starts where the
+// transmittance of every pixel of a block has fallen below ~1e-6 and needs nothing behind that point (the skipped layers
+// are bracketed, composite_tile): of the lists of more than 2048 keys -- two thirds of all keys on C3, five sixths on C5 --
+// the deepest of a tile's four walks reaches 2-9 % (SPLAT_DBG_STARTS, tools/starts_probe.py).  Sorting the other 90 % is
+// the single largest piece of wasted work in the frame.  So, by the tile's own workgroup (NT = 256 threads, its
+// sort_lds_bytes<NT, 2048>() of LDS), in three streaming passes over the n keys at g (global, unordered):
+//   1  the depth range of the list (min / max of the keys' depth halves)
+//   2  a histogram of (depth - min) >> shift over 1024 bins (LDS atomics)
+//   3  the largest SUFFIX of bins -- ascending depth key = far first, so the suffix is the near end -- that holds at most
+//      `cap` <= 2048 keys; those keys are compacted into LDS (smem as the key array s[0 .. m)), in arrival order
+// and returns m (with the min / max of the selected depth halves for the digit plan of the sort that follows).  A bin
+// holds every key of its depths, so the selection is EXACTLY the last m entries of the fully sorted list, ties in depth
+// included.  Returns 0 if the nearest bin alone holds more than `cap` keys (hundreds of Gaussians at one depth): the
+// caller sorts the whole list instead.  Ends with a barrier: s[0 .. m) is complete.
+template <int NT>
+__device__ __forceinline__ unsigned int select_near(unsigned char* smem, const unsigned long long* __restrict__ g, unsigned int n,
+                                                    unsigned int cap, unsigned int* sel_mn, unsigned int* sel_mx) {
+    constexpr unsigned int NB = 1024u;
+    static_assert(NT == 256, "four bins per thread");
+    static_assert(2048u * 8u + NB * 4u + 64u <= sort_lds_bytes<NT, 2048>(), "keys + bins + a few words fit the workspace");
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
+    unsigned int* bins = reinterpret_cast<unsigned int*>(smem + 2048u * 8u);
+    unsigned int* misc = bins + NB;                 // 0 min, 1 max, 2 first selected bin, 3 selected keys, 4 compaction cursor, 8.. wave sums
+    const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (unsigned int q = tid; q < NB; q += NT) bins[q] = 0u;
+    if (tid == 0u) { misc[0] = 0xffffffffu; misc[1] = 0u; misc[2] = NB; misc[3] = 0u; misc[4] = 0u; }
+    unsigned int mn = 0xffffffffu, mx = 0u;
+    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {              // eight loads in flight per thread
+        unsigned int d[8];
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; d[u] = (t < n) ? (unsigned int)(g[t] >> 32) : 0u; }
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) if (t0 + u * NT < n) { mn = min(mn, d[u]); mx = max(mx, d[u]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (unsigned int)__shfl_xor((int)mn, o));
+        mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+    }
+    __syncthreads();
+    if (lane == 0u) { atomicMin(&misc[0], mn); atomicMax(&misc[1], mx); }
+    __syncthreads();
+    const unsigned int dmin = misc[0], range = misc[1] - dmin;
+    const unsigned int sh = range >= NB ? (unsigned int)(32 - __clz((int)range)) - 10u : 0u;      // (range >> sh) < 1024
+    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {
+        unsigned int d[8];
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; d[u] = (t < n) ? (unsigned int)(g[t] >> 32) : 0u; }
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) if (t0 + u * NT < n) atomicAdd(&bins[(d[u] - dmin) >> sh], 1u);
+    }
+    __syncthreads();
+    {   // suffix sums, four consecutive bins per thread: thread t owns bins 4t .. 4t+3; S(b) = keys in bins >= b
+        unsigned int c[4], sum = 0u;
+#pragma unroll
+        for (unsigned int j = 0; j < 4; ++j) { c[j] = bins[4u * tid + j]; sum += c[j]; }
+        unsigned int v = sum;                       // inclusive scan over the wave's lanes, then the waves behind this one
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int u = (unsigned int)__shfl_up((int)v, o);
+            if ((int)lane >= o) v += u;
+        }
+        if (lane == 63u) misc[8u + wave] = v;
+        __syncthreads();
+        unsigned int total = 0u, before = v - sum;  // keys in the bins in front of this thread's
+        for (unsigned int w = 0; w < NT / 64u; ++w) { const unsigned int x = misc[8u + w]; total += x; if (w < wave) before += x; }
+        // S(4t + j) = total - before - c[0] - .. - c[j-1]; the first selected bin is the smallest b with S(b) <= cap
+        unsigned int S = total - before;
+#pragma unroll
+        for (unsigned int j = 0; j < 4; ++j) {
+            // S(b) <= cap and (b == 0 or S(b - 1) > cap): S(b - 1) = S(b) + count(b - 1)
+            const unsigned int b = 4u * tid + j;
+            const unsigned int cnt_prev = (j == 0u) ? ((tid == 0u) ? 0u : bins[b - 1u]) : c[j - 1u];
+            if (S <= cap && (b == 0u || S + cnt_prev > cap)) { misc[2] = b; misc[3] = S; }
+            S -= c[j];
+        }
+    }
+    __syncthreads();
+    const unsigned int first = misc[2], m = misc[3];
+    if (first >= NB || m == 0u) { __syncthreads(); return 0u; }          // the nearest bin alone overflows the cap
+    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {
+        unsigned long long k[8];
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; k[u] = (t < n) ? g[t] : 0ull; }
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) {
+            const unsigned int d = (unsigned int)(k[u] >> 32);
+            const bool take = (t0 + u * NT < n) && (((d - dmin) >> sh) >= first);
+            const unsigned long long tm = __builtin_amdgcn_ballot_w64(take);
+            if (tm) {                               // one cursor atomic per wave and round
+                unsigned int base = 0u;
+                if (lane == 0u) base = atomicAdd(&misc[4], (unsigned int)__builtin_popcountll(tm));
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if (take)
+                    s[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(tm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)tm, 0u))] = k[u];
+            }
+        }
+    }
+    // (the bounds only size the sort's digits: the selection's lower bin edge and the list's maximum do as well as the exact
+    // extremes, and every thread knows them)
+    *sel_mn = dmin + (first << sh);
+    *sel_mx = misc[1];
+    __syncthreads();
+    return m;
 }
 
 // The whole of it, for the compositor's workgroup.
@@ -1992,7 +2093,13 @@ __device__ __forceinline__ f2 blend_channel2(f2 k, float ia, f2 ac) {
 // One tile (slot `item` of the longest-first tile order) by one workgroup; `smem` = sort_lds_bytes<256, 2048>() bytes.
 // PAIR: the exact walk takes two records per step with packed math (see the note above WaveLds).
 // LONG: lists of more than 2048 keys are sorted by this workgroup as well (sort_long_list), no sort launch needed.
-template <bool PAIR, bool LIBM, bool LONG>
+// LONGM: who orders a list of more than 2048 keys when no sort launch did --
+//   0  nobody here (the sort launches ran)
+//   1  this workgroup, in full (sort_long_list)
+//   2  NEAR SELECTION: this workgroup selects and sorts the nearest <= near_cap keys only; a wave whose walk needs more
+//      reports its tile for the repair launch (composite_repair_kernel: flavour 1 over the reported tiles, their
+//      reported waves only)
+template <bool PAIR, bool LIBM, int LONGM>
 __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsigned long long* exptab, const unsigned int item, const FrameConst& fc,
                                                const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
                                                const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
@@ -2000,7 +2107,9 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                                                FrameStatus* __restrict__ status, unsigned int fused_sort_max,
                                                unsigned int radix_min, uint2* __restrict__ iters, unsigned int keep_keys,
                                                const unsigned int* __restrict__ orig, const unsigned int clear_first,
-                                               unsigned long long* __restrict__ keys2) {
+                                               unsigned long long* __restrict__ keys2, const unsigned int near_cap,
+                                               unsigned int* __restrict__ repair_mask, unsigned int* __restrict__ repair_list,
+                                               const unsigned int wave_mask) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -2030,20 +2139,46 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // (see `stage`), so that the exact walk over the same batches does not test them again.
     static_assert(sizeof(WaveLds) * 4 + 2048 * 4 + 4 * 32 * 8 <= sort_lds_bytes<256, 2048>(), "the batch masks fit too");
     unsigned long long* const wmask = reinterpret_cast<unsigned long long*>(smem + sizeof(WaveLds) * 4 + 2048 * 4) + (tid >> 6) * 32u;
-    const bool own_order = end - beg >= 2u && end - beg <= fused_sort_max;
-    // A list of more than 2048 keys, when no sort launch ran in front of this kernel (keys2 != nullptr says so), is
-    // ordered here too: partitioned by depth into parts of fewer than 1792 keys through the second key buffer
-    // (partition_long_list), every part sorted through LDS back into the bucket, and then read from memory like a
-    // list a sort launch had left.
-    if constexpr (LONG) {
-        if (end - beg > 2048u) {
-            sort_long_list(smem, keys + beg, keys2 + beg, end - beg, radix_min, status, orig);
-            __syncthreads();
+    bool own_order = end - beg >= 2u && end - beg <= fused_sort_max;
+    // A list of more than 2048 keys, when no sort launch ran in front of this kernel, is this workgroup's to order.
+    // LONGM == 1: in full -- partitioned by depth into parts of fewer than 1792 keys through the second key buffer
+    // (partition_long_list), every part sorted through LDS back into the region, then read from memory like a list a sort
+    // launch had left.
+    // LONGM == 2, NEAR SELECTION: only its nearest <= near_cap keys are picked out by depth (select_near: three streaming
+    // passes, no sort) and sorted through LDS like a short list; the walks then see the list [lb, end) with `has_far` set
+    // -- farther keys exist in front of `lb`, NOT in order.  The early-out makes that enough: a walk that starts inside
+    // the selection and closes its bracket there is exact as always.  A wave whose walk would have to start at or before
+    // `lb` (its pixels did not saturate within the selection, the bracket did not close, a pixel met no record) writes no
+    // pixel and reports the tile instead: the repair launch behind this one sorts that list in full and walks those
+    // waves again.  On C3 / C5 the selection serves every tile of the bench pose (tools/starts_probe.py): 93-98 % of the
+    // long lists' keys are never sorted.
+    unsigned int lb = beg;
+    bool has_far = false, no_selection = false;
+    {
+        const unsigned long long* gin = keys + beg;
+        unsigned int n_sort = end - beg, smn = 0xffffffffu, smx = 0u;
+        if constexpr (LONGM == 1) {
+            if (end - beg > 2048u) {
+                sort_long_list(smem, keys + beg, keys2 + beg, end - beg, radix_min, status, orig);
+                __syncthreads();
+            }
         }
-    }
-    if (own_order) {
-        sort_list_in_lds<256, 2048>(smem, keys + beg, keys + beg, end - beg, radix_min, status, orig, lds_idx, keep_keys != 0u);
-        __syncthreads();          // the order is in LDS, the rest of the workspace is free for the batches
+        if constexpr (LONGM == 2) {
+            if (end - beg > 2048u) {
+                const unsigned int m = select_near<256>(smem, keys + beg, end - beg, near_cap, &smn, &smx);
+                if (m != 0u) {
+                    gin = nullptr; n_sort = m; own_order = true;
+                    has_far = true; lb = end - m;
+                    if (tid == 0u) atomicAdd(&status->n_near_tiles, 1u);
+                } else {
+                    no_selection = true;            // (hundreds of keys at the nearest depth: the repair launch takes the tile)
+                }
+            }
+        }
+        if (own_order) {
+            sort_list_in_lds<256, 2048>(smem, gin, keys + beg, n_sort, radix_min, status, orig, lds_idx, (keep_keys & 1u) != 0u && gin != nullptr, 0u, smn, smx);
+            __syncthreads();          // the order is in LDS, the rest of the workspace is free for the batches
+        }
     }
     const unsigned int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     // The longest lists are the critical path of the launch: let their waves win VALU arbitration
@@ -2066,6 +2201,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     const int x1w = min(bx0 + 7, fc.W - 1);
     const int y0w = by0, y1w = min(y0w + 7, min(fc.H, fc.row_px1) - 1);
     if (bx0 > x1w || y0w > y1w) return;           // block entirely off the target: nothing to do (no barriers below)
+    if (((wave_mask >> wave) & 1u) == 0u) return; // (repair launch: this wave's pixels are final already)
     const float xlo = (float)bx0 + off, xhi = (float)x1w + off;
     const float ylo = (float)y0w + off, yhi = (float)y1w + off;
     const float sx = (float)px + off, sy = (float)py + off;
@@ -2080,7 +2216,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     //        issues one instruction per ~4 cycles whatever its type, so scalar bookkeeping per record
     //        is as expensive as vector work on the launch's critical path.
     auto fetch = [&](unsigned int base, unsigned int cnt, Rec& r) {
-        if (lane < cnt) r = recs[own_order ? lds_idx[base - beg + lane] : (unsigned int)keys[base + lane]];
+        if (lane < cnt) r = recs[own_order ? lds_idx[base - lb + lane] : (unsigned int)keys[base + lane]];
     };
     // Can ANY sample of the block be accepted?  Upper bound of alpha over the block: the minimum of
     // the conic's quadratic form q = a dx^2 + 2 b dx dy + c dy^2 over the block's sample rectangle
@@ -2147,11 +2283,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 L.a[slot] = make_float4(r.a.x, r.a.y, __uint_as_float(base + lane), 0.0f);
                 L.b[slot] = make_float4(-0.5f * L2E * r.b.x, -L2E * r.b.y, -0.5f * L2E * r.b.z, __log2f(r.b.w));
             } else {
-#if SPLAT_EXP & 2
-                L.a[slot] = r.a; L.b[slot] = make_float4(-0.5f * r.b.x, r.b.y, -0.5f * r.b.z, r.b.w);
-#else
                 L.a[slot] = r.a; L.b[slot] = r.b;
-#endif
                 L.c[slot] = make_float4(r.c.x, r.c.y, r.c.z, __uint_as_float(base + lane));   // .w: list position
             }
         }
@@ -2182,6 +2314,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         return accept ? alpha : 0.0f;
     };
 
+    bool need_far = no_selection;                // near selection: this wave's walk needs keys in front of the selection
     unsigned int itA = 0, itB = 0;               // (wave, record) iterations per phase, for the stats
     // ---------------- alpha pass: the alpha byte ----------------
     // blend() stores the NEW fragment's alpha (src/pipelines.rs:162-167), rejected fragments store 0,
@@ -2189,15 +2322,15 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // cannot contribute colour and are dropped from the walks below.  Nearest first, until every
     // pixel of the block has met one.
     float alast = -1.0f;                         // < 0: no record covers the pixel, the byte keeps its old value
-    {
+    if (!need_far) {
         bool found = !inside;
         Rec r;
-        unsigned int cntN = min(64u, end - beg), bsN = end - cntN;
+        unsigned int cntN = min(64u, end - lb), bsN = end - cntN;
         fetch(bsN, cntN, r);
         while (true) {
             const unsigned int bs = bsN, cnt = cntN;
             const unsigned int k = stage(r, cnt, bs, false);
-            if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }
+            if (bs > lb) { cntN = min(64u, bs - lb); bsN = bs - cntN; fetch(bsN, cntN, r); }
             // the walk itself only tests coverage (six VALU per record) and remembers which record of
             // the batch each pixel met first; the exact alpha is evaluated once per batch, every lane
             // on its own record
@@ -2216,26 +2349,29 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 const float alpha = frag_alpha(a, b, expv, cov);      // exact, 0 when rejected
                 alast = (jsel != 0xffffffffu) ? alpha : alast;
             }
-            if (__builtin_amdgcn_ballot_w64(!found) == 0ull || bs == beg) break;
+            if (__builtin_amdgcn_ballot_w64(!found) == 0ull || bs == lb) break;
         }
+        // (near selection: a pixel that met no record among the selected keys may meet one among the farther ones)
+        if (has_far && __builtin_amdgcn_ballot_w64(!found) != 0ull) need_far = true;
     }
     // ---------------- phase A: where must the exact walk start? ----------------
-    unsigned int ws = beg;                       // this wave's start position (uniform)
+    unsigned int ws = lb;                        // this wave's start position (uniform)
     unsigned int nA = 0;                         // batches (from the end of the list) whose staging verdicts the scan saved
-    if (fc.early_eps > 0.0f && end - beg >= (unsigned int)fc.early_min) {
+    if (fc.early_eps > 0.0f && (has_far || end - beg >= (unsigned int)fc.early_min) && !need_far) {
         float T = 1.0f;
-        unsigned int sp = inside ? beg : 0xffffffffu;    // per lane: first layer the lane needs
+        unsigned int sp = inside ? lb : 0xffffffffu;     // per lane: first layer the lane needs
         bool done = !inside;
         // a strip that has not saturated after half of its list will not save enough to pay for the scan
-        const unsigned int giveup = end - (unsigned int)(((unsigned long long)(end - beg) * (unsigned int)fc.early_scan8) >> 3);
+        // (a selection is scanned to its end: what lies behind it costs a sort of the whole list)
+        const unsigned int giveup = has_far ? lb : end - (unsigned int)(((unsigned long long)(end - beg) * (unsigned int)fc.early_scan8) >> 3);
         Rec r;
-        unsigned int cntN = min(64u, end - beg), bsN = end - cntN;
+        unsigned int cntN = min(64u, end - lb), bsN = end - cntN;
         fetch(bsN, cntN, r);
         while (true) {
             const unsigned int bs = bsN, cnt = cntN;
             const unsigned int k = stage(r, cnt, bs, true, true, false, -1, 0u, nA < 32u ? (int)nA : -1);
             nA += nA < 32u ? 1u : 0u;
-            if (bs > beg) { cntN = min(64u, bs - beg); bsN = bs - cntN; fetch(bsN, cntN, r); }   // prefetch farther batch
+            if (bs > lb) { cntN = min(64u, bs - lb); bsN = bs - cntN; fetch(bsN, cntN, r); }   // prefetch farther batch
             for (unsigned int j = k; j-- > 0;) {                  // nearest first
                 const float4 a = L.a[j], b = L.b[j];
                 // an estimate is enough here (too shallow a start costs a retry, never exactness):
@@ -2250,9 +2386,9 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 done = done | now;
             }
             itA += k;
-            if (__builtin_amdgcn_ballot_w64(!done) == 0ull || bs == beg || bs <= giveup) break;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull || bs == lb || bs <= giveup) break;
         }
-        unsigned int need = done ? sp : beg;              // lanes that never saturated need the whole list
+        unsigned int need = done ? sp : lb;               // lanes that never saturated need the whole list
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) need = min(need, (unsigned int)__shfl_xor((int)need, o));
         ws = (unsigned int)__builtin_amdgcn_readfirstlane((int)need);
@@ -2275,19 +2411,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     auto shade = [&](auto BRt, const float4& a, const float4& b, const float4& c) {
         constexpr bool BR = decltype(BRt)::value;
         bool cov;
-#if SPLAT_EXP & 2
-        float alpha;
-        {
-            float dx = sxm - a.x, dy = a.y - sym;
-            cov = (fabsf(dx) <= a.z) & (fabsf(dy) <= a.w);
-            float power = (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-            float al = fminf(0.99f, b.w * expv(power));
-            bool accept = cov & !(power > 0.0f) & !(al < 1.0f / 255.0f);
-            alpha = accept ? al : 0.0f;
-        }
-#else
         const float alpha = frag_alpha(a, b, expv, cov);
-#endif
         const float ia = 1.0f - alpha;
         const float ar = alpha * c.x, ag = alpha * c.y, ab = alpha * c.z;
         R = blend_channel(R, ia, ar);
@@ -2347,7 +2471,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         while (cntN) {
             const unsigned int bs = bsN, cnt = cntN;
             const bool reuse = kb < nA;
-            const unsigned int abase = (end - beg >= ((kb + 1u) << 6)) ? end - ((kb + 1u) << 6) : beg;   // where the scan's batch began
+            const unsigned int abase = (end - lb >= ((kb + 1u) << 6)) ? end - ((kb + 1u) << 6) : lb;   // where the scan's batch began
             const unsigned int k = stage(r, cnt, bs, true, false, PAIR, reuse ? (int)kb : -1, bs - abase);
             bsN = bs + cnt; cntN = min(64u, end - bsN); kb -= cntN ? 1u : 0u;
             if (cntN) fetch(bsN, cntN, r);                  // prefetch the next (nearer) batch
@@ -2356,11 +2480,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 for (unsigned int j = 0; j < (k + 1u) / 2u; ++j)
                     shade_pair(BRt, P4[6 * j], P4[6 * j + 1], P4[6 * j + 2], P4[6 * j + 3], P4[6 * j + 4], P4[6 * j + 5]);
             } else {
-#if SPLAT_EXP & 1
-                for (unsigned int j = 0; j < k; ++j) { const float4 cc = L.c[j]; asm volatile("" :: "v"(cc.w)); shade(BRt, L.a[j], L.b[j], cc); }
-#else
                 for (unsigned int j = 0; j < k; ++j) shade(BRt, L.a[j], L.b[j], L.c[j]);
-#endif
             }
             itB += k;
             if (BR && __builtin_amdgcn_ballot_w64(inside & ((R2 - R > cw) | (G2 - G > cw) | (B2 - B > cw))) == 0ull) return bsN;
@@ -2368,10 +2488,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         return end;
     };
     unsigned int start = ws;
-    while (true) {
-        if (start <= beg) {                           // nothing skipped: exact from the real pixel
+    while (!need_far) {
+        if (start <= lb) {                            // nothing skipped: exact from the real pixel ...
+            if (has_far) { need_far = true; break; }  // ... unless unsorted keys lie in front of the selection: the whole list, then
             R = (float)((old >> 16) & 0xffu); G = (float)((old >> 8) & 0xffu); B = (float)(old & 0xffu);
-            run(std::false_type{}, beg);
+            run(std::false_type{}, lb);
             break;
         }
         // skipped layers [beg, start): bracket them
@@ -2388,7 +2509,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         // (geometric, so a long list is not redone in full for one stubborn LSB).
         if (lane == 0) atomicAdd(&status->n_fallback, 1ull);
         const unsigned int depth = end - start;
-        start = (start - beg > depth) ? start - depth : beg;
+        start = (start - lb > depth) ? start - depth : lb;
     }
     const float A = (alast < 0.0f) ? (float)(old >> 24) : truncf(alast * 255.0f);   // alpha in {0} U [1/255, .99]
     // statistics frames only (iters != nullptr): this wave's (scan, blend) iteration counts as one plain store
@@ -2396,6 +2517,13 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // (keep_keys bit 1, SPLAT_DBG_STARTS: the list's length and how many of its nearest keys this wave's walk needed instead)
     if (iters != nullptr && lane == 0)
         iters[item * 4u + wave] = (keep_keys & 2u) ? make_uint2(end - beg, end - max(start, beg)) : make_uint2(itA, itB);
+    if constexpr (LONGM == 2) {
+        if (need_far) {
+            // the first wave of a tile to ask puts the tile on the repair list; the mask says which waves to walk again
+            if (lane == 0u && atomicOr(&repair_mask[tile], 1u << wave) == 0u) repair_list[atomicAdd(&status->n_near_fallback, 1u)] = item;
+            return;
+        }
+    }
     if (inside)
         argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
 }
@@ -2403,11 +2531,14 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 // The launch: one workgroup per tile, slot blockIdx.x of the longest-first order.  (A persistent grid pulling
 // slots from a ticket counter, and the order composited as consecutive chunk launches, were both measured as
 // ways to cap the compositor's residency beside the next frame's K1: both slower -- DESIGN.md section 3.)
-// LONG = true: seven waves per SIMD = seven workgroups per CU, which is also what the 21.5 KB of LDS allow: at most 72
+// LONGM == 1: seven waves per SIMD = seven workgroups per CU, which is also what the 21.5 KB of LDS allow: at most 72
 // VGPRs.  The walks need 64; the long-list sort in front of them would take 88, and under this bound spills nine
 // registers around its loop over the parts instead -- outside every hot loop (checked in the ISA).
-template <bool PAIR, bool LIBM, bool LONG>
-__global__ __launch_bounds__(256, LONG ? 7 : SPLAT_COMP_WAVES) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+// (At most 96 SGPRs: with 97-112 a CU admits six 256-thread workgroups instead of seven -- MI355X_MICROARCH.md,
+// "Residency" -- and the compositor hides its LDS and dependency latency with residency.  The near-selection flavour
+// carries a few more uniform values than the others and would take 106.)
+template <bool PAIR, bool LIBM, int LONGM>
+__global__ __launch_bounds__(256, LONGM == 1 ? 7 : SPLAT_COMP_WAVES) __attribute__((amdgpu_num_sgpr(96))) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
                                                               const unsigned int* __restrict__ order,
                                                               const unsigned int* __restrict__ lens,
                                                               unsigned long long* __restrict__ keys,
@@ -2415,7 +2546,9 @@ __global__ __launch_bounds__(256, LONG ? 7 : SPLAT_COMP_WAVES) void composite_ex
                                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
                                                               unsigned int radix_min, uint2* __restrict__ iters,
                                                               unsigned int keep_keys, const unsigned int* __restrict__ orig,
-                                                              unsigned int clear_first, unsigned long long* __restrict__ keys2) {
+                                                              unsigned int clear_first, unsigned long long* __restrict__ keys2,
+                                                              unsigned int near_cap, unsigned int* __restrict__ repair_mask,
+                                                              unsigned int* __restrict__ repair_list) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
@@ -2424,7 +2557,40 @@ __global__ __launch_bounds__(256, LONG ? 7 : SPLAT_COMP_WAVES) void composite_ex
         if (threadIdx.x < 32) exptab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
         __syncthreads();
     }
-    composite_tile<PAIR, LIBM, LONG>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig, clear_first, keys2);
+    composite_tile<PAIR, LIBM, LONGM>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig, clear_first, keys2,
+                                      near_cap, repair_mask, repair_list, 0xfu);
+}
+
+// The repair launch behind a near-selection frame: the tiles whose selected nearest keys did not do for every wave
+// (status->n_near_fallback entries of repair_list; normally none) are taken again by a few workgroups -- the whole list
+// sorted (flavour 1), the reported waves walked from memory.  The other waves' pixels are final and stay untouched.
+template <bool PAIR, bool LIBM>
+__global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
+                                                               const unsigned int* __restrict__ order,
+                                                               const unsigned int* __restrict__ lens,
+                                                               unsigned long long* __restrict__ keys,
+                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
+                                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
+                                                               unsigned int radix_min, const unsigned int* __restrict__ orig,
+                                                               unsigned int clear_first, unsigned long long* __restrict__ keys2,
+                                                               const unsigned int* __restrict__ repair_mask,
+                                                               const unsigned int* __restrict__ repair_list) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
+    __shared__ unsigned long long exptab[LIBM ? 32 : 1];
+    if (status->overflow) return;
+    const unsigned int count = status->n_near_fallback;
+    if (blockIdx.x >= count) return;
+    if constexpr (LIBM) {
+        if (threadIdx.x < 32) exptab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
+        __syncthreads();
+    }
+    for (unsigned int i = blockIdx.x; i < count; i += gridDim.x) {
+        const unsigned int item = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_list[i]);
+        const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_mask[order[item]]);
+        composite_tile<PAIR, LIBM, 1>(smem, exptab, item, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, nullptr, 0u, orig, clear_first, keys2,
+                                      0u, nullptr, nullptr, mask);
+        __syncthreads();          // the workspace is the next tile's: every wave has finished its walk
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2476,7 +2642,8 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
-                 FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts, float spare_max) {
+                 FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts, float spare_max,
+                 unsigned int* repair_mask) {
     if (bucket_cap && layout)
     {
         const unsigned int nwg = (next_layout && next_counts) ? 2u : 1u;
@@ -2487,17 +2654,17 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         const unsigned int dyn = in_lds ? cls_bytes : 0u;
         if (nt == 256)
             hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(nwg), dim3(256), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask);
         else if (nt == 512)
             hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(nwg), dim3(512), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask);
         else
             hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(nwg), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
-                           bucket_cap, grid_big, grid_mid, grid_long, host_status);
+                           bucket_cap, grid_big, grid_mid, grid_long, host_status, repair_mask);
 }
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
                    unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max) {
@@ -2535,24 +2702,39 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
-                      bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2) {
+                      bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2, unsigned int near_cap,
+                      unsigned int* repair_mask, unsigned int* repair_list) {
     if (!n_tiles) return;
     if (g_knobs->dbg_ntiles) n_tiles = std::min(n_tiles, g_knobs->dbg_ntiles);   // debug: composite only the N longest tiles
     // SPLAT_COMP_LDS_PAD: extra dynamic LDS per workgroup, i.e. an occupancy cap (12 KB are in use:
     // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
     const unsigned int pad = g_knobs->comp_lds_pad;
+    const bool near = near_cap != 0u && keys2 != nullptr && repair_mask != nullptr && repair_list != nullptr;
+    const unsigned int flags = (keep_keys ? 1u : 0u) | (g_knobs->dbg_starts ? 2u : 0u);
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                           sort_radix_min(), iters, (keep_keys ? 1u : 0u) | (g_knobs->dbg_starts ? 2u : 0u), orig, clear_first ? 1u : 0u, keys2);
+                           sort_radix_min(), iters, flags, orig, clear_first ? 1u : 0u, keys2, std::min(near_cap, 2048u), repair_mask, repair_list);
     };
-    if (keys2 != nullptr) {
-        if (libm_exp) go(composite_exact_kernel<false, true, true>);
-        else if (pair_walk) go(composite_exact_kernel<true, false, true>);
-        else go(composite_exact_kernel<false, false, true>);
+    if (near) {
+        if (libm_exp) go(composite_exact_kernel<false, true, 2>);
+        else if (pair_walk) go(composite_exact_kernel<true, false, 2>);
+        else go(composite_exact_kernel<false, false, 2>);
+        // the repair launch: tiles the selection did not serve (normally none: its workgroups read one word and leave)
+        auto fix = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(std::min(n_tiles, 64u)), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
+                               sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list);
+        };
+        if (libm_exp) fix(composite_repair_kernel<false, true>);
+        else if (pair_walk) fix(composite_repair_kernel<true, false>);
+        else fix(composite_repair_kernel<false, false>);
+    } else if (keys2 != nullptr) {
+        if (libm_exp) go(composite_exact_kernel<false, true, 1>);
+        else if (pair_walk) go(composite_exact_kernel<true, false, 1>);
+        else go(composite_exact_kernel<false, false, 1>);
     } else {
-        if (libm_exp) go(composite_exact_kernel<false, true, false>);
-        else if (pair_walk) go(composite_exact_kernel<true, false, false>);
-        else go(composite_exact_kernel<false, false, false>);
+        if (libm_exp) go(composite_exact_kernel<false, true, 0>);
+        else if (pair_walk) go(composite_exact_kernel<true, false, 0>);
+        else go(composite_exact_kernel<false, false, 0>);
     }
 }
 

@@ -761,6 +761,7 @@ int splat_multi_render(splat_multi* m, const splat_camera* cam, uint32_t* argb, 
             stats->n_fallback += s.n_fallback; stats->n_sort_fallback += s.n_sort_fallback;
             stats->n_iter_scan += s.n_iter_scan; stats->n_iter_blend += s.n_iter_blend;
             stats->n_blocks_culled += s.n_blocks_culled;
+            stats->n_near_tiles += s.n_near_tiles; stats->n_near_fallback += s.n_near_fallback;
             stats->ms_preprocess = std::max(stats->ms_preprocess, s.ms_preprocess); stats->ms_scan = std::max(stats->ms_scan, s.ms_scan);
             stats->ms_emit = std::max(stats->ms_emit, s.ms_emit); stats->ms_sort = std::max(stats->ms_sort, s.ms_sort);
             stats->ms_composite = std::max(stats->ms_composite, s.ms_composite); stats->ms_total = std::max(stats->ms_total, s.ms_total);

@@ -693,6 +693,78 @@ def test_bench_launches_its_own_ranks():
         assert drops == 0
 
 
+def test_near_selection_renders_the_fully_sorted_frame():
+    """Near selection (the default): of a tile list of more than 2048 keys only the nearest <= SPLAT_OPT_NEAR_SELECT_KEYS are
+    selected by depth and sorted; a wave whose walk needs more reports the tile and the repair launch sorts that list in
+    full.  Either way the frame must be the one the full sort gives, byte for byte -- with a generous selection (no tile
+    repaired), with one so small that most long tiles are repaired, blending onto a non-zero image (a repaired wave must
+    not have touched its pixels), in every mode, both walk flavours, and asynchronously."""
+    from splat_amd import _lib as L
+    g = splat_amd.synthetic_scene(120000, 77)
+    g.positions[:, :3] *= 0.22                                 # dense: thousands of keys per tile
+    g.opacities[::3] *= 0.05                                   # ... a third of them faint: deep walks
+    cams = [make_camera(184, 264, (0.0, 0.1, 3.0), yaw=0.3), make_camera(184, 264, (0.2, 0.1, 0.5), yaw=1.0, pitch=-0.2)]
+    rng = np.random.default_rng(5)
+    init = rng.integers(0, 2**32, (184, 264), dtype=np.uint64).astype(np.uint32)
+    for mode in (splat_amd.MODE_EXACT, splat_amd.MODE_LIBM_EXP, splat_amd.MODE_FAST):
+        r = splat_amd.Renderer(mode=mode)
+        try:
+            if not g.cov3d.any():
+                g.compute_cov3d(r)
+            r.upload(g)
+            for ci, cam in enumerate(cams):
+                cam_c = cam.to_c(0.01)
+                frames = {}
+                for pair in (0, 1):
+                    r.set_option(L.OPT_PAIR_WALK, pair)
+                    for near in (0, 2048, 512, 64):
+                        r.set_option(L.OPT_NEAR_SELECT_KEYS, near)
+                        img = init.copy()
+                        st = r.render(cam_c, img)
+                        clear = np.zeros((184, 264), np.uint32)
+                        r.render(cam_c, clear)
+                        frames[(pair, near)] = (img, clear, int(st.n_near_tiles), int(st.n_near_fallback), int(st.max_tile_len))
+                        if near == 0:
+                            assert st.n_near_tiles == 0 and st.n_near_fallback == 0
+                base = frames[(0, 0)]
+                assert base[4] > 2048 and base[0].any()
+                for key, f in frames.items():
+                    assert np.array_equal(f[0], base[0]), (mode, ci, key, int((f[0] != base[0]).sum()))
+                    assert np.array_equal(f[1], base[1]), (mode, ci, key)
+                assert frames[(0, 2048)][2] > 0                                   # tiles were served by their selection ...
+                assert frames[(0, 64)][3] > 0                                     # ... and a 64-key selection does send tiles to the repair launch
+                assert frames[(0, 64)][3] >= frames[(0, 2048)][3]
+            # asynchronous frames through the swap of settings (the repair launch rides behind every near frame)
+            r.set_option(L.OPT_NEAR_SELECT_KEYS, 128)
+            buf = r.host_image(184, 264)
+            for _ in range(4):
+                r.render_stream(cams[0].to_c(0.01), buf)
+                r.stream_wait(buf)
+            want = np.zeros((184, 264), np.uint32)
+            r.set_option(L.OPT_NEAR_SELECT_KEYS, 0)
+            r.render(cams[0].to_c(0.01), want)
+            assert np.array_equal(buf, want)
+        finally:
+            r.close()
+    # against the oracle as well (exact mode, default selection)
+    r = splat_amd.Renderer()
+    try:
+        r.upload(g)
+        img = np.zeros((184, 264), np.uint32)
+        st = r.render(cams[0].to_c(0.01), img)
+        ref, ost = O.render(scene_dict(g), oracle_camera(cams[0], 0.01), nthreads=8)
+        assert st.n_pairs == ost.n_tile_pairs and image_diff(img, ref)[0] <= TOL_LSB
+        # the debug getter still returns every list in full painter's order (the long lists are sorted on demand)
+        n_tiles = ((264 + 15) // 16) * ((184 + 15) // 16)
+        offs, order = r.tile_lists(n_tiles, int(st.n_pairs))
+        depth = r.records()["depth"]
+        for t in range(len(offs) - 1):
+            d = depth[order[offs[t]:offs[t + 1]]]
+            assert (np.diff(d) >= 0).all(), t
+    finally:
+        r.close()
+
+
 def test_options_set_from_code_change_the_schedule_not_the_pixels():
     """splat_set_option: what the SPLAT_* environment variables choose, set through the ABI by a host that cannot reach
     its environment.  Every setting must render the frame the defaults render, byte for byte; the

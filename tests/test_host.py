@@ -60,7 +60,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.CameraC) == 4 * (16 + 16 + 2 + 3 + 3 + 1 + 1)
     assert C.sizeof(_lib.Record) == 64
     assert C.sizeof(_lib.Config) == 40
-    assert C.sizeof(_lib.Stats) == 6 * 8 + 6 * 4 + 6 * 8
+    assert C.sizeof(_lib.Stats) == 6 * 8 + 6 * 4 + 8 * 8
 
 
 def test_create_fails_loudly_without_gpu():
