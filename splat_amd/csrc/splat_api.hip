@@ -53,7 +53,8 @@ struct Slot {                  // everything one frame writes before the image
     unsigned int* cursor = nullptr;
     unsigned int* order = nullptr;
     unsigned int* lens = nullptr;           // list length per tile (the list starts at offsets[tile])
-    unsigned int* repair_mask = nullptr;    // near selection: per tile, the waves whose walk needed more than the selected keys
+    unsigned int* near_m = nullptr;         // near selection: per tile, how many of its list's nearest keys launch_select put in order
+    unsigned int* repair_mask = nullptr;    // ... the waves whose walk needed more than that
     unsigned int* repair_list = nullptr;    // ... and the tiles (slots of `order`) the repair launch takes again
     unsigned long long* keys = nullptr;
     unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
@@ -175,6 +176,7 @@ struct splat_ctx {
     // tile's compositor workgroup selects the nearest <= near_cap keys by depth and sorts those -- the exact early-out never
     // looks farther on all but a few tiles, which then sort their whole list after all.  No sort launches in such frames.
     unsigned int near_cap = 2048;
+    unsigned int* need_hint = nullptr;     // 4 x m_alloc words: per tile and wave, the nearest keys its walk needed in the most recent frame
     bool last_near = false;                // the most recent frame ran with near selection: its long lists are unordered in memory
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
     int pipeline = 6;                      // frames in flight on the device (SPLAT_PIPELINE = 1..6, see enqueue_frame)
@@ -409,10 +411,14 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     dfree(c->zero_layout);
     HIP_TRY(c, dmalloc(c, &c->zero_layout, sizeof(unsigned int) * (size_t)(m + 1)));
     HIP_TRY(c, hipMemset(c->zero_layout, 0, sizeof(unsigned int) * (size_t)(m + 1)));
+    dfree(c->need_hint);
+    HIP_TRY(c, dmalloc(c, &c->need_hint, sizeof(unsigned int) * 4u * (size_t)(m + 1)));
+    HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
-        dfree(s.repair_mask); dfree(s.repair_list);
+        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m);
         s.layout_valid = false; s.flip = 0;
+        HIP_TRY(c, dmalloc(c, &s.near_m, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.repair_mask, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.repair_list, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.counts_b, sizeof(unsigned int) * (size_t)(m + 1)));
@@ -608,7 +614,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, d_st);
     HIP_TRY(c, mark(3, ss));
     const bool comp_sorts = comp_sorts_frame;
-    if (!comp_sorts)
+    if (near_cap)       // near selection: the nearest keys of the long lists instead of the sort launches
+        launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m);
+    else if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
     // Which lane composites?  Frames to one image stay on one lane (stream order is their write-after-write / in-out
@@ -670,8 +678,8 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const bool pair_walk = c->pair_mode >= 0 ? c->pair_mode != 0
                                              : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
     launch_composite(cs, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
-                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr, near_cap,
-                     s.repair_mask, s.repair_list);
+                     pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr, near_cap ? s.near_m : nullptr,
+                     s.repair_mask, s.repair_list, c->need_hint);
     c->last_near = near_cap != 0u;
     HIP_TRY(c, mark(6, cs));
     // the scan has already delivered this frame's status to h_status[r]; a statistics frame refreshes it with the late
@@ -775,6 +783,7 @@ int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
             sl.layout_valid = false; sl.flip = 0;
             if (sl.counts) HIP_TRY(c, hipMemsetAsync(sl.counts, 0, sizeof(unsigned int) * (size_t)(m + 1), c->stream));
         }
+        if (c->need_hint) HIP_TRY(c, hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)(m + 1), c->stream));   // another grid: another tile under every index
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->last_one_pass = one_pass; c->layout_m = m;
     }
@@ -1080,10 +1089,10 @@ void splat_destroy(splat_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);      // lane 1: compositors and gathers that use the buffers / the communicator released below
     if (c->comm) { comm_release(c->comm); c->comm = nullptr; }
     free_scene(c);
-    dfree(c->zero_layout);
+    dfree(c->zero_layout); dfree(c->need_hint);
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
-        dfree(s.repair_mask); dfree(s.repair_list);
+        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m);
         dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
         if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);
@@ -1143,6 +1152,9 @@ int splat_set_option(splat_ctx* c, int32_t option, double value) {
         return splat_set_frame_overlap(c, (int32_t)value);
     }
     if (!store_option(c, option, value)) return fail(c, SPLAT_ERR_INVALID, "option value out of range");
+    // (another selection size: what the tiles' walks needed under the old one is forgotten)
+    if (option == SPLAT_OPT_NEAR_SELECT_KEYS && c->need_hint && c->m_alloc)
+        HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)c->m_alloc));
     return SPLAT_OK;
 }
 
@@ -1255,6 +1267,7 @@ int splat_set_slab(splat_ctx* c, int32_t tile_row0, int32_t tile_row1) {
     for (Slot& sl : c->slots) sl.layout_valid = false;
     c->sort_hint = false;
     c->hint_pairs = 0; c->hint_maxlen = 0;
+    if (c->need_hint && c->m_alloc) (void)hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)c->m_alloc, c->stream);
     c->slab0 = tile_row0; c->slab1 = tile_row1;
     return rc;
 }
@@ -1599,6 +1612,19 @@ int splat_debug_k1_hwid(splat_ctx* c, unsigned long long* out, unsigned long lon
     return hipMemcpy(out, c->slots[c->last_slot].rect, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? SPLAT_OK : SPLAT_ERR_HIP;
 }
 #endif
+
+// (debug, not part of the ABI: tools/near_debug.py)  The near selection's per-tile state of the most recent frame: lens[m],
+// near_m[m], repair_mask[m], need_hint[4 m].
+int splat_debug_near_state(splat_ctx* c, unsigned int* lens, unsigned int* near_m, unsigned int* repair_mask, unsigned int* need_hint, unsigned int m) {
+    if (!c || c->last_slot < 0 || m != c->n_tiles) return SPLAT_ERR_INVALID;
+    (void)sync_all(c);
+    const Slot& s = c->slots[c->last_slot];
+    bool ok = hipMemcpy(lens, s.lens, sizeof(unsigned int) * m, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(near_m, s.near_m, sizeof(unsigned int) * m, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(repair_mask, s.repair_mask, sizeof(unsigned int) * m, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(need_hint, c->need_hint, sizeof(unsigned int) * 4u * m, hipMemcpyDeviceToHost) == hipSuccess;
+    return ok ? SPLAT_OK : SPLAT_ERR_HIP;
+}
 
 int64_t splat_binning_mode(splat_ctx* c) {
     if (!c || c->last_slot < 0) return -1;

@@ -119,6 +119,10 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
                  unsigned int fused_sort_max = 0);
 // fused_sort_max: lists of up to this many keys (<= 2048) are sorted by the compositor's workgroups
 // themselves (launch_sort must be given the same value and then leaves them alone); 0 = off.
+// near selection instead of the sort launches: the nearest keys of every list of more than 2048 keys, by last frame's need
+void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
+                   unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
+                   const unsigned int* need_hint, unsigned int* near_m /* per tile: how many of the nearest keys are in order */);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max = 0,
@@ -131,11 +135,12 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                                                   nothing covers are zeroed (color.clear(0) of src/main.rs:73, fused) */,
                       unsigned long long* keys2 = nullptr /* != nullptr: no sort launch ran; lists of more than 2048 keys
                                                              are sorted by their tile's workgroup through this buffer */,
-                      unsigned int near_cap = 0 /* != 0 (with keys2): near selection -- of a list of more than 2048 keys only the
-                                                   nearest <= near_cap (<= 2048) are selected and sorted; the whole list only if a
-                                                   walk turns out to need it (select_near, composite_tile) */,
+                      const unsigned int* near_m = nullptr /* != nullptr (with keys2): near selection -- launch_select ran in front: of a
+                                                   list of more than 2048 keys only the nearest near_m[tile] are in order (composite_tile) */,
                       unsigned int* repair_mask = nullptr /* per tile: waves whose walk needed more than the selection (zeroed by the scan) */,
-                      unsigned int* repair_list = nullptr /* n_tiles entries: the tiles the repair launch takes again */);
+                      unsigned int* repair_list = nullptr /* n_tiles entries: the tiles the repair launch takes again */,
+                      unsigned int* need_hint = nullptr /* 4 words per tile, kept from frame to frame: how many of its list's nearest
+                                                           keys each wave's walk needed (sizes the next frame's selection) */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 // ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)

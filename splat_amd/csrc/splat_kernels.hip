@@ -1633,40 +1633,42 @@ __device__ __forceinline__ void sort_list_global(unsigned char* smem, unsigned l
     }
 }
 
-// A list LONGER than the 2048 keys a compositor workgroup sorts in its LDS, sorted by that same workgroup (NT = 256
+// A list LONGER than the 2048 keys a compositor workgroup sorts in its LDS, put in order by that same workgroup (NT = 256
 // threads, the compositor's sort_lds_bytes<NT, 2048>() of LDS) before it composites the tile -- so that no frame
 // waits for sort launches whose big workgroups (74 / 147 KB of LDS) only find room on a chip full of compositor
-// workgroups once those have drained:
-//   1  depth range of the list; 1024 bins of (depth - min) >> shift
-//   2  histogram (LDS atomics), exclusive scan -> every bin's place in the output
-//   3  scatter g -> h (the second key buffer): the list is now grouped by bin, bins in depth order
-//   4  consecutive bins are grouped into PARTS of fewer than 1792 keys (a part begins at the first bin whose place
-//      crosses a multiple of 1280; no bin holds more than 512 keys) and every part is sorted through LDS, h -> g,
-//      by the code that sorts the short lists.
-// A bin of more than 512 keys (hundreds of Gaussians at one depth), or more than 63 parts, goes the global route.
+// workgroups once those have drained -- in full, or only its nearest `cap` keys (cap < n: near selection, see select_near):
+//   1  a depth range from a 256-key sample of the list; 1024 bins over it (keys outside fall into the end bins)
+//   2  histogram (LDS atomics); the largest SUFFIX of bins -- the near end -- that holds at most `cap` keys is the
+//      selection (all of them if cap >= n); exclusive scan of the selected bins -> every bin's place in the output
+//   3  scatter g -> h (the second key buffer): the selected keys are now grouped by bin, bins in depth order; g is untouched
+//   4  consecutive bins are grouped into PARTS of at most 1792 keys (a bin of more than 512 keys is a part of its own, up
+//      to the 2048 keys the LDS sort holds) and every part is sorted through LDS by the code that
+//      sorts the short lists: into g for a full sort (the list in its region, as a sort launch leaves it), in place in h
+//      for a selection (the region keeps the whole unordered list: a repair can still sort it all).
+// A selected bin of more than 2048 keys (thousands of Gaussians at one depth), or more than 63 parts, fails: the caller
+// takes the whole list the global route.
 // partition_long_list does 1-3 and returns the number of parts (their bounds in `pstart`, LDS, the last
-// LONG_SORT_RESERVE bytes of the workspace), or 0 if the list went the global route and is already sorted in g; the
-// caller runs the parts through sort_list_in_lds (the compositor has ONE inlined copy of that code for its short and
-// its long lists: a second one cost 24 VGPRs, two workgroups per CU).
+// LONG_SORT_RESERVE bytes of the workspace) and the number of selected keys in *m_out, or 0 on failure; the caller runs
+// the parts through sort_list_in_lds (the compositor has ONE inlined copy of that code for its short and its long
+// lists: a second one cost 24 VGPRs, two workgroups per CU).
 constexpr unsigned int LONG_SORT_RESERVE = 256u;
 template <int NT>
-__device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem, unsigned long long* g, unsigned long long* h,
-                                                            unsigned int n, FrameStatus* __restrict__ status,
-                                                            const unsigned int* __restrict__ orig) {
-    constexpr unsigned int NB = 1024u, PART_T = 1280u, BIN_MAX = 512u, PMAX = 63u, RESERVE = LONG_SORT_RESERVE;
+__device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem, const unsigned long long* __restrict__ g, unsigned long long* __restrict__ h,
+                                                            unsigned int n, unsigned int cap, unsigned int* m_out) {
+    constexpr unsigned int NB = 1024u, PART_T = 1280u, PART_MAX = 1792u, BIN_MAX = 512u, PMAX = 63u, RESERVE = LONG_SORT_RESERVE;
     static_assert(NT == 256, "four bins per thread");
     unsigned int* bins = reinterpret_cast<unsigned int*>(smem);             // counts, then exclusive starts
     unsigned int* cur = bins + NB;                                          // scatter cursors
-    unsigned int* misc = cur + NB;                                          // 0 min, 1 max, 2 largest bin, 3 last part, 4.. wave sums
+    unsigned int* misc = cur + NB;                                          // 0 min, 1 max, 2 largest selected bin, 3 last part, 4 first bin, 5 selected keys, 8.. wave sums
     unsigned int* pstart = reinterpret_cast<unsigned int*>(smem + sort_lds_bytes<NT, 2048>() - RESERVE);   // [64]
     const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (unsigned int q = tid; q < NB; q += NT) { bins[q] = 0u; cur[q] = 0u; }
     if (tid < 64u) pstart[tid] = 0xffffffffu;
-    if (tid == 0u) { misc[0] = 0xffffffffu; misc[1] = 0u; misc[2] = 0u; misc[3] = 0u; }
-    unsigned int mn = 0xffffffffu, mx = 0u;
-    for (unsigned int t = tid; t < n; t += NT) {
-        const unsigned int d = (unsigned int)(g[t] >> 32);
-        mn = min(mn, d); mx = max(mx, d);
+    if (tid == 0u) { misc[0] = 0xffffffffu; misc[1] = 0u; misc[2] = 0u; misc[3] = 0u; misc[4] = NB; misc[5] = 0u; }
+    unsigned int mn, mx;
+    {   // the sample (see select_near)
+        const unsigned int d = (unsigned int)(g[(unsigned int)(((unsigned long long)tid * n) / NT)] >> 32);
+        mn = d; mx = d;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1676,51 +1678,116 @@ __device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem,
     __syncthreads();
     if (lane == 0u) { atomicMin(&misc[0], mn); atomicMax(&misc[1], mx); }
     __syncthreads();
-    const unsigned int dmin = misc[0], range = misc[1] - dmin;
+    const unsigned int smin = misc[0], smax = misc[1], quarter = (smax - smin) >> 2;
+    const unsigned int lo = smin > quarter ? smin - quarter : 0u;
+    const unsigned int hi = smax < 0xffffffffu - quarter ? smax + quarter : 0xffffffffu;
+    const unsigned int range = hi - lo;
     const unsigned int sh = range >= NB ? (unsigned int)(32 - __clz((int)range)) - 10u : 0u;      // (range >> sh) < 1024
-    for (unsigned int t = tid; t < n; t += NT) atomicAdd(&bins[((unsigned int)(g[t] >> 32) - dmin) >> sh], 1u);
-    __syncthreads();
-    {   // exclusive scan, four consecutive bins per thread
-        unsigned int c[4], sum = 0u, big = 0u;
+    auto bin_of = [&](unsigned int d) -> unsigned int { return d < lo ? 0u : min((d - lo) >> sh, NB - 1u); };
+    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {              // eight loads in flight per thread
+        unsigned int d[8];
 #pragma unroll
-        for (unsigned int j = 0; j < 4; ++j) { c[j] = bins[4u * tid + j]; sum += c[j]; big = max(big, c[j]); }
+        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; d[u] = (t < n) ? (unsigned int)(g[t] >> 32) : 0u; }
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) if (t0 + u * NT < n) atomicAdd(&bins[bin_of(d[u])], 1u);
+    }
+    __syncthreads();
+    unsigned int c[4], before;                     // this thread's four bins and the keys in the bins in front of them
+    {
+        unsigned int sum = 0u;
+#pragma unroll
+        for (unsigned int j = 0; j < 4; ++j) { c[j] = bins[4u * tid + j]; sum += c[j]; }
         unsigned int v = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned int u = (unsigned int)__shfl_up((int)v, o);
             if ((int)lane >= o) v += u;
         }
-        if (lane == 63u) misc[4u + wave] = v;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned int)__shfl_xor((int)big, o));
-        if (lane == 0u) atomicMax(&misc[2], big);
+        if (lane == 63u) misc[8u + wave] = v;
         __syncthreads();
-        unsigned int ex = v - sum;
-        for (unsigned int w = 0; w < wave; ++w) ex += misc[4u + w];
+        before = v - sum;
+        for (unsigned int w = 0; w < wave; ++w) before += misc[8u + w];
+        // the first selected bin: the smallest b with S(b) = n - (keys in bins < b) <= cap
+        unsigned int S = n - before;
 #pragma unroll
         for (unsigned int j = 0; j < 4; ++j) {
-            bins[4u * tid + j] = ex;
-            if (c[j]) {                                 // a part begins at the first (non-empty) bin placed in its interval
-                const unsigned int p = ex / PART_T;
-                if (p <= PMAX) atomicMin(&pstart[p], ex);
-                atomicMax(&misc[3], p);
-            }
-            ex += c[j];
+            const unsigned int b = 4u * tid + j;
+            const unsigned int cnt_prev = (j == 0u) ? ((tid == 0u) ? 0u : bins[b - 1u]) : c[j - 1u];
+            if (S <= cap && (b == 0u || S + cnt_prev > cap)) { misc[4] = b; misc[5] = S; }
+            S -= c[j];
         }
     }
     __syncthreads();
-    const unsigned int P = misc[3] + 1u;
-    if (misc[2] > BIN_MAX || P > PMAX) {
-        __syncthreads();                               // (misc is about to be overwritten)
-        sort_list_global<NT>(smem, g, h, n, status, orig);
-        return 0u;
+    const unsigned int first = misc[4], m = misc[5];
+    *m_out = m;
+    if (first >= NB || m == 0u) { __syncthreads(); return 0u; }          // the nearest bin alone overflows the cap
+    {
+        const unsigned int skipped = n - m;        // keys in the bins in front of the selection
+        unsigned int ex = before, big = 0u;
+#pragma unroll
+        for (unsigned int j = 0; j < 4; ++j) {
+            const unsigned int b = 4u * tid + j;
+            if (b >= first) {
+                const unsigned int at = ex - skipped;
+                bins[b] = at;                               // the bin's place in the output
+                if (c[j]) {                                 // (ordinary lists) a part begins at the first bin placed in its interval of PART_T places
+                    const unsigned int p = at / PART_T;
+                    if (p < PMAX) atomicMin(&pstart[p], at);
+                    atomicMax(&misc[3], p);
+                    big = max(big, c[j]);
+                }
+            }
+            ex += c[j];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned int)__shfl_xor((int)big, o));
+        if (lane == 0u) atomicMax(&misc[2], big);
     }
-    for (unsigned int t = tid; t < n; t += NT) {
-        const unsigned long long key = g[t];
-        const unsigned int b = ((unsigned int)(key >> 32) - dmin) >> sh;
-        h[bins[b] + atomicAdd(&cur[b], 1u)] = key;
+    __syncthreads();
+    // The parts.  No selected bin above BIN_MAX keys (the rule): every interval of PART_T = 1280 output places holds a bin's
+    // start, the first of them begins a part, parts stay under 1280 + 512 keys.  Otherwise -- many Gaussians at one depth:
+    // a wall seen face on -- one thread walks the selected bins: consecutive bins are grouped while the group stays within
+    // PART_MAX keys, a bin above BIN_MAX is a part of its own (it must fit the LDS sort: 2048 keys, else the whole list goes
+    // the global route).
+    if (tid == 0u) {
+        unsigned int np = 0u;
+        bool ok = true;
+        if (misc[2] <= BIN_MAX) {
+            np = misc[3] + 1u;
+            ok = np < PMAX;
+        } else {
+            unsigned int part_beg = 0u, size = 0u;
+            bool prev_big = false;
+            for (unsigned int b = first; b < NB && ok; ++b) {
+                const unsigned int at = bins[b], cnt = ((b + 1u < NB) ? bins[b + 1u] : m) - at;
+                if (cnt == 0u) continue;
+                const bool bigbin = cnt > BIN_MAX;
+                if (cnt > 2048u) { ok = false; break; }
+                if (size != 0u && (bigbin || prev_big || size + cnt > PART_MAX)) {
+                    if (np >= PMAX - 1u) { ok = false; break; }
+                    pstart[np++] = part_beg;
+                    part_beg = at; size = 0u;
+                }
+                size += cnt; prev_big = bigbin;
+            }
+            if (ok && size != 0u) pstart[np++] = part_beg;
+        }
+        if (ok) pstart[np] = m;
+        misc[3] = ok ? np : 0u;
     }
-    if (tid == 0u) pstart[P] = n;
+    __syncthreads();
+    const unsigned int P = misc[3];
+    if (P == 0u) { __syncthreads(); return 0u; }
+    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {
+        unsigned long long k[8];
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; k[u] = (t < n) ? g[t] : 0ull; }
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) {
+            const unsigned int b = bin_of((unsigned int)(k[u] >> 32));
+            if (t0 + u * NT < n && b >= first) h[bins[b] + atomicAdd(&cur[b], 1u)] = k[u];
+        }
+    }
     __syncthreads();                                   // h is complete (this workgroup's own global writes) and bins / cur are free
     return P;
 }
@@ -1730,9 +1797,9 @@ __device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem,
 // are bracketed, composite_tile): of the lists of more than 2048 keys -- two thirds of all keys on C3, five sixths on C5 --
 // the deepest of a tile's four walks reaches 2-9 % (SPLAT_DBG_STARTS, tools/starts_probe.py).  Sorting the other 90 % is
 // the single largest piece of wasted work in the frame.  So, by the tile's own workgroup (NT = 256 threads, its
-// sort_lds_bytes<NT, 2048>() of LDS), in three streaming passes over the n keys at g (global, unordered):
-//   1  the depth range of the list (min / max of the keys' depth halves)
-//   2  a histogram of (depth - min) >> shift over 1024 bins (LDS atomics)
+// sort_lds_bytes<NT, 2048>() of LDS), in two streaming passes over the n keys at g (global, unordered):
+//   1  a depth range for the bins, from a 256-key sample of the list
+//   2  a histogram of the keys' depths over 1024 bins of that range (LDS atomics)
 //   3  the largest SUFFIX of bins -- ascending depth key = far first, so the suffix is the near end -- that holds at most
 //      `cap` <= 2048 keys; those keys are compacted into LDS (smem as the key array s[0 .. m)), in arrival order
 // and returns m (with the min / max of the selected depth halves for the digit plan of the sort that follows).  A bin
@@ -1751,13 +1818,14 @@ __device__ __forceinline__ unsigned int select_near(unsigned char* smem, const u
     const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (unsigned int q = tid; q < NB; q += NT) bins[q] = 0u;
     if (tid == 0u) { misc[0] = 0xffffffffu; misc[1] = 0u; misc[2] = NB; misc[3] = 0u; misc[4] = 0u; }
-    unsigned int mn = 0xffffffffu, mx = 0u;
-    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {              // eight loads in flight per thread
-        unsigned int d[8];
-#pragma unroll
-        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; d[u] = (t < n) ? (unsigned int)(g[t] >> 32) : 0u; }
-#pragma unroll
-        for (unsigned int u = 0; u < 8; ++u) if (t0 + u * NT < n) { mn = min(mn, d[u]); mx = max(mx, d[u]); }
+    // The bins' depth range comes from a SAMPLE of the list -- one key per thread, strided over the list (its order is
+    // K1's arrival order: arbitrary) -- widened by a quarter on either side; keys outside fall into the end bins.  Any
+    // monotone binning selects correctly; a range that misses only costs resolution there (the true extremes would take a
+    // pass over the whole list: a third of this function's memory traffic).
+    unsigned int mn, mx;
+    {
+        const unsigned int d = (unsigned int)(g[(unsigned int)(((unsigned long long)tid * n) / NT)] >> 32);
+        mn = d; mx = d;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1767,21 +1835,25 @@ __device__ __forceinline__ unsigned int select_near(unsigned char* smem, const u
     __syncthreads();
     if (lane == 0u) { atomicMin(&misc[0], mn); atomicMax(&misc[1], mx); }
     __syncthreads();
-    const unsigned int dmin = misc[0], range = misc[1] - dmin;
+    const unsigned int smin = misc[0], smax = misc[1], quarter = (smax - smin) >> 2;
+    const unsigned int lo = smin > quarter ? smin - quarter : 0u;
+    const unsigned int hi = smax < 0xffffffffu - quarter ? smax + quarter : 0xffffffffu;
+    const unsigned int range = hi - lo;
     const unsigned int sh = range >= NB ? (unsigned int)(32 - __clz((int)range)) - 10u : 0u;      // (range >> sh) < 1024
-    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {
+    auto bin_of = [&](unsigned int d) -> unsigned int { return d < lo ? 0u : min((d - lo) >> sh, NB - 1u); };
+    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {              // eight loads in flight per thread
         unsigned int d[8];
 #pragma unroll
         for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; d[u] = (t < n) ? (unsigned int)(g[t] >> 32) : 0u; }
 #pragma unroll
-        for (unsigned int u = 0; u < 8; ++u) if (t0 + u * NT < n) atomicAdd(&bins[(d[u] - dmin) >> sh], 1u);
+        for (unsigned int u = 0; u < 8; ++u) if (t0 + u * NT < n) atomicAdd(&bins[bin_of(d[u])], 1u);
     }
     __syncthreads();
     {   // suffix sums, four consecutive bins per thread: thread t owns bins 4t .. 4t+3; S(b) = keys in bins >= b
         unsigned int c[4], sum = 0u;
 #pragma unroll
         for (unsigned int j = 0; j < 4; ++j) { c[j] = bins[4u * tid + j]; sum += c[j]; }
-        unsigned int v = sum;                       // inclusive scan over the wave's lanes, then the waves behind this one
+        unsigned int v = sum;                       // inclusive scan over the wave's lanes, then the waves in front of this one
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned int u = (unsigned int)__shfl_up((int)v, o);
@@ -1791,11 +1863,10 @@ __device__ __forceinline__ unsigned int select_near(unsigned char* smem, const u
         __syncthreads();
         unsigned int total = 0u, before = v - sum;  // keys in the bins in front of this thread's
         for (unsigned int w = 0; w < NT / 64u; ++w) { const unsigned int x = misc[8u + w]; total += x; if (w < wave) before += x; }
-        // S(4t + j) = total - before - c[0] - .. - c[j-1]; the first selected bin is the smallest b with S(b) <= cap
+        // the first selected bin is the smallest b with S(b) <= cap: S(b) <= cap and (b == 0 or S(b - 1) = S(b) + count(b - 1) > cap)
         unsigned int S = total - before;
 #pragma unroll
         for (unsigned int j = 0; j < 4; ++j) {
-            // S(b) <= cap and (b == 0 or S(b - 1) > cap): S(b - 1) = S(b) + count(b - 1)
             const unsigned int b = 4u * tid + j;
             const unsigned int cnt_prev = (j == 0u) ? ((tid == 0u) ? 0u : bins[b - 1u]) : c[j - 1u];
             if (S <= cap && (b == 0u || S + cnt_prev > cap)) { misc[2] = b; misc[3] = S; }
@@ -1805,6 +1876,9 @@ __device__ __forceinline__ unsigned int select_near(unsigned char* smem, const u
     __syncthreads();
     const unsigned int first = misc[2], m = misc[3];
     if (first >= NB || m == 0u) { __syncthreads(); return 0u; }          // the nearest bin alone overflows the cap
+    __syncthreads();                                                     // (misc[0..1] are reused for the selection's extremes)
+    if (tid == 0u) { misc[0] = 0xffffffffu; misc[1] = 0u; }
+    mn = 0xffffffffu; mx = 0u;
     for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {
         unsigned long long k[8];
 #pragma unroll
@@ -1812,36 +1886,60 @@ __device__ __forceinline__ unsigned int select_near(unsigned char* smem, const u
 #pragma unroll
         for (unsigned int u = 0; u < 8; ++u) {
             const unsigned int d = (unsigned int)(k[u] >> 32);
-            const bool take = (t0 + u * NT < n) && (((d - dmin) >> sh) >= first);
+            const bool take = (t0 + u * NT < n) && (bin_of(d) >= first);
             const unsigned long long tm = __builtin_amdgcn_ballot_w64(take);
             if (tm) {                               // one cursor atomic per wave and round
                 unsigned int base = 0u;
                 if (lane == 0u) base = atomicAdd(&misc[4], (unsigned int)__builtin_popcountll(tm));
                 base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-                if (take)
+                if (take) {
                     s[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(tm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)tm, 0u))] = k[u];
+                    mn = min(mn, d); mx = max(mx, d);
+                }
             }
         }
     }
-    // (the bounds only size the sort's digits: the selection's lower bin edge and the list's maximum do as well as the exact
-    // extremes, and every thread knows them)
-    *sel_mn = dmin + (first << sh);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (unsigned int)__shfl_xor((int)mn, o));
+        mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+    }
+    __syncthreads();                                // (tid 0's reset of misc[0..1] is in place)
+    if (lane == 0u) { atomicMin(&misc[0], mn); atomicMax(&misc[1], mx); }
+    __syncthreads();                                // s[0 .. m) and the extremes are complete
+    *sel_mn = misc[0];                              // the depth range of the selection: sizes the digits of the sort that follows
     *sel_mx = misc[1];
-    __syncthreads();
     return m;
 }
 
-// The whole of it, for the compositor's workgroup.
-__device__ __forceinline__ void sort_long_list(unsigned char* smem, unsigned long long* g, unsigned long long* h, unsigned int n,
-                                               unsigned int radix_min, FrameStatus* status, const unsigned int* orig) {
-    const unsigned int parts = partition_long_list<256>(smem, g, h, n, status, orig);
+// The whole of it, for the compositor's workgroup: the nearest min(cap, n) keys of the list at g (region of the key buffer,
+// n keys, unordered) put in painter's order.  Returns m, how many that are: m == n -- the whole list, sorted in g (the
+// global route of last resort included); m < n -- the selection, sorted in h[0 .. m) (h = the second key buffer's region),
+// g untouched.  A selection that cannot be partitioned (a bin too full, too many parts) becomes the whole list.
+// need_min: a selection of fewer keys than this is not worth having (the bins are coarse where many keys share a depth): the
+// whole list instead.
+__device__ __forceinline__ unsigned int sort_long_list(unsigned char* smem, unsigned long long* g, unsigned long long* h, unsigned int n,
+                                                       unsigned int cap, unsigned int radix_min, FrameStatus* status, const unsigned int* orig,
+                                                       unsigned int need_min = 0u) {
+    unsigned int m = 0u, parts = 0u;
+    for (int attempt = 0; attempt < 2; ++attempt) {        // (one inlined copy of the partition)
+        parts = partition_long_list<256>(smem, g, h, n, cap, &m);
+        if ((parts != 0u && (m >= need_min || m == n)) || cap >= n) break;
+        cap = n; parts = 0u;
+    }
+    if (parts == 0u) {
+        sort_list_global<256>(smem, g, h, n, status, orig);
+        return n;
+    }
     const unsigned int* const pstart = reinterpret_cast<const unsigned int*>(smem + sort_lds_bytes<256, 2048>() - LONG_SORT_RESERVE);
+    unsigned long long* const dst = (m == n) ? g : h;
     for (unsigned int p = 0; p < parts; ++p) {
         const unsigned int a = (unsigned int)__builtin_amdgcn_readfirstlane((int)pstart[p]);
         const unsigned int b = (unsigned int)__builtin_amdgcn_readfirstlane((int)pstart[p + 1u]);
-        sort_list_in_lds<256, 2048>(smem, h + a, g + a, b - a, radix_min, status, orig, nullptr, true, LONG_SORT_RESERVE);
+        sort_list_in_lds<256, 2048>(smem, h + a, dst + a, b - a, radix_min, status, orig, nullptr, true, LONG_SORT_RESERVE);
         __syncthreads();                               // the workspace is the next part's
     }
+    return m;
 }
 
 // One workgroup per tile; a launch handles the lists with lo < n <= CAP (three size classes, so
@@ -2107,9 +2205,9 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                                                FrameStatus* __restrict__ status, unsigned int fused_sort_max,
                                                unsigned int radix_min, uint2* __restrict__ iters, unsigned int keep_keys,
                                                const unsigned int* __restrict__ orig, const unsigned int clear_first,
-                                               unsigned long long* __restrict__ keys2, const unsigned int near_cap,
+                                               unsigned long long* __restrict__ keys2, const unsigned int* __restrict__ near_m,
                                                unsigned int* __restrict__ repair_mask, unsigned int* __restrict__ repair_list,
-                                               const unsigned int wave_mask) {
+                                               const unsigned int wave_mask, unsigned int* __restrict__ need_hint) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -2144,39 +2242,39 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // LONGM == 1: in full -- partitioned by depth into parts of fewer than 1792 keys through the second key buffer
     // (partition_long_list), every part sorted through LDS back into the region, then read from memory like a list a sort
     // launch had left.
-    // LONGM == 2, NEAR SELECTION: only its nearest <= near_cap keys are picked out by depth (select_near: three streaming
-    // passes, no sort) and sorted through LDS like a short list; the walks then see the list [lb, end) with `has_far` set
-    // -- farther keys exist in front of `lb`, NOT in order.  The early-out makes that enough: a walk that starts inside
-    // the selection and closes its bracket there is exact as always.  A wave whose walk would have to start at or before
-    // `lb` (its pixels did not saturate within the selection, the bracket did not close, a pixel met no record) writes no
-    // pixel and reports the tile instead: the repair launch behind this one sorts that list in full and walks those
-    // waves again.  On C3 / C5 the selection serves every tile of the bench pose (tools/starts_probe.py): 93-98 % of the
-    // long lists' keys are never sorted.
+    // LONGM == 2, NEAR SELECTION: a kernel in front of this one (select_near_kernel, on the frame's binning stream) has put
+    // only the NEAREST keys of the list in order; the walks then see the list [lb, end) with `has_far` set -- farther keys
+    // exist in front of `lb`, NOT in order.  The early-out makes that enough: a walk that starts inside the selection
+    // and closes its bracket there is exact as always.  A wave whose walk would have to start at or before `lb` (its
+    // pixels did not saturate within the selection, the bracket did not close, a pixel met no record) writes no pixel and
+    // reports the tile instead: the repair launch behind this one sorts that list in full and walks those waves again.
+    // On C3 / C5 the selection serves every tile of the bench pose (tools/near_probe.py): 93-98 % of the long lists' keys
+    // are never sorted.
     unsigned int lb = beg;
-    bool has_far = false, no_selection = false;
+    bool has_far = false;
+    const unsigned long long* wk = keys;          // the walks' key of list position p (lb <= p < end) is wk[p] (unless the order is in LDS)
     {
         const unsigned long long* gin = keys + beg;
-        unsigned int n_sort = end - beg, smn = 0xffffffffu, smx = 0u;
+        unsigned int n_sort = end - beg;
         if constexpr (LONGM == 1) {
             if (end - beg > 2048u) {
-                sort_long_list(smem, keys + beg, keys2 + beg, end - beg, radix_min, status, orig);
+                (void)sort_long_list(smem, keys + beg, keys2 + beg, end - beg, end - beg, radix_min, status, orig);
                 __syncthreads();
             }
         }
         if constexpr (LONGM == 2) {
             if (end - beg > 2048u) {
-                const unsigned int m = select_near<256>(smem, keys + beg, end - beg, near_cap, &smn, &smx);
-                if (m != 0u) {
-                    gin = nullptr; n_sort = m; own_order = true;
+                // select_near_kernel has been here: near_m[tile] of the list's nearest keys are in order -- all of them (in
+                // the region itself), or a selection (at the start of the second key buffer's region)
+                const unsigned int m = (unsigned int)__builtin_amdgcn_readfirstlane((int)near_m[tile]);
+                if (m < end - beg) {
                     has_far = true; lb = end - m;
-                    if (tid == 0u) atomicAdd(&status->n_near_tiles, 1u);
-                } else {
-                    no_selection = true;            // (hundreds of keys at the nearest depth: the repair launch takes the tile)
+                    wk = keys2 + beg - lb;
                 }
             }
         }
         if (own_order) {
-            sort_list_in_lds<256, 2048>(smem, gin, keys + beg, n_sort, radix_min, status, orig, lds_idx, (keep_keys & 1u) != 0u && gin != nullptr, 0u, smn, smx);
+            sort_list_in_lds<256, 2048>(smem, gin, keys + beg, n_sort, radix_min, status, orig, lds_idx, (keep_keys & 1u) != 0u);
             __syncthreads();          // the order is in LDS, the rest of the workspace is free for the batches
         }
     }
@@ -2216,7 +2314,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     //        issues one instruction per ~4 cycles whatever its type, so scalar bookkeeping per record
     //        is as expensive as vector work on the launch's critical path.
     auto fetch = [&](unsigned int base, unsigned int cnt, Rec& r) {
-        if (lane < cnt) r = recs[own_order ? lds_idx[base - lb + lane] : (unsigned int)keys[base + lane]];
+        if (lane < cnt) r = recs[own_order ? lds_idx[base - lb + lane] : (unsigned int)wk[base + lane]];
     };
     // Can ANY sample of the block be accepted?  Upper bound of alpha over the block: the minimum of
     // the conic's quadratic form q = a dx^2 + 2 b dx dy + c dy^2 over the block's sample rectangle
@@ -2314,7 +2412,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         return accept ? alpha : 0.0f;
     };
 
-    bool need_far = no_selection;                // near selection: this wave's walk needs keys in front of the selection
+    bool need_far = false;                       // near selection: this wave's walk needs keys in front of the selection
     unsigned int itA = 0, itB = 0;               // (wave, record) iterations per phase, for the stats
     // ---------------- alpha pass: the alpha byte ----------------
     // blend() stores the NEW fragment's alpha (src/pipelines.rs:162-167), rejected fragments store 0,
@@ -2517,6 +2615,10 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // (keep_keys bit 1, SPLAT_DBG_STARTS: the list's length and how many of its nearest keys this wave's walk needed instead)
     if (iters != nullptr && lane == 0)
         iters[item * 4u + wave] = (keep_keys & 2u) ? make_uint2(end - beg, end - max(start, beg)) : make_uint2(itA, itB);
+    if constexpr (LONGM != 0) {
+        // what this wave's walk needed of the list's near end, for the next frame's selection (see the prologue)
+        if (need_hint != nullptr && end - beg > 2048u && lane == 0u) need_hint[tile * 4u + wave] = need_far ? 0xffffffffu : end - max(start, lb);
+    }
     if constexpr (LONGM == 2) {
         if (need_far) {
             // the first wave of a tile to ask puts the tile on the repair list; the mask says which waves to walk again
@@ -2526,6 +2628,59 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     }
     if (inside)
         argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
+}
+
+// NEAR SELECTION, the kernel (one workgroup per slot of the longest-first tile order; 256 threads and the compositor's
+// 21.5 KB of LDS, so that its workgroups find room beside a compositor in flight -- the sort launches it replaces need
+// 74 / 147 KB each and starve there).  A list of more than 2048 keys is NOT sorted: how many of its nearest keys the tile's
+// walks will need is known from the previous frame -- every wave leaves it in need_hint, four words per tile, plain
+// stores: 0 = nothing known, ~0 = more than it was given -- and the deepest of the four, half as much again, is
+// selected by depth and put in order:
+//   through LDS (select_near + the short lists' sort) while that fits the 2048-key workspace: the sorted selection goes
+//   to the START of the second key buffer's region, the region itself keeps the whole unordered list;
+//   as sorted parts (sort_long_list with a cap) beyond that; and a tile that ran out of its selection last time, or whose
+//   selection would be most of the list anyway, is sorted in full, in its region, as a sort launch would leave it.
+// near_m[tile] = how many of the nearest keys are in order (== the list's length: all of them).  A wrong guess costs time
+// only -- a larger sort than necessary, or the compositor's repair launch -- never a pixel.
+__global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
+                                                          const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
+                                                          unsigned long long* __restrict__ keys2, FrameStatus* __restrict__ status,
+                                                          const unsigned int* __restrict__ orig, unsigned int radix_min, unsigned int near_cap,
+                                                          const unsigned int* __restrict__ need_hint, unsigned int* __restrict__ near_m) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
+    if (status->overflow) return;
+    const unsigned int tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);
+    const unsigned int n = (unsigned int)__builtin_amdgcn_readfirstlane((int)lens[tile]);
+    if (n <= 2048u) return;                     // (the compositor's workgroup sorts those itself)
+    const unsigned int beg = (unsigned int)__builtin_amdgcn_readfirstlane((int)offsets[tile]);
+    unsigned int want = near_cap, deepest;
+    {
+        const uint4 h4 = reinterpret_cast<const uint4*>(need_hint)[tile];
+        deepest = (unsigned int)__builtin_amdgcn_readfirstlane((int)max(max(h4.x, h4.y), max(h4.z, h4.w)));
+        if (deepest == 0xffffffffu) want = n;
+        else if (deepest != 0u) want = max(768u, deepest + (deepest >> 1) + 128u);
+        if (want > n - (n >> 2)) want = n;      // (three quarters of the list: the whole list, then, and no repair to fear)
+    }
+    unsigned int m = 0u;
+    if (want <= near_cap) {
+        unsigned int smn, smx;
+        m = select_near<256>(smem, keys + beg, n, want, &smn, &smx);
+        // (the bins are coarse where many keys share a depth: a selection that came out shorter than the tile needed last
+        // time is not worth walking)
+        if (m != 0u && (deepest == 0u || m >= deepest + (deepest >> 3))) {
+            sort_list_in_lds<256, 2048>(smem, nullptr, keys2 + beg, m, radix_min, status, orig, nullptr, true, 0u, smn, smx);
+        } else {
+            m = 0u; want = min(n, 2u * near_cap);
+            __syncthreads();
+        }
+    }
+    if (m == 0u)
+        m = sort_long_list(smem, keys + beg, keys2 + beg, n, want, radix_min, status, orig,
+                           (deepest != 0u && deepest != 0xffffffffu) ? min(n, deepest + (deepest >> 3)) : 0u);
+    if (threadIdx.x == 0u) {
+        near_m[tile] = m;
+        if (m < n) atomicAdd(&status->n_near_tiles, 1u);
+    }
 }
 
 // The launch: one workgroup per tile, slot blockIdx.x of the longest-first order.  (A persistent grid pulling
@@ -2547,8 +2702,8 @@ __global__ __launch_bounds__(256, LONGM == 1 ? 7 : SPLAT_COMP_WAVES) __attribute
                                                               unsigned int radix_min, uint2* __restrict__ iters,
                                                               unsigned int keep_keys, const unsigned int* __restrict__ orig,
                                                               unsigned int clear_first, unsigned long long* __restrict__ keys2,
-                                                              unsigned int near_cap, unsigned int* __restrict__ repair_mask,
-                                                              unsigned int* __restrict__ repair_list) {
+                                                              const unsigned int* __restrict__ near_m, unsigned int* __restrict__ repair_mask,
+                                                              unsigned int* __restrict__ repair_list, unsigned int* __restrict__ need_hint) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
@@ -2558,7 +2713,7 @@ __global__ __launch_bounds__(256, LONGM == 1 ? 7 : SPLAT_COMP_WAVES) __attribute
         __syncthreads();
     }
     composite_tile<PAIR, LIBM, LONGM>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig, clear_first, keys2,
-                                      near_cap, repair_mask, repair_list, 0xfu);
+                                      near_m, repair_mask, repair_list, 0xfu, need_hint);
 }
 
 // The repair launch behind a near-selection frame: the tiles whose selected nearest keys did not do for every wave
@@ -2574,7 +2729,8 @@ __global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, co
                                                                unsigned int radix_min, const unsigned int* __restrict__ orig,
                                                                unsigned int clear_first, unsigned long long* __restrict__ keys2,
                                                                const unsigned int* __restrict__ repair_mask,
-                                                               const unsigned int* __restrict__ repair_list) {
+                                                               const unsigned int* __restrict__ repair_list,
+                                                               unsigned int* __restrict__ need_hint) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
@@ -2588,7 +2744,7 @@ __global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, co
         const unsigned int item = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_list[i]);
         const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_mask[order[item]]);
         composite_tile<PAIR, LIBM, 1>(smem, exptab, item, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, nullptr, 0u, orig, clear_first, keys2,
-                                      0u, nullptr, nullptr, mask);
+                                      nullptr, nullptr, nullptr, mask, need_hint);
         __syncthreads();          // the workspace is the next tile's: every wave has finished its walk
     }
 }
@@ -2699,21 +2855,28 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
         hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
                            lens, keys, keys2, status, fused_sort_max, radix_min, 0, 0u, 1u, orig);
 }
+void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
+                   unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
+                   const unsigned int* need_hint, unsigned int* near_m) {
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(select_near_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, order, lens, keys, keys2, status, orig, sort_radix_min(),
+                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m);
+}
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
-                      bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2, unsigned int near_cap,
-                      unsigned int* repair_mask, unsigned int* repair_list) {
+                      bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2, const unsigned int* near_m,
+                      unsigned int* repair_mask, unsigned int* repair_list, unsigned int* need_hint) {
     if (!n_tiles) return;
     if (g_knobs->dbg_ntiles) n_tiles = std::min(n_tiles, g_knobs->dbg_ntiles);   // debug: composite only the N longest tiles
     // SPLAT_COMP_LDS_PAD: extra dynamic LDS per workgroup, i.e. an occupancy cap (12 KB are in use:
     // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
     const unsigned int pad = g_knobs->comp_lds_pad;
-    const bool near = near_cap != 0u && keys2 != nullptr && repair_mask != nullptr && repair_list != nullptr;
+    const bool near = near_m != nullptr && keys2 != nullptr && repair_mask != nullptr && repair_list != nullptr && need_hint != nullptr;
     const unsigned int flags = (keep_keys ? 1u : 0u) | (g_knobs->dbg_starts ? 2u : 0u);
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                           sort_radix_min(), iters, flags, orig, clear_first ? 1u : 0u, keys2, std::min(near_cap, 2048u), repair_mask, repair_list);
+                           sort_radix_min(), iters, flags, orig, clear_first ? 1u : 0u, keys2, near_m, repair_mask, repair_list, near ? need_hint : nullptr);
     };
     if (near) {
         if (libm_exp) go(composite_exact_kernel<false, true, 2>);
@@ -2722,7 +2885,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
         // the repair launch: tiles the selection did not serve (normally none: its workgroups read one word and leave)
         auto fix = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(std::min(n_tiles, 64u)), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                               sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list);
+                               sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list, need_hint);
         };
         if (libm_exp) fix(composite_repair_kernel<false, true>);
         else if (pair_walk) fix(composite_repair_kernel<true, false>);

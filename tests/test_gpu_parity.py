@@ -729,6 +729,13 @@ def test_near_selection_renders_the_fully_sorted_frame():
                 base = frames[(0, 0)]
                 assert base[4] > 2048 and base[0].any()
                 for key, f in frames.items():
+                    if mode & splat_amd.MODE_FAST:
+                        # (the fast mode's frame depends on where a walk starts -- within 1 of the exact frame whatever the
+                        # start; a selection is scanned to its end where a full list is given up on half way)
+                        for a, b in ((f[0], base[0]), (f[1], base[1])):
+                            d = np.abs(np.stack([((a >> sh) & 255).astype(np.int32) - ((b >> sh) & 255).astype(np.int32) for sh in (24, 16, 8, 0)]))
+                            assert d[0].max() == 0 and d[1:].max() <= 1, (mode, ci, key)
+                        continue
                     assert np.array_equal(f[0], base[0]), (mode, ci, key, int((f[0] != base[0]).sum()))
                     assert np.array_equal(f[1], base[1]), (mode, ci, key)
                 assert frames[(0, 2048)][2] > 0                                   # tiles were served by their selection ...

@@ -12,9 +12,14 @@ if len(sys.argv) >= 3 and sys.argv[1] == "--one":
     R = splat_amd.Renderer(); g = splat_amd.synthetic_scene(n, seed); g.compute_cov3d(R); R.upload(g)
     cam = splat_amd.Camera(H, W, (0, 0, 5.0)); cam.update_camera_pose(); cam_c = cam.to_c(0.01, 15)
     img = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    st0 = R.render_frame_device(cam_c, img.data_ptr(), sync=True, want_stats=True)
     for _ in range(100):
         R.render_frame_device(cam_c, img.data_ptr())
-    R.sync(); torch.cuda.synchronize()
+    try:
+        R.sync()
+    except Exception as e:
+        print("(setup frames: %s)" % e)
+    torch.cuda.synchronize()
     rows = []
     for rep in range(3):
         R.timing(reset=True)
@@ -32,6 +37,7 @@ if len(sys.argv) >= 3 and sys.argv[1] == "--one":
         fps = 300 / (time.perf_counter() - t0)
         rows.append((fps, iso))
     name = os.path.basename(os.environ.get("SPLAT_AMD_LIB", "product"))
+    print("%-22s %s near-selection tiles %d, repaired %d, early-out retries %d" % (name, wl, st0.n_near_tiles, st0.n_near_fallback, st0.n_fallback))
     for fps, iso in rows:
         print("%-22s %s %8.1f fps | alone: K1 %.4f scan %.4f sort %.4f K4 %.4f" % (name, wl, fps, iso["preprocess"], iso["scan"], iso["sort"], iso["composite"]))
     if slabs_too:
