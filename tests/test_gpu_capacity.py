@@ -121,8 +121,10 @@ def test_streamed_frame_that_overflows_is_redone_by_the_wait(scene_and_poses):
 
 
 def test_sort_launch_miss_with_tight_grids():
-    """the sort launches for long lists cover a prefix sized from the previous frame; with no margin
-    (SPLAT_DBG_TIGHT_GRIDS) a pose with more long lists than the last one misses, is skipped, and redone"""
+    """the sort launches for long lists (near selection off: with it there are none, and nothing to miss) cover a prefix sized
+    from the previous frame; with no margin (SPLAT_DBG_TIGHT_GRIDS) a pose with more long lists than the last one misses,
+    is skipped, and redone"""
+    from splat_amd import _lib as L
     saved = os.environ.get("SPLAT_DBG_TIGHT_GRIDS")
     os.environ["SPLAT_DBG_TIGHT_GRIDS"] = "1"
     try:
@@ -137,13 +139,19 @@ def test_sort_launch_miss_with_tight_grids():
         r.upload(g)
         wide = make_camera(240, 320, (0.0, 0.0, 3.0))       # spread out: few lists reach 2048 keys
         tight = make_camera(240, 320, (0.0, 0.0, 9.0))      # concentrated: many do
-        for cam in (wide, tight, wide, tight):
-            img = np.zeros((240, 320), np.uint32)
-            st = r.render(cam.to_c(0.01), img)
-            ref, ost = oracle_frame(g, cam)
-            assert st.n_pairs == ost.n_tile_pairs
-            assert image_diff(img, ref)[0] <= 1
-        assert r.frames_dropped() >= 1, "expected at least one sort-launch miss"
+        for near in (2048, 0):
+            r.set_option(L.OPT_NEAR_SELECT_KEYS, near)
+            d0 = r.frames_dropped()
+            for cam in (wide, tight, wide, tight):
+                img = np.zeros((240, 320), np.uint32)
+                st = r.render(cam.to_c(0.01), img)
+                ref, ost = oracle_frame(g, cam)
+                assert st.n_pairs == ost.n_tile_pairs
+                assert image_diff(img, ref)[0] <= 1
+            if near:
+                assert r.frames_dropped() == d0, "near selection has no launch sizes to miss"
+            else:
+                assert r.frames_dropped() > d0, "expected at least one sort-launch miss"
     finally:
         r.close()
 
