@@ -1039,6 +1039,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
+    if (const char* k6 = std::getenv("SPLAT_DBG_REPAIR_GRID")) c->knobs.dbg_repair_grid = (unsigned int)std::max(0, std::atoi(k6));
     if (const char* k5 = std::getenv("SPLAT_DBG_STARTS")) c->knobs.dbg_starts = std::atoi(k5) != 0 ? 1u : 0u;
     if (const char* k4 = std::getenv("SPLAT_COMP_LDS_PAD")) c->knobs.comp_lds_pad = (unsigned int)std::max(0, std::atoi(k4));
     auto bail = [&](const char* what, hipError_t err) {

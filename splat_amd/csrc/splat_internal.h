@@ -82,6 +82,7 @@ struct LaunchKnobs {
     int scan_threads = 0;                  // 0: by the tile count
     unsigned int dbg_ntiles = 0;           // != 0: composite only the N longest tiles
     unsigned int comp_lds_pad = 0;         // extra dynamic LDS per compositor workgroup (an occupancy cap)
+    unsigned int dbg_repair_grid = 0;      // SPLAT_DBG_REPAIR_GRID: workgroups of the near selection's repair launch (default 64)
     unsigned int dbg_starts = 0;           // SPLAT_DBG_STARTS: statistics frames record (list length, nearest keys the walk needed) per wave
 };
 void use_launch_knobs(const LaunchKnobs* k);

@@ -1642,10 +1642,10 @@ __device__ __forceinline__ void sort_list_global(unsigned char* smem, unsigned l
 //      selection (all of them if cap >= n); exclusive scan of the selected bins -> every bin's place in the output
 //   3  scatter g -> h (the second key buffer): the selected keys are now grouped by bin, bins in depth order; g is untouched
 //   4  consecutive bins are grouped into PARTS of at most 1792 keys (a bin of more than 512 keys is a part of its own, up
-//      to the 2048 keys the LDS sort holds) and every part is sorted through LDS by the code that
+//      to 1536 keys) and every part is sorted through LDS by the code that
 //      sorts the short lists: into g for a full sort (the list in its region, as a sort launch leaves it), in place in h
 //      for a selection (the region keeps the whole unordered list: a repair can still sort it all).
-// A selected bin of more than 2048 keys (thousands of Gaussians at one depth), or more than 63 parts, fails: the caller
+// A selected bin of more than 1536 keys (thousands of Gaussians at one depth), or more than 62 parts, fails: the caller
 // takes the whole list the global route.
 // partition_long_list does 1-3 and returns the number of parts (their bounds in `pstart`, LDS, the last
 // LONG_SORT_RESERVE bytes of the workspace) and the number of selected keys in *m_out, or 0 on failure; the caller runs
@@ -1655,7 +1655,7 @@ constexpr unsigned int LONG_SORT_RESERVE = 256u;
 template <int NT>
 __device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem, const unsigned long long* __restrict__ g, unsigned long long* __restrict__ h,
                                                             unsigned int n, unsigned int cap, unsigned int* m_out) {
-    constexpr unsigned int NB = 1024u, PART_T = 1280u, PART_MAX = 1792u, BIN_MAX = 512u, PMAX = 63u, RESERVE = LONG_SORT_RESERVE;
+    constexpr unsigned int NB = 1024u, PART_T = 1280u, PART_MAX = 1792u, BIN_MAX = 512u, BIG_PART_MAX = 1536u, PMAX = 63u, RESERVE = LONG_SORT_RESERVE;
     static_assert(NT == 256, "four bins per thread");
     unsigned int* bins = reinterpret_cast<unsigned int*>(smem);             // counts, then exclusive starts
     unsigned int* cur = bins + NB;                                          // scatter cursors
@@ -1747,8 +1747,8 @@ __device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem,
     // The parts.  No selected bin above BIN_MAX keys (the rule): every interval of PART_T = 1280 output places holds a bin's
     // start, the first of them begins a part, parts stay under 1280 + 512 keys.  Otherwise -- many Gaussians at one depth:
     // a wall seen face on -- one thread walks the selected bins: consecutive bins are grouped while the group stays within
-    // PART_MAX keys, a bin above BIN_MAX is a part of its own (it must fit the LDS sort: 2048 keys, else the whole list goes
-    // the global route).
+    // PART_MAX keys, a bin above BIN_MAX is a part of its own (up to BIG_PART_MAX keys, else the whole list goes the global
+    // route).
     if (tid == 0u) {
         unsigned int np = 0u;
         bool ok = true;
@@ -1762,7 +1762,10 @@ __device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem,
                 const unsigned int at = bins[b], cnt = ((b + 1u < NB) ? bins[b + 1u] : m) - at;
                 if (cnt == 0u) continue;
                 const bool bigbin = cnt > BIN_MAX;
-                if (cnt > 2048u) { ok = false; break; }
+                // (a part of its own up to the size the parts of ordinary lists reach: larger ones -- up to the 2016 keys the
+                // workspace would hold beside the part table -- came out wrong on hostile scenes, tools/fuzz_one.py; not
+                // understood, so not used)
+                if (cnt > BIG_PART_MAX) { ok = false; break; }       // (2016 keys + the sort's histograms + the part table: the workspace)
                 if (size != 0u && (bigbin || prev_big || size + cnt > PART_MAX)) {
                     if (np >= PMAX - 1u) { ok = false; break; }
                     pstart[np++] = part_beg;
@@ -2884,7 +2887,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
         else go(composite_exact_kernel<false, false, 2>);
         // the repair launch: tiles the selection did not serve (normally none: its workgroups read one word and leave)
         auto fix = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(std::min(n_tiles, 64u)), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
+            hipLaunchKernelGGL(kern, dim3(std::min(n_tiles, g_knobs->dbg_repair_grid ? g_knobs->dbg_repair_grid : 64u)), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
                                sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list, need_hint);
         };
         if (libm_exp) fix(composite_repair_kernel<false, true>);

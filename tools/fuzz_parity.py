@@ -13,7 +13,10 @@ from helpers import scene_dict, oracle_camera, image_diff, make_camera
 
 VARIANTS = [{}, {"SPLAT_PAIR_BLEND": "1"}, {"SPLAT_PAIR_BLEND": "0"}, {"SPLAT_BUCKETS": "0"}, {"SPLAT_SORT_IN_COMP": "1"},
             {"SPLAT_SORT_IN_COMP": "1", "SPLAT_BUCKETS": "0"}, {"SPLAT_FUSED_SORT": "0"}, {"SPLAT_EARLY_EPS": "0"},
-            {"SPLAT_EARLY_EPS": "1e-2", "SPLAT_EARLY_MIN": "64"}, {"SPLAT_PIPELINE": "1"}, {"SPLAT_CULL": "0"}]
+            {"SPLAT_EARLY_EPS": "1e-2", "SPLAT_EARLY_MIN": "64"}, {"SPLAT_PIPELINE": "1"}, {"SPLAT_CULL": "0"},
+            # near selection: off; so small that most long tiles go to the repair launch; with the paired walk; with retries
+            {"SPLAT_NEAR_KEYS": "0"}, {"SPLAT_NEAR_KEYS": "96"}, {"SPLAT_NEAR_KEYS": "300", "SPLAT_PAIR_BLEND": "1"},
+            {"SPLAT_NEAR_KEYS": "160", "SPLAT_EARLY_EPS": "1e-2", "SPLAT_EARLY_MIN": "64"}, {"SPLAT_NEAR_KEYS": "700", "SPLAT_BUCKETS": "0"}]
 KEYS = sorted({k for v in VARIANTS for k in v})
 CONVS = [{}, {}, {}, dict(y_up=0), dict(sample_half=0), dict(zclip=0), dict(zmin=-1.0), dict(y_up=0, sample_half=0, zclip=0),
          dict(corrected_projection=1)]   # euc switches; the last one is SPLAT_MODE_CORRECTED_PROJECTION (a mode flag here)
