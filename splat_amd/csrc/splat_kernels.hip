@@ -2637,7 +2637,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 // 21.5 KB of LDS, so that its workgroups find room beside a compositor in flight -- the sort launches it replaces need
 // 74 / 147 KB each and starve there).  A list of more than 2048 keys is NOT sorted: how many of its nearest keys the tile's
 // walks will need is known from the previous frame -- every wave leaves it in need_hint, four words per tile, plain
-// stores: 0 = nothing known, ~0 = more than it was given -- and the deepest of the four, half as much again, is
+// stores: 0 = nothing known, ~0 = more than it was given -- and the deepest of the four, with a margin, is
 // selected by depth and put in order:
 //   through LDS (select_near + the short lists' sort) while that fits the 2048-key workspace: the sorted selection goes
 //   to the START of the second key buffer's region, the region itself keeps the whole unordered list;
@@ -2660,8 +2660,11 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
     {
         const uint4 h4 = reinterpret_cast<const uint4*>(need_hint)[tile];
         deepest = (unsigned int)__builtin_amdgcn_readfirstlane((int)max(max(h4.x, h4.y), max(h4.z, h4.w)));
+        // (While the hint leaves room, the selection is the full workspace: this kernel runs beside the previous frame's
+        // compositor, its time is hidden, and a moving camera puts other Gaussians under the tile than the hint saw -- a
+        // 36-pose orbit, 10 degrees a frame, lost a third of its rate to repairs with selections sized tightly.)
         if (deepest == 0xffffffffu) want = n;
-        else if (deepest != 0u) want = max(768u, deepest + (deepest >> 1) + 128u);
+        else if (deepest != 0u) want = (deepest + (deepest >> 1) + 128u <= near_cap) ? near_cap : 2u * deepest + 256u;
         if (want > n - (n >> 2)) want = n;      // (three quarters of the list: the whole list, then, and no repair to fear)
     }
     unsigned int m = 0u;
