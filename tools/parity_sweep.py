@@ -32,7 +32,8 @@ for pos, yaw, pitch in poses:
     mx, cnt = image_diff(img, ref)
     row = dict(pos=pos, yaw=round(yaw, 3), pitch=pitch, n_visible=int(st.n_visible), n_pairs=int(st.n_pairs),
                pairs_equal=bool(st.n_pairs == ost.n_tile_pairs and st.n_visible == ost.n_visible),
-               max_tile_len=int(st.max_tile_len), binning_mode=R.binning_mode(), max_channel_diff_lsb=int(mx),
+               max_tile_len=int(st.max_tile_len), binning_mode=R.binning_mode(), near_selection_tiles=int(st.n_near_tiles),
+               near_selection_repaired=int(st.n_near_fallback), max_channel_diff_lsb=int(mx),
                pixels_differing=int(cnt), pixels=W * H, oracle_s=round(time.time() - t0, 2))
     rows.append(row)
     print(row, flush=True)
