@@ -235,6 +235,14 @@ int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
                                             farther on all but a few tiles, which sort their whole list after all (stats:
                                             n_near_tiles, n_near_fallback); 64..2048, 0 = off: every long list is sorted in full
                                             (default 2048; SPLAT_NEAR_KEYS)                                                      */
+#define SPLAT_OPT_OVERFLOW_REDO 17       /* a frame whose camera differs from the one its tile regions were sized for carries a
+                                            second binning behind its scan -- launches that leave at once unless a list outgrew its
+                                            region -- so that such a frame is binned again ON THE DEVICE instead of being skipped and
+                                            reported (SPLAT_ERR_CAPACITY at the next splat_sync).  0 = off; 1 = adaptive (default):
+                                            only while a list has outgrown its region within the last 256 frames -- a scene that
+                                            never does pays nothing, the first such frame after a quiet stretch is skipped and
+                                            reported as before and arms the redo; 2 = on every frame of a moving camera (five
+                                            near-empty launches per frame on the binning stream).  SPLAT_OVERFLOW_REDO           */
 int splat_set_option(splat_ctx* ctx, int32_t option, double value);
 int splat_get_option(const splat_ctx* ctx, int32_t option, double* value);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */

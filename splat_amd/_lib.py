@@ -118,6 +118,7 @@ OPT_FAST_CLOSE_WIDTH = 13
 OPT_PRIORITY_LIST_LEN = 14
 OPT_FRAME_OVERLAP = 15
 OPT_NEAR_SELECT_KEYS = 16
+OPT_OVERFLOW_REDO = 17
 
 _LIB = None
 

@@ -53,6 +53,12 @@ struct Slot {                  // everything one frame writes before the image
     unsigned int* cursor = nullptr;
     unsigned int* order = nullptr;
     unsigned int* lens = nullptr;           // list length per tile (the list starts at offsets[tile])
+    // Binning again on the device (overflow redo): counters, regions and cursors of a frame whose lists outgrew the regions
+    // it was given -- its count pass and second binning pass write here, not into the copies the pipeline hands on
+    unsigned int* redo_counts = nullptr;
+    unsigned int* redo_layout = nullptr;
+    unsigned int* redo_cursors = nullptr;
+    uint64_t layout_cam[2] = {0, 0};        // per copy of the layout: a hash of the camera whose lists sized it
     unsigned int* near_m = nullptr;         // near selection: per tile, how many of its list's nearest keys launch_select put in order
     unsigned int* repair_mask = nullptr;    // ... the waves whose walk needed more than that
     unsigned int* repair_list = nullptr;    // ... and the tiles (slots of `order`) the repair launch takes again
@@ -176,6 +182,15 @@ struct splat_ctx {
     // tile's compositor workgroup selects the nearest <= near_cap keys by depth and sorts those -- the exact early-out never
     // looks farther on all but a few tiles, which then sort their whole list after all.  No sort launches in such frames.
     unsigned int near_cap = 2048;
+    // Overflow redo (SPLAT_OVERFLOW_REDO / SPLAT_OPT_OVERFLOW_REDO, default on): a frame whose camera differs from the one its
+    // tile regions were sized for carries a second binning (count pass, exact regions, K1, scan) behind its scan, as launches
+    // that leave at once unless that scan found a tile beyond its region -- such a frame is binned again on the device
+    // instead of being skipped, reported and rendered again by the caller.
+    // 0 = off; 1 = ADAPTIVE (default): the redo launches ride on moving frames only while a list has outgrown its region within
+    // the last 256 frames (a scene that never does -- most -- pays nothing; the first such frame after a quiet stretch is
+    // skipped and reported as before, and arms the redo); 2 = on every moving frame.
+    int overflow_redo = 1;
+    int redo_armed = 0;                    // moving frames left that still carry the redo launches (adaptive)
     unsigned int* need_hint = nullptr;     // 4 x m_alloc words: per tile and wave, the nearest keys its walk needed in the most recent frame
     bool last_near = false;                // the most recent frame ran with near selection: its long lists are unordered in memory
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
@@ -338,6 +353,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow) c->frames_dropped++;
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) c->bucket_overflow = true;           // a tile's list outgrew its region: the layouts are stale
+    if (st.overflow == 2 || st.pad_ == 1u) c->redo_armed = 256;  // ... or did and was binned again on the device: keep the redo launches on
     if (st.layout_total > c->cap) c->layout_want = std::max<uint64_t>(c->layout_want, st.layout_total);   // the regions were cut off
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
@@ -416,9 +432,12 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
-        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m);
+        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_counts); dfree(s.redo_layout); dfree(s.redo_cursors);
         s.layout_valid = false; s.flip = 0;
         HIP_TRY(c, dmalloc(c, &s.near_m, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.redo_counts, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.redo_layout, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, dmalloc(c, &s.redo_cursors, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.repair_mask, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.repair_list, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.counts_b, sizeof(unsigned int) * (size_t)(m + 1)));
@@ -508,6 +527,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->early_scan8 = c->early_scan8;
     fc->bucket_cap = 0;
     fc->corrected = (c->cfg.mode & SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
+    fc->redo_only = 0;
     // (a singular cov2d needs lowpass == 0 or a non-PSD cov3d; with lowpass == 0 every Gaussian is
     // looked at so that n_singular stays what the reference would have panicked on)
     fc->cull_blocks = (c->cull_blocks && c->bounds && cam->lowpass > 0.0f) ? 1 : 0;
@@ -564,15 +584,27 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // frames, a new scene / target / slab, after a frame outgrew a region) counts its pairs first -- K1 against the
     // empty layout drops every key and counts every pair -- and builds regions that fit exactly this camera.
     unsigned int *cursors = s.counts, *layout = nullptr;
+    // (a hash of what places the Gaussians on the target: the camera and the slab.  A frame binned into regions sized under the
+    // SAME hash cannot outgrow them -- the lists are the same lists)
+    uint64_t cam_hash = 1469598103934665603ull;
+    {
+        auto mix = [&](const void* p, size_t nbytes) { const unsigned char* b = (const unsigned char*)p; for (size_t q = 0; q < nbytes; ++q) { cam_hash ^= b[q]; cam_hash *= 1099511628211ull; } };
+        mix(c->fc.view, sizeof c->fc.view); mix(c->fc.proj, sizeof c->fc.proj); mix(&c->fc.w, sizeof(float) * 5); mix(c->fc.cam, sizeof c->fc.cam);
+        mix(&c->fc.lowpass, sizeof(float)); mix(&c->fc.tile_row0, sizeof(int) * 2);
+        if (cam_hash == 0) cam_hash = 1;
+    }
+    bool moved = false;
     if (c->fc.bucket_cap) {
         if (!s.layout_valid) {
             HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));
             launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout);
             launch_layout(bs, m, s.counts, c->zero_layout, s.lay_b, s.counts_b, c->fc.bucket_cap, nullptr, nullptr, c->region_spare);
             s.flip = 1; s.layout_valid = true;
+            s.layout_cam[1] = cam_hash;
         }
         cursors = s.flip ? s.counts_b : s.counts;
         layout = s.flip ? s.lay_b : s.lay_a;
+        moved = s.layout_cam[s.flip] != cam_hash;
     }
     HIP_TRY(c, mark(0, bs));
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, layout);
@@ -599,11 +631,29 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         const int into = (&nx == &s) ? (s.flip ^ 1) : (nx.layout_valid ? (nx.flip ^ 1) : 1);
         next_layout = into ? nx.lay_b : nx.lay_a; next_counts = into ? nx.counts_b : nx.counts;
         nx.flip = into; nx.layout_valid = true;
+        nx.layout_cam[into] = cam_hash;
     }
     const bool comp_sorts_frame = compositor_sorts_long_lists(c, m) && s.keys2 != nullptr;
     const unsigned int near_cap = (comp_sorts_frame && near_selection_for_frame(c)) ? c->near_cap : 0u;
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
                 next_layout, next_counts, c->region_spare, near_cap ? s.repair_mask : nullptr);
+    const bool redo = c->fc.bucket_cap && moved && (c->overflow_redo >= 2 || (c->overflow_redo == 1 && c->redo_armed > 0));
+    if (redo && c->redo_armed > 0) --c->redo_armed;
+    if (redo) {
+        // OVERFLOW REDO.  The regions this frame was binned into were sized for another camera (two frames back on a moving
+        // path): if the scan above found a list beyond its region, the frame is binned again right here -- count pass
+        // against the empty layout, regions that fit exactly this camera, K1, scan -- into copies of their own; if not
+        // (the usual case) every one of these launches reads one word and leaves.  Either way the kernels behind see a
+        // complete frame: nothing is skipped, nothing to report, nothing for the caller to render again.
+        FrameConst fr = c->fc;
+        fr.redo_only = 1;
+        HIP_TRY(c, hipMemsetAsync(s.redo_counts, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));
+        launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_counts, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout);
+        launch_layout(bs, m, s.redo_counts, c->zero_layout, s.redo_layout, s.redo_cursors, c->fc.bucket_cap, nullptr, nullptr, c->region_spare, d_st);
+        launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, s.redo_layout);
+        launch_scan(bs, m, s.redo_cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], s.redo_layout,
+                    nullptr, nullptr, c->region_spare, near_cap ? s.repair_mask : nullptr, true);
+    }
     HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
         HIP_TRY(c, hipEventRecord(s.ev_binned, bs));
@@ -940,6 +990,7 @@ bool store_option(splat_ctx* c, int opt, double v) {
         case SPLAT_OPT_PRIORITY_LIST_LEN: if (v < 1.0 || v > 1073741823.0) return false; c->prio_len = (int)v; return true;
         case SPLAT_OPT_FRAME_OVERLAP: if (v != 1.0 && v != 2.0) return false; c->overlap = (int)v; return true;    // (lanes: splat_set_option / splat_create make them)
         case SPLAT_OPT_NEAR_SELECT_KEYS: if (v != 0.0 && (v < 64.0 || v > 2048.0)) return false; c->near_cap = (unsigned int)v; return true;
+        case SPLAT_OPT_OVERFLOW_REDO: if (v != 0.0 && v != 1.0 && v != 2.0) return false; c->overflow_redo = (int)v; return true;
         default: return false;
     }
 }
@@ -961,6 +1012,7 @@ bool load_option(const splat_ctx* c, int opt, double* v) {
         case SPLAT_OPT_PRIORITY_LIST_LEN: *v = c->prio_len; return true;
         case SPLAT_OPT_FRAME_OVERLAP: *v = c->overlap; return true;
         case SPLAT_OPT_NEAR_SELECT_KEYS: *v = c->near_cap; return true;
+        case SPLAT_OPT_OVERFLOW_REDO: *v = c->overflow_redo; return true;
         default: return false;
     }
 }
@@ -1031,6 +1083,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     option_from_env(c, SPLAT_OPT_PAIR_WALK, "SPLAT_PAIR_BLEND", -1, 1);
     if (const char* e6 = std::getenv("SPLAT_BUCKET_BYTES")) { c->bucket_bytes = std::strtoull(e6, nullptr, 10); c->env_pinned |= 1u << SPLAT_OPT_KEY_BUFFER_BYTES; }
     option_from_env(c, SPLAT_OPT_REGION_SPARE, "SPLAT_REGION_SPARE", 1, 1e9);
+    if (const char* er = std::getenv("SPLAT_OVERFLOW_REDO")) { c->overflow_redo = std::min(2, std::max(0, std::atoi(er))); c->env_pinned |= 1u << SPLAT_OPT_OVERFLOW_REDO; }
     if (const char* en = std::getenv("SPLAT_NEAR_KEYS")) {
         const int v = std::atoi(en);
         c->near_cap = v <= 0 ? 0u : (unsigned int)std::min(2048, std::max(64, v));
@@ -1093,7 +1146,7 @@ void splat_destroy(splat_ctx* c) {
     dfree(c->zero_layout); dfree(c->need_hint);
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
-        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m);
+        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_counts); dfree(s.redo_layout); dfree(s.redo_cursors);
         dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
         if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);

@@ -42,6 +42,7 @@ struct FrameConst {
     unsigned int bucket_cap; // one-pass binning: entries of the key buffer the tiles' regions live in (0: two-pass binning with exact lists)
     int corrected;         // SPLAT_MODE_CORRECTED_PROJECTION: J enters transposed (perspective-shear terms kept)
     int cull_blocks;       // K1 skips 256-Gaussian blocks whose bounds cannot reach the slab (needs lowpass > 0)
+    int redo_only;         // K1 as a REDO launch: leaves at once unless the frame's scan flagged a tile that outgrew its region
 };
 
 // Upload-time bounds of one K1 block (256 consecutive slots of the Morton-ordered scene): the AABB
@@ -105,11 +106,13 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  unsigned int* next_layout = nullptr, unsigned int* next_counts = nullptr /* both given: a second workgroup of
                      the launch builds the regions + cursors of the next frame on this stream (see launch_layout) */,
                  float spare_max = 4.0f /* how far a region may grow into the buffer's spare room */,
-                 unsigned int* repair_mask = nullptr /* near selection: per-tile words the scan zeroes for the compositor */);
+                 unsigned int* repair_mask = nullptr /* near selection: per-tile words the scan zeroes for the compositor */,
+                 bool redo_only = false /* the second scan of a frame binned again on the device: nothing unless status->overflow == 2 */);
 // the regions (and cursors) of the slot's next one-pass frame from this frame's lists; an all-zero `layout` with cursors
 // counted from zero is the bootstrap
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
-                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max = 4.0f);
+                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max = 4.0f,
+                   const FrameStatus* redo_gate = nullptr /* != nullptr: a redo launch -- does nothing unless redo_gate->overflow == 2 */);
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 // grid_big / grid_mid: how many entries of `order` (longest lists first) the 1024- and 512-thread

@@ -694,6 +694,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
     // K1 is a chain of dependent phases with little arithmetic in each; beside the compositor's
     // throughput-bound waves every one of its instructions queued behind theirs.  One priority step above the
     // compositor's default: K1 0.38 -> 0.32 ms inside the pipeline, +4 % frames/s on C3.
+    // (the REDO launches behind a frame's scan -- count pass and second binning pass of a frame whose lists outgrew regions
+    // sized from earlier frames -- leave at once unless that scan said so)
+    if (fc.redo_only && status->overflow != 2u) return;
     __builtin_amdgcn_s_setprio(1);
 #if SPLAT_K1X == 30 || SPLAT_K1X == 31
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(depth) + ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u;
@@ -1109,8 +1112,10 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
 __global__ __launch_bounds__(1024) void layout_kernel(unsigned int m, const unsigned int* __restrict__ counts,
                                                       const unsigned int* __restrict__ layout, unsigned int* __restrict__ next_layout,
                                                       unsigned int* __restrict__ next_counts, unsigned int key_entries,
-                                                      FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status, float spare_max) {
+                                                      FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status, float spare_max,
+                                                      const FrameStatus* __restrict__ redo_gate) {
     __shared__ unsigned long long wsum[16];
+    if (redo_gate != nullptr && redo_gate->overflow != 2u) return;        // (a redo launch of a frame that needs none)
     build_layout<1024>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, wsum, spare_max);
 }
 
@@ -1129,8 +1134,10 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
                                                            unsigned int cls_in_lds, FrameStatus* __restrict__ host_status,
                                                            unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
-                                                           unsigned int key_entries, float spare_max, unsigned int* __restrict__ repair_mask) {
+                                                           unsigned int key_entries, float spare_max, unsigned int* __restrict__ repair_mask,
+                                                           unsigned int redo_only) {
     constexpr int NCLS = 64;
+    if (redo_only && status->overflow != 2u) return;       // (the second scan of a frame that was binned again: see enqueue_frame)
     // Workgroup 1 of the launch (when there is one) builds the regions of the next frame on this binning stream from
     // the same cursors, beside the scan: no launch of its own, nothing added to the chain K1 -> scan -> sort.
     if (blockIdx.x == 1u) {
@@ -1221,7 +1228,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
         status->n_visible = 0; status->n_singular = 0;
         status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
-        status->pad_ = 0; status->n_blocks_culled = 0;
+        status->pad_ = redo_only ? 1u : 0u;    // (1: this frame outgrew its regions and was binned again on the device)
+        status->n_blocks_culled = 0;
         // ... and delivers it to the host: everything an asynchronous frame reports is decided here (layout_total, the
         // last word, belongs to the workgroup that builds the layout: both copies are its to write)
         if (host_status) {
@@ -2742,6 +2750,9 @@ __global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, co
     if (status->overflow) return;
     const unsigned int count = status->n_near_fallback;
     if (blockIdx.x >= count) return;
+    // (a repair is pure latency on the frame -- a handful of workgroups, the next frame's compositor waits behind them, the chip
+    // is busy with the next frames' binning: their waves go first)
+    __builtin_amdgcn_s_setprio(3);
     if constexpr (LIBM) {
         if (threadIdx.x < 32) exptab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
         __syncthreads();
@@ -2805,7 +2816,7 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
                  FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts, float spare_max,
-                 unsigned int* repair_mask) {
+                 unsigned int* repair_mask, bool redo_only) {
     if (bucket_cap && layout)
     {
         const unsigned int nwg = (next_layout && next_counts) ? 2u : 1u;
@@ -2816,21 +2827,22 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         const unsigned int dyn = in_lds ? cls_bytes : 0u;
         if (nt == 256)
             hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(nwg), dim3(256), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask, redo_only ? 1u : 0u);
         else if (nt == 512)
             hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(nwg), dim3(512), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask, redo_only ? 1u : 0u);
         else
             hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(nwg), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask, redo_only ? 1u : 0u);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
                            bucket_cap, grid_big, grid_mid, grid_long, host_status, repair_mask);
 }
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
-                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max) {
-    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max);
+                   unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max,
+                   const FrameStatus* redo_gate) {
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max, redo_gate);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {

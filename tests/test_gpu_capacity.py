@@ -35,6 +35,9 @@ def scene_and_poses():
         os.environ.pop("SPLAT_REGION_SPARE", None)
         if saved is not None:
             os.environ["SPLAT_REGION_SPARE"] = saved
+    # (the device-side redo of such frames -- SPLAT_OPT_OVERFLOW_REDO, on by default -- is switched off here: these tests are
+    # about what happens when a frame IS skipped; test_overflowing_async_frame_is_binned_again_on_the_device has it on)
+    r.set_option(_lib.OPT_OVERFLOW_REDO, 0)
     g = splat_amd.synthetic_scene(120000, 71)
     g.compute_cov3d(r)
     near = make_camera(256, 256, (0.0, 0.0, 5.0))
@@ -118,6 +121,56 @@ def test_streamed_frame_that_overflows_is_redone_by_the_wait(scene_and_poses):
     ref_near, _ = oracle_frame(g, near)
     assert image_diff(np.array(f1), ref_far)[0] <= 1 and np.array(f1).any()
     assert image_diff(np.array(f0), ref_near)[0] <= 1
+
+
+def test_overflowing_async_frame_is_binned_again_on_the_device(scene_and_poses):
+    """Overflow redo (the default): an ASYNCHRONOUS frame whose lists outgrow the regions sized for an earlier camera is
+    binned again on the device -- count pass, exact regions, K1, scan, all behind its own scan -- instead of being
+    skipped: nothing dropped, nothing reported, the image is the oracle's.  In/out blending onto a non-zero image (a
+    frame must blend exactly once), several such frames in flight, and the near pose again afterwards."""
+    r, g, near, far = scene_and_poses
+    r.set_option(_lib.OPT_OVERFLOW_REDO, 2)                    # on every frame of a moving camera (the default arms itself on the first miss)
+    rng = np.random.default_rng(6)
+    init = rng.integers(0, 2**32, (256, 256), dtype=np.uint64).astype(np.uint32)
+    a, b, c = r.device_image(init), r.device_image(init), r.device_image(init)
+    r.render_device(near.to_c(0.01), a, sync=True)
+    assert r.binning_mode() > 0, "one-pass binning expected"
+    d0 = r.frames_dropped()
+    r.render_device(far.to_c(0.01), b, sync=False)            # outgrows its regions: binned again, not skipped
+    r.render_device(near.to_c(0.01), c, sync=False)
+    r.sync()                                                  # nothing to report
+    assert r.frames_dropped() == d0
+    ref_far, _ = oracle_frame(g, far, init)
+    ref_near, _ = oracle_frame(g, near, init)
+    assert image_diff(r.device_download(b, 256, 256), ref_far)[0] <= 1
+    assert image_diff(r.device_download(c, 256, 256), ref_near)[0] <= 1
+    # cleared frames alternating between the two poses, all in flight
+    clear_far, _ = oracle_frame(g, far)
+    clear_near, _ = oracle_frame(g, near)
+    for k in range(8):
+        r.render_frame_device((far if k % 2 else near).to_c(0.01), b if k % 2 else c)
+    r.sync()
+    assert r.frames_dropped() == d0
+    assert image_diff(r.device_download(b, 256, 256), clear_far)[0] <= 1
+    assert image_diff(r.device_download(c, 256, 256), clear_near)[0] <= 1
+    # the default (adaptive): quiet so far, the first far frame is skipped and reported as before -- and arms the redo: the next is not
+    r.set_option(_lib.OPT_OVERFLOW_REDO, 1)
+    wiggle = [near.to_c(0.01), make_camera(256, 256, (0.0, 0.0, 5.001)).to_c(0.01), make_camera(256, 256, (0.0, 0.0, 5.002)).to_c(0.01)]
+    for k in range(300):                                      # (256 moving frames disarm; a still camera never counts)
+        r.render_frame_device(wiggle[k % 3], c)
+    r.sync()
+    d1 = r.frames_dropped()
+    r.render_frame_device(far.to_c(0.01), b)
+    with pytest.raises(SplatError):
+        r.sync()
+    assert r.frames_dropped() == d1 + 1
+    r.render_frame_device(near.to_c(0.01), c)
+    r.render_frame_device(far.to_c(0.01), b)
+    r.sync()
+    assert r.frames_dropped() == d1 + 1
+    assert image_diff(r.device_download(b, 256, 256), clear_far)[0] <= 1
+    for p in (a, b, c):
+        r.device_free(p)
 
 
 def test_sort_launch_miss_with_tight_grids():

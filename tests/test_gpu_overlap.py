@@ -215,6 +215,15 @@ def test_gather_follows_its_frame_on_either_lane(scene):
                     continue
                 for k in (k0, k0 + 1):
                     assert np.array_equal(r.device_download(imgs[k % 2], H, W), want[k]), (rep, k)
+        # ... and a download right behind a gather, with no sync in between (the copy entry points follow the
+        # frame's "ended" event, which the gather now re-records behind itself -- on whichever lane the frame ran)
+        for k in (0, 1, 2, 3):
+            r.render_frame_device(cams[k], imgs[k % 2])
+            r.comm_gather(imgs[k % 2], W, H, 0)
+            got = r.device_download(imgs[k % 2], H, W)
+            if r.frames_dropped() == 0:
+                assert np.array_equal(got, want[k]), k
+        settled(r)
         for d in imgs:
             r.device_free(d)
     finally:
