@@ -490,6 +490,7 @@ def main():
     if swap_chain:
         images.append(torch.zeros((H, W), dtype=torch.int32, device="cuda"))
         R.set_frame_overlap(2)
+    torch.cuda.synchronize()           # (the fills run on torch's default stream, the frames on `stream`)
 
     frame_no = [0]
 
@@ -604,6 +605,7 @@ def main():
             # Nothing for a frame that fills the chip (C3, C5); a frame bound by its densest tile's lone wave (C1, C2, a
             # multi-GPU slab) runs a third faster.  Both images must hold the frame `value` rendered.
             image2 = torch.zeros_like(image)
+            torch.cuda.synchronize()   # (fill on the default stream, frames on the context's)
             R.set_frame_overlap(2)
             pair = (image, image2)
             for k in range(20):
@@ -711,6 +713,8 @@ def main():
         # the gathered frame must equal the frame this rank renders alone, byte for byte
         R.set_slab(0, -1)
         full = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()       # (the fill runs on torch's default stream, the frame on `stream`: without this the fill
+                                       # may land in the middle of the frame -- seen once in ~30 runs with eight ranks on one GPU)
         with torch.cuda.stream(stream):
             R.render_device(last_pose, full.data_ptr(), sync=True)
         torch.cuda.synchronize()

@@ -665,7 +665,8 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     HIP_TRY(c, mark(3, ss));
     const bool comp_sorts = comp_sorts_frame;
     if (near_cap)       // near selection: the nearest keys of the long lists instead of the sort launches
-        launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m);
+        launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m,
+                      (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows);
     else if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));

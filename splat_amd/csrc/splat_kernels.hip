@@ -2653,11 +2653,15 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 //   selection would be most of the list anyway, is sorted in full, in its region, as a sort launch would leave it.
 // near_m[tile] = how many of the nearest keys are in order (== the list's length: all of them).  A wrong guess costs time
 // only -- a larger sort than necessary, or the compositor's repair launch -- never a pixel.
+#ifndef SPLAT_HINT_RADIUS
+#define SPLAT_HINT_RADIUS 2
+#endif
 __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
                                                           const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
                                                           unsigned long long* __restrict__ keys2, FrameStatus* __restrict__ status,
                                                           const unsigned int* __restrict__ orig, unsigned int radix_min, unsigned int near_cap,
-                                                          const unsigned int* __restrict__ need_hint, unsigned int* __restrict__ near_m) {
+                                                          const unsigned int* __restrict__ need_hint, unsigned int* __restrict__ near_m,
+                                                          unsigned int tiles_x, unsigned int tile_rows) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
     const unsigned int tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);
@@ -2666,8 +2670,37 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
     const unsigned int beg = (unsigned int)__builtin_amdgcn_readfirstlane((int)offsets[tile]);
     unsigned int want = near_cap, deepest;
     {
-        const uint4 h4 = reinterpret_cast<const uint4*>(need_hint)[tile];
-        deepest = (unsigned int)__builtin_amdgcn_readfirstlane((int)max(max(h4.x, h4.y), max(h4.z, h4.w)));
+        // ONE wave reads the hints and the workgroup takes its word for them: the previous frames' compositors are storing
+        // into these words while this kernel runs (frames overlap on the device), and four waves that each read for
+        // themselves can disagree -- on which path to take through the barriers below.
+        unsigned int* const word = reinterpret_cast<unsigned int*>(smem);
+        if (threadIdx.x < 64u) {
+            const uint4 h4 = reinterpret_cast<const uint4*>(need_hint)[tile];
+            unsigned int d0 = max(max(h4.x, h4.y), max(h4.z, h4.w));
+#if SPLAT_HINT_RADIUS > 0
+            // ... and the tiles around it (a camera in motion carries a deep spot of the image from tile to tile: what the
+            // neighbours' walks needed last frame is what this tile's may need now).  A neighbour that ran out (~0) says nothing.
+            {
+                constexpr int D = 2 * SPLAT_HINT_RADIUS + 1;
+                const int lane = (int)threadIdx.x;
+                const int tx = (int)(tile % tiles_x) + lane % D - SPLAT_HINT_RADIUS, ty = (int)(tile / tiles_x) + lane / D - SPLAT_HINT_RADIUS;
+                unsigned int nb = 0u;
+                if (lane < D * D && tx >= 0 && ty >= 0 && tx < (int)tiles_x && ty < (int)tile_rows) {
+                    const uint4 q = reinterpret_cast<const uint4*>(need_hint)[(unsigned int)ty * tiles_x + (unsigned int)tx];
+                    const unsigned int a = q.x == 0xffffffffu ? 0u : q.x, b = q.y == 0xffffffffu ? 0u : q.y;
+                    const unsigned int cc = q.z == 0xffffffffu ? 0u : q.z, d = q.w == 0xffffffffu ? 0u : q.w;
+                    nb = max(max(a, b), max(cc, d));
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) nb = max(nb, (unsigned int)__shfl_xor((int)nb, o));
+                d0 = max(d0, nb);           // (~0 stays ~0)
+            }
+#endif
+            if (threadIdx.x == 0u) word[0] = d0;
+        }
+        __syncthreads();
+        deepest = (unsigned int)__builtin_amdgcn_readfirstlane((int)word[0]);
+        __syncthreads();                    // (the workspace is the selection's from here on)
         // (While the hint leaves room, the selection is the full workspace: this kernel runs beside the previous frame's
         // compositor, its time is hidden, and a moving camera puts other Gaussians under the tile than the hint saw -- a
         // 36-pose orbit, 10 degrees a frame, lost a third of its rate to repairs with selections sized tightly.)
@@ -2875,10 +2908,10 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 }
 void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
                    unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
-                   const unsigned int* need_hint, unsigned int* near_m) {
+                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows) {
     if (!n_tiles) return;
     hipLaunchKernelGGL(select_near_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, order, lens, keys, keys2, status, orig, sort_radix_min(),
-                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m);
+                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
