@@ -555,6 +555,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     auto mark = [&](int k, hipStream_t st) -> hipError_t { return timed ? hipEventRecord(ev.e[k], st) : hipSuccess; };
     c->ring_next = (c->ring_next + 1) % EV_RING;
     harvest(c, r);
+    std::memset(&c->h_status[r], 0, sizeof(FrameStatus));      // (this frame's scan fills it; until then it says nothing: see the peek below)
     const int si = (int)(c->frame_idx++ % (uint64_t)slots_in_use(c));
     Slot& s = c->slots[si];
     FrameStatus* const d_st = c->d_status_ring + r;       // (initialised by this frame's scan)
@@ -637,6 +638,16 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const unsigned int near_cap = (comp_sorts_frame && near_selection_for_frame(c)) ? c->near_cap : 0u;
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
                 next_layout, next_counts, c->region_spare, near_cap ? s.repair_mask : nullptr);
+    if (c->fc.bucket_cap && moved && c->overflow_redo == 1 && c->redo_armed < 128) {
+        // A frame still in flight that outgrew a region (or was binned again): its scan has written that to the host
+        // already -- a peek, no wait; the harvest proper comes when the ring wraps, 32 frames on -- and the frames of this
+        // path carry the redo launches from here on, not from 32 lost frames later.
+        for (int q = 0; q < EV_RING; ++q) {
+            if (!c->ring[q].used || q == r) continue;
+            const volatile FrameStatus* hs = &c->h_status[q];
+            if (hs->overflow == 2u || hs->pad_ == 1u) { c->redo_armed = 256; break; }
+        }
+    }
     const bool redo = c->fc.bucket_cap && moved && (c->overflow_redo >= 2 || (c->overflow_redo == 1 && c->redo_armed > 0));
     if (redo && c->redo_armed > 0) --c->redo_armed;
     if (redo) {
@@ -1126,7 +1137,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     }
     if ((e = dmalloc(c, &c->d_status_ring, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMalloc(status ring)", e);
     if ((e = hipMemset(c->d_status_ring, 0, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMemset(status ring)", e);
-    if ((e = hipHostMalloc(&c->h_status, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipHostMalloc(status)", e);
+    if ((e = hipHostMalloc(&c->h_status, sizeof(FrameStatus) * EV_RING, hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc(status)", e);
     std::memset(c->h_status, 0, sizeof(FrameStatus) * EV_RING);
     for (auto& s : c->ring)
         for (auto& ev : s.e)

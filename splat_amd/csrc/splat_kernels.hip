@@ -1045,13 +1045,13 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
     // (the frame's chain K1 -> scan -> sort) ends when this workgroup does.
     constexpr unsigned int KEEP = 32u;
     const bool keep = C <= KEEP;
-    unsigned int kept[KEEP];
+    unsigned int kept[KEEP];                       // the tiles' list lengths
     bool loaded = false;
-    auto sum_regions = [&](auto&& each) {
+    auto each_len = [&](auto&& each) {
         if (keep) {
             if (!loaded) {
 #pragma unroll
-                for (unsigned int u = 0; u < KEEP; ++u) { const unsigned int k = k0 + u; kept[u] = k < k1 ? region_for(counts[k] - layout[k]) : 0u; }
+                for (unsigned int u = 0; u < KEEP; ++u) { const unsigned int k = k0 + u; kept[u] = k < k1 ? counts[k] - layout[k] : 0u; }
                 loaded = true;
             }
 #pragma unroll
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
 #pragma unroll
             for (unsigned int u = 0; u < 8u; ++u) { const unsigned int k = kb + u; c[u] = k < k1 ? counts[k] : 0u; l[u] = k < k1 ? layout[k] : 0u; }
 #pragma unroll
-            for (unsigned int u = 0; u < 8u; ++u) if (kb + u < k1) each(kb + u, region_for(c[u] - l[u]));
+            for (unsigned int u = 0; u < 8u; ++u) if (kb + u < k1) each(kb + u, c[u] - l[u]);
         }
     };
     // block-wide exclusive scan of one value per thread (and the total); two barriers
@@ -1083,24 +1083,35 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
         for (unsigned int w = 0; w < NT / 64u; ++w) { const unsigned long long x = wsum[w]; total += x; if (w < wave) run += x; }
         return run;
     };
-    unsigned long long local = 0, total = 0;
-    sum_regions([&](unsigned int, unsigned int r) { local += r; });
-    (void)block_scan(local, total);
+    // (two sums in one scan: what the regions ask for, and what the lists themselves take -- a list rounded up to 64 keys --
+    // in units of 64 keys, 32 bits each: 2^38 keys)
+    auto exact_for = [](unsigned int len) -> unsigned int { return (len + 63u) & ~63u; };
+    unsigned long long local = 0, both = 0;
+    each_len([&](unsigned int, unsigned int len) { local += ((unsigned long long)(region_for(len) >> 6) << 32) | (unsigned long long)(exact_for(len) >> 6); });
+    (void)block_scan(local, both);
+    const unsigned long long total = (both >> 32) << 6, total_exact = (both & 0xffffffffull) << 6;
     // The buffer is there: what the regions do not ask for is handed out in proportion (up to four times a region's
     // size), so that a camera that jumps finds room in the tiles its lists move to -- a frame that outgrows a region is
-    // skipped and redone, or lost if it was asynchronous.  C3: 24 M entries for regions that ask for 16 M.
+    // binned again (the redo launches), or skipped and redone, or lost if it was asynchronous.  C3: 24 M entries for
+    // regions that ask for 16 M.  Regions that ask for MORE than the buffer holds, while the lists themselves fit, give up
+    // their margins in proportion instead of being cut off: this frame has room for every key (the next one is more
+    // likely to be binned again), and layout_total tells the host what a buffer with the full margins takes.
     const float spare = total ? fminf(spare_max, (float)key_entries / (float)total) : 1.0f;
-    auto grown = [&](unsigned int r) -> unsigned int {
+    const bool squeeze = total > (unsigned long long)key_entries && total_exact <= (unsigned long long)key_entries;
+    const float keep_frac = squeeze ? (float)((unsigned long long)key_entries - total_exact) / (float)(total - total_exact) * (1.0f - 1.0f / 1048576.0f) : 0.0f;
+    auto grown = [&](unsigned int len) -> unsigned int {
+        const unsigned int r = region_for(len);
+        if (squeeze) { const unsigned int e = exact_for(len); return e + ((unsigned int)((float)(r - e) * keep_frac) & ~63u); }   // (rounded down: the sum stays within key_entries)
         return spare > 1.0f ? max(r, (unsigned int)((float)r * spare) & ~63u) : r;    // (the sum stays within key_entries: every term is rounded down)
     };
     local = 0;
-    sum_regions([&](unsigned int, unsigned int r) { local += grown(r); });
+    each_len([&](unsigned int, unsigned int len) { local += grown(len); });
     unsigned long long dummy;
     unsigned long long run = block_scan(local, dummy);
-    sum_regions([&](unsigned int k, unsigned int r) {
+    each_len([&](unsigned int k, unsigned int len) {
         const unsigned int off = (unsigned int)min(run, (unsigned long long)key_entries);
         next_layout[k] = off; next_counts[k] = off;
-        run += grown(r);
+        run += grown(len);
     });
     if (tid == NT - 1u) next_layout[m] = (unsigned int)min(run, (unsigned long long)key_entries);      // (the last thread's run ends the last region)
     if (tid == 0u) {
@@ -1236,7 +1247,10 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
             static_assert(offsetof(FrameStatus, layout_total) + 8 == sizeof(FrameStatus), "layout_total is the last word");
             const unsigned long long* src = reinterpret_cast<const unsigned long long*>(status);
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(host_status);
-            for (unsigned int q = 0; q < offsetof(FrameStatus, layout_total) / 8u; ++q) dst[q] = src[q];
+            // (system scope: the host peeks at frames in flight -- enqueue_frame, the redo's arming -- without waiting for anything)
+            for (unsigned int q = 0; q < offsetof(FrameStatus, layout_total) / 8u; ++q)
+                __hip_atomic_store(&dst[q], src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
         }
     }
     __syncthreads();

@@ -173,6 +173,37 @@ def test_overflowing_async_frame_is_binned_again_on_the_device(scene_and_poses):
         r.device_free(p)
 
 
+def test_regions_that_ask_for_more_than_the_key_buffer_give_up_their_margins():
+    """A frame whose lists FIT the key buffer while their regions with the usual margins (1.5 x + 512 keys a tile) do not
+    -- here: 9216 tiles, whose 512-key margins alone exceed the 4 M entries a small scene starts with: the layout squeezes
+    the margins in proportion instead of cutting the last tiles off (build_layout).  Asynchronous frames from the very
+    first one, a moving camera with the redo launches on: every frame is rendered; the buffer grows at the first sync."""
+    r = splat_amd.Renderer()
+    try:
+        r.set_option(_lib.OPT_OVERFLOW_REDO, 2)
+        g = splat_amd.synthetic_scene(120000, 71)
+        g.compute_cov3d(r)
+        r.upload(g)
+        S, m = 1536, 96 * 96
+        cams = [make_camera(S, S, (0.0, 0.0, 5.0 - 0.02 * k)) for k in range(6)]
+        img = r.device_image(np.zeros((S, S), np.uint32))
+        for cam in cams:
+            r.render_frame_device(cam.to_c(0.01), img)
+        cap = r.binning_mode()
+        r.sync()
+        assert r.frames_dropped() == 0, "frames skipped although their lists fit the buffer"
+        ref, ost = oracle_frame(g, cams[-1])
+        pairs = int(ost.n_tile_pairs)
+        assert pairs + 64 * m <= cap < 1.5 * pairs + 500 * m, ("the case this test is about", pairs, cap)
+        assert image_diff(r.device_download(img, S, S), ref)[0] <= 1
+        st = r.render_frame_device(cams[-1].to_c(0.01), img, sync=True, want_stats=True)
+        assert st.n_pairs == pairs
+        assert r.binning_mode() > cap, "the buffer grows to the full margins at the sync"
+        r.device_free(img)
+    finally:
+        r.close()
+
+
 def test_sort_launch_miss_with_tight_grids():
     """the sort launches for long lists (near selection off: with it there are none, and nothing to miss) cover a prefix sized
     from the previous frame; with no margin (SPLAT_DBG_TIGHT_GRIDS) a pose with more long lists than the last one misses,
