@@ -191,6 +191,7 @@ struct splat_ctx {
     // skipped and reported as before, and arms the redo); 2 = on every moving frame.
     int overflow_redo = 1;
     int redo_armed = 0;                    // moving frames left that still carry the redo launches (adaptive)
+    bool one_pass_select = true;           // SPLAT_DBG_ONE_PASS_SELECT=0: near selection always takes its two passes (histogram, compaction)
     unsigned int* need_hint = nullptr;     // 4 x m_alloc words: per tile and wave, the nearest keys its walk needed in the most recent frame
     bool last_near = false;                // the most recent frame ran with near selection: its long lists are unordered in memory
     int timing_every = 8;                  // SPLAT_TIMING_EVERY: per-kernel events on every n-th frame (and whenever stats are asked for)
@@ -428,8 +429,8 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     HIP_TRY(c, dmalloc(c, &c->zero_layout, sizeof(unsigned int) * (size_t)(m + 1)));
     HIP_TRY(c, hipMemset(c->zero_layout, 0, sizeof(unsigned int) * (size_t)(m + 1)));
     dfree(c->need_hint);
-    HIP_TRY(c, dmalloc(c, &c->need_hint, sizeof(unsigned int) * 4u * (size_t)(m + 1)));
-    HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)(m + 1)));
+    HIP_TRY(c, dmalloc(c, &c->need_hint, sizeof(unsigned int) * 5u * (size_t)(m + 1)));      // (+ one word per tile behind them: the depth its last selection began at)
+    HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 5u * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
         dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_counts); dfree(s.redo_layout); dfree(s.redo_cursors);
@@ -677,7 +678,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const bool comp_sorts = comp_sorts_frame;
     if (near_cap)       // near selection: the nearest keys of the long lists instead of the sort launches
         launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m,
-                      (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows);
+                      (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows, c->one_pass_select ? c->need_hint + 4u * (size_t)c->m_alloc : nullptr);
     else if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
@@ -845,7 +846,7 @@ int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
             sl.layout_valid = false; sl.flip = 0;
             if (sl.counts) HIP_TRY(c, hipMemsetAsync(sl.counts, 0, sizeof(unsigned int) * (size_t)(m + 1), c->stream));
         }
-        if (c->need_hint) HIP_TRY(c, hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)(m + 1), c->stream));   // another grid: another tile under every index
+        if (c->need_hint) HIP_TRY(c, hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 5u * (size_t)c->m_alloc, c->stream));   // another grid: another tile under every index
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->last_one_pass = one_pass; c->layout_m = m;
     }
@@ -1104,6 +1105,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
+    if (const char* k7 = std::getenv("SPLAT_DBG_ONE_PASS_SELECT")) c->one_pass_select = std::atoi(k7) != 0;
     if (const char* k6 = std::getenv("SPLAT_DBG_REPAIR_GRID")) c->knobs.dbg_repair_grid = (unsigned int)std::max(0, std::atoi(k6));
     if (const char* k5 = std::getenv("SPLAT_DBG_STARTS")) c->knobs.dbg_starts = std::atoi(k5) != 0 ? 1u : 0u;
     if (const char* k4 = std::getenv("SPLAT_COMP_LDS_PAD")) c->knobs.comp_lds_pad = (unsigned int)std::max(0, std::atoi(k4));
@@ -1220,7 +1222,7 @@ int splat_set_option(splat_ctx* c, int32_t option, double value) {
     if (!store_option(c, option, value)) return fail(c, SPLAT_ERR_INVALID, "option value out of range");
     // (another selection size: what the tiles' walks needed under the old one is forgotten)
     if (option == SPLAT_OPT_NEAR_SELECT_KEYS && c->need_hint && c->m_alloc)
-        HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)c->m_alloc));
+        HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 5u * (size_t)c->m_alloc));
     return SPLAT_OK;
 }
 
@@ -1333,7 +1335,7 @@ int splat_set_slab(splat_ctx* c, int32_t tile_row0, int32_t tile_row1) {
     for (Slot& sl : c->slots) sl.layout_valid = false;
     c->sort_hint = false;
     c->hint_pairs = 0; c->hint_maxlen = 0;
-    if (c->need_hint && c->m_alloc) (void)hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 4u * (size_t)c->m_alloc, c->stream);
+    if (c->need_hint && c->m_alloc) (void)hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 5u * (size_t)c->m_alloc, c->stream);
     c->slab0 = tile_row0; c->slab1 = tile_row1;
     return rc;
 }

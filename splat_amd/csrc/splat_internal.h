@@ -127,7 +127,8 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
                    unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
                    const unsigned int* need_hint, unsigned int* near_m /* per tile: how many of the nearest keys are in order */,
-                   unsigned int tiles_x, unsigned int tile_rows /* the tile grid: a tile's selection also looks at its neighbours' hints */);
+                   unsigned int tiles_x, unsigned int tile_rows /* the tile grid: a tile's selection also looks at its neighbours' hints */,
+                   unsigned int* near_thr = nullptr /* one word per tile, kept from frame to frame: the depth its last selection began at */);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max = 0,

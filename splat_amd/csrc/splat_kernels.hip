@@ -1833,7 +1833,7 @@ __device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem,
 // caller sorts the whole list instead.  Ends with a barrier: s[0 .. m) is complete.
 template <int NT>
 __device__ __forceinline__ unsigned int select_near(unsigned char* smem, const unsigned long long* __restrict__ g, unsigned int n,
-                                                    unsigned int cap, unsigned int* sel_mn, unsigned int* sel_mx) {
+                                                    unsigned int cap, unsigned int* sel_mn, unsigned int* sel_mx, unsigned int* sel_thr) {
     constexpr unsigned int NB = 1024u;
     static_assert(NT == 256, "four bins per thread");
     static_assert(2048u * 8u + NB * 4u + 64u <= sort_lds_bytes<NT, 2048>(), "keys + bins + a few words fit the workspace");
@@ -1901,6 +1901,10 @@ __device__ __forceinline__ unsigned int select_near(unsigned char* smem, const u
     __syncthreads();
     const unsigned int first = misc[2], m = misc[3];
     if (first >= NB || m == 0u) { __syncthreads(); return 0u; }          // the nearest bin alone overflows the cap
+    {   // the selection is exactly the keys of depth >= this (0: no such statement -- bin 0 also holds what lies in front of the range)
+        const unsigned long long t = (unsigned long long)lo + ((unsigned long long)first << sh);
+        *sel_thr = (first == 0u || t > 0xffffffffull) ? 0u : (unsigned int)t;
+    }
     __syncthreads();                                                     // (misc[0..1] are reused for the selection's extremes)
     if (tid == 0u) { misc[0] = 0xffffffffu; misc[1] = 0u; }
     mn = 0xffffffffu; mx = 0u;
@@ -1935,6 +1939,55 @@ __device__ __forceinline__ unsigned int select_near(unsigned char* smem, const u
     *sel_mn = misc[0];                              // the depth range of the selection: sizes the digits of the sort that follows
     *sel_mx = misc[1];
     return m;
+}
+
+// The same selection in ONE pass over the list, when the depth it begins at is known beforehand (the tile's selection of
+// the previous frame began there: select_near's *sel_thr): every key of depth >= thr is compacted into LDS, s[0 .. count).
+// Returns the count -- which may be anything: more than the 2048 keys the workspace holds (only the first 2048 arrivals
+// were stored: the caller takes the two passes after all), or too few to be worth walking.  Exactly the nearest `count`
+// keys of the list whatever the threshold (every key at or beyond a depth is a suffix of the sorted list, ties included).
+template <int NT>
+__device__ __forceinline__ unsigned int select_by_depth(unsigned char* smem, const unsigned long long* __restrict__ g, unsigned int n,
+                                                        unsigned int thr, unsigned int* sel_mn, unsigned int* sel_mx) {
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
+    unsigned int* misc = reinterpret_cast<unsigned int*>(smem + 2048u * 8u);      // 0 min, 1 max, 2 cursor
+    const unsigned int tid = threadIdx.x, lane = tid & 63u;
+    if (tid == 0u) { misc[0] = 0xffffffffu; misc[1] = 0u; misc[2] = 0u; }
+    __syncthreads();
+    unsigned int mn = 0xffffffffu, mx = 0u;
+    for (unsigned int t0 = tid; t0 < n; t0 += 8u * NT) {              // eight loads in flight per thread
+        unsigned long long k[8];
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) { const unsigned int t = t0 + u * NT; k[u] = (t < n) ? g[t] : 0ull; }
+#pragma unroll
+        for (unsigned int u = 0; u < 8; ++u) {
+            const unsigned int d = (unsigned int)(k[u] >> 32);
+            const bool take = (t0 + u * NT < n) && d >= thr;
+            const unsigned long long tm = __builtin_amdgcn_ballot_w64(take);
+            if (tm) {                               // one cursor atomic per wave and round
+                unsigned int base = 0u;
+                if (lane == 0u) base = atomicAdd(&misc[2], (unsigned int)__builtin_popcountll(tm));
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if (take) {
+                    const unsigned int at = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(tm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)tm, 0u));
+                    if (at < 2048u) s[at] = k[u];
+                    mn = min(mn, d); mx = max(mx, d);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (unsigned int)__shfl_xor((int)mn, o));
+        mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+    }
+    if (lane == 0u) { atomicMin(&misc[0], mn); atomicMax(&misc[1], mx); }
+    __syncthreads();                                // s[0 .. count) and the extremes are complete
+    *sel_mn = misc[0];
+    *sel_mx = misc[1];
+    const unsigned int count = misc[2];
+    __syncthreads();                                // (misc is the sort's from here on)
+    return count;
 }
 
 // The whole of it, for the compositor's workgroup: the nearest min(cap, n) keys of the list at g (region of the key buffer,
@@ -2675,14 +2728,14 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
                                                           unsigned long long* __restrict__ keys2, FrameStatus* __restrict__ status,
                                                           const unsigned int* __restrict__ orig, unsigned int radix_min, unsigned int near_cap,
                                                           const unsigned int* __restrict__ need_hint, unsigned int* __restrict__ near_m,
-                                                          unsigned int tiles_x, unsigned int tile_rows) {
+                                                          unsigned int tiles_x, unsigned int tile_rows, unsigned int* __restrict__ near_thr) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
     const unsigned int tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);
     const unsigned int n = (unsigned int)__builtin_amdgcn_readfirstlane((int)lens[tile]);
     if (n <= 2048u) return;                     // (the compositor's workgroup sorts those itself)
     const unsigned int beg = (unsigned int)__builtin_amdgcn_readfirstlane((int)offsets[tile]);
-    unsigned int want = near_cap, deepest;
+    unsigned int want = near_cap, deepest, thr = 0u;
     {
         // ONE wave reads the hints and the workgroup takes its word for them: the previous frames' compositors are storing
         // into these words while this kernel runs (frames overlap on the device), and four waves that each read for
@@ -2710,10 +2763,11 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
                 d0 = max(d0, nb);           // (~0 stays ~0)
             }
 #endif
-            if (threadIdx.x == 0u) word[0] = d0;
+            if (threadIdx.x == 0u) { word[0] = d0; word[1] = near_thr != nullptr ? near_thr[tile] : 0u; }
         }
         __syncthreads();
         deepest = (unsigned int)__builtin_amdgcn_readfirstlane((int)word[0]);
+        thr = (unsigned int)__builtin_amdgcn_readfirstlane((int)word[1]);
         __syncthreads();                    // (the workspace is the selection's from here on)
         // (While the hint leaves room, the selection is the full workspace: this kernel runs beside the previous frame's
         // compositor, its time is hidden, and a moving camera puts other Gaussians under the tile than the hint saw -- a
@@ -2725,7 +2779,19 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
     unsigned int m = 0u;
     if (want <= near_cap) {
         unsigned int smn, smx;
-        m = select_near<256>(smem, keys + beg, n, want, &smn, &smx);
+        // ONE pass while the camera is coherent: every key at or beyond the depth the tile's last selection began at -- if
+        // those are still a workspace-full at most and three quarters of one at least (a moving camera finds its margin in
+        // the size of the selection); else the two passes
+        // (histogram over a sampled depth range, compaction), which leave the depth for the next frame
+        if (thr != 0u && deepest != 0u && want == near_cap) {
+            m = select_by_depth<256>(smem, keys + beg, n, thr, &smn, &smx);
+            if (m > near_cap || m < max(deepest + (deepest >> 1) + 128u, near_cap - (near_cap >> 2)) || m >= n) m = 0u;
+        }
+        if (m == 0u) {
+            unsigned int thr_new = 0u;
+            m = select_near<256>(smem, keys + beg, n, want, &smn, &smx, &thr_new);
+            if (near_thr != nullptr && threadIdx.x == 0u) near_thr[tile] = m != 0u ? thr_new : 0u;
+        }
         // (the bins are coarse where many keys share a depth: a selection that came out shorter than the tile needed last
         // time is not worth walking)
         if (m != 0u && (deepest == 0u || m >= deepest + (deepest >> 3))) {
@@ -2922,10 +2988,10 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 }
 void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
                    unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
-                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows) {
+                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows, unsigned int* near_thr) {
     if (!n_tiles) return;
     hipLaunchKernelGGL(select_near_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, order, lens, keys, keys2, status, orig, sort_radix_min(),
-                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows);
+                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
