@@ -549,7 +549,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
 // drains its queue for a few microseconds -- nine of them per frame were ~25 us of bubbles in a
 // 590 us frame -- so untimed frames (all but every `timing_every`-th of an asynchronous run) record
 // only the one event that tells the host the frame's status has arrived.
-int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = false, bool may_overlap = false) {
+int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = false, bool may_overlap = false, bool awaited = false) {
     use_launch_knobs(&c->knobs);
     const int r = c->ring_next;
     EvSet& ev = c->ring[r];
@@ -676,9 +676,17 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         launch_emit(ss, c->n, c->fc, s.depth, s.rect, c->orig, s.vislist, s.cursor, s.keys, d_st);
     HIP_TRY(c, mark(3, ss));
     const bool comp_sorts = comp_sorts_frame;
-    if (near_cap)       // near selection: the nearest keys of the long lists instead of the sort launches
+    if (near_cap) {     // near selection: the nearest keys of the long lists instead of the sort launches
+        // Its workgroups: an eighth as many as tiles, each walking the longest-first order with that stride until the lists get
+        // short -- a frame in the pipeline has 0.3 ms of slack in front of its compositor, and fewer resident selections leave
+        // the previous frame's compositor its LDS (C3 +2 %, C3s +4 %; a sixteenth: C3 +1 %, C3s -1 %; a 64th: -15 %).  A frame
+        // the caller waits for gets a workgroup per long list (their number a frame ago, plus an eighth).
+        unsigned int grid = (m + 7u) / 8u;
+        if (awaited) grid = c->sort_hint ? std::max<unsigned int>(grid, c->hint_ge2048 + c->hint_ge2048 / 8u + 16u) : m;
         launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m,
-                      (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows, c->one_pass_select ? c->need_hint + 4u * (size_t)c->m_alloc : nullptr);
+                      (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows, c->one_pass_select ? c->need_hint + 4u * (size_t)c->m_alloc : nullptr,
+                      std::min(grid, m));
+    }
     else if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
     HIP_TRY(c, mark(4, ss));
@@ -1105,6 +1113,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
+    if (const char* k8 = std::getenv("SPLAT_DBG_SELECT_STRIDE")) c->knobs.dbg_select_stride = (unsigned int)std::max(0, std::atoi(k8));
     if (const char* k7 = std::getenv("SPLAT_DBG_ONE_PASS_SELECT")) c->one_pass_select = std::atoi(k7) != 0;
     if (const char* k6 = std::getenv("SPLAT_DBG_REPAIR_GRID")) c->knobs.dbg_repair_grid = (unsigned int)std::max(0, std::atoi(k6));
     if (const char* k5 = std::getenv("SPLAT_DBG_STARTS")) c->knobs.dbg_starts = std::atoi(k5) != 0 ? 1u : 0u;
@@ -1422,7 +1431,8 @@ int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int3
         if (rc != SPLAT_OK) return rc;
         const bool timed = stats != nullptr || c->timing_every <= 1 || (c->frame_idx % (uint64_t)c->timing_every) == 0;
         c->clear_first = clear_first;
-        rc = enqueue_frame(c, (uint32_t*)d_argb, timed, stats != nullptr, !sync && !stats && c->comp2 != nullptr && c->overlap >= 2 && !c->streamed_call);
+        rc = enqueue_frame(c, (uint32_t*)d_argb, timed, stats != nullptr, !sync && !stats && c->comp2 != nullptr && c->overlap >= 2 && !c->streamed_call,
+                           sync || stats != nullptr);
         c->clear_first = false;
         if (rc != SPLAT_OK) return rc;
         if (!sync && !stats) return SPLAT_OK;

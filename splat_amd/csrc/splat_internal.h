@@ -83,6 +83,7 @@ struct LaunchKnobs {
     int scan_threads = 0;                  // 0: by the tile count
     unsigned int dbg_ntiles = 0;           // != 0: composite only the N longest tiles
     unsigned int comp_lds_pad = 0;         // extra dynamic LDS per compositor workgroup (an occupancy cap)
+    unsigned int dbg_select_stride = 0;    // SPLAT_DBG_SELECT_STRIDE: slots of the tile order per workgroup of the near selection's launch (default 8)
     unsigned int dbg_repair_grid = 0;      // SPLAT_DBG_REPAIR_GRID: workgroups of the near selection's repair launch (default 64)
     unsigned int dbg_starts = 0;           // SPLAT_DBG_STARTS: statistics frames record (list length, nearest keys the walk needed) per wave
 };
@@ -128,7 +129,8 @@ void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offs
                    unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
                    const unsigned int* need_hint, unsigned int* near_m /* per tile: how many of the nearest keys are in order */,
                    unsigned int tiles_x, unsigned int tile_rows /* the tile grid: a tile's selection also looks at its neighbours' hints */,
-                   unsigned int* near_thr = nullptr /* one word per tile, kept from frame to frame: the depth its last selection began at */);
+                   unsigned int* near_thr = nullptr /* one word per tile, kept from frame to frame: the depth its last selection began at */,
+                   unsigned int grid = 0 /* workgroups (each strides over the tile order); 0 = an eighth of the tiles */);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max = 0,

@@ -2728,12 +2728,20 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
                                                           unsigned long long* __restrict__ keys2, FrameStatus* __restrict__ status,
                                                           const unsigned int* __restrict__ orig, unsigned int radix_min, unsigned int near_cap,
                                                           const unsigned int* __restrict__ need_hint, unsigned int* __restrict__ near_m,
-                                                          unsigned int tiles_x, unsigned int tile_rows, unsigned int* __restrict__ near_thr) {
+                                                          unsigned int tiles_x, unsigned int tile_rows, unsigned int* __restrict__ near_thr,
+                                                          unsigned int n_slots) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
-    const unsigned int tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);
+    // (an eighth as many workgroups as tiles, each taking the slots blockIdx.x, + gridDim.x, ... of the longest-first order until it
+    // meets a list the compositor sorts itself: seven of eight tiles have one, and a workgroup launched only to find that
+    // out still has to wait for 21.5 KB of LDS on a chip the compositor fills)
+  for (unsigned int slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
+    const unsigned int tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)order[slot]);
     const unsigned int n = (unsigned int)__builtin_amdgcn_readfirstlane((int)lens[tile]);
-    if (n <= 2048u) return;                     // (the compositor's workgroup sorts those itself)
+    // (the compositor's workgroup sorts those itself -- and every slot behind this one: the order is by length CLASS, half
+    // octaves, longest class first, so a list of exactly 2048 keys may stand in front of longer ones of its class)
+    if (n < 2048u) return;
+    if (n == 2048u) continue;
     const unsigned int beg = (unsigned int)__builtin_amdgcn_readfirstlane((int)offsets[tile]);
     unsigned int want = near_cap, deepest, thr = 0u;
     {
@@ -2808,6 +2816,8 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
         near_m[tile] = m;
         if (m < n) atomicAdd(&status->n_near_tiles, 1u);
     }
+    __syncthreads();                            // the workspace is the next slot's
+  }
 }
 
 // The launch: one workgroup per tile, slot blockIdx.x of the longest-first order.  (A persistent grid pulling
@@ -2988,10 +2998,12 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 }
 void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
                    unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
-                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows, unsigned int* near_thr) {
+                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows, unsigned int* near_thr, unsigned int grid) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(select_near_kernel, dim3(n_tiles), dim3(256), 0, s, offsets, order, lens, keys, keys2, status, orig, sort_radix_min(),
-                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr);
+    if (g_knobs->dbg_select_stride) grid = (n_tiles + g_knobs->dbg_select_stride - 1u) / g_knobs->dbg_select_stride;
+    if (!grid) grid = (n_tiles + 7u) / 8u;
+    hipLaunchKernelGGL(select_near_kernel, dim3(std::min(grid, n_tiles)), dim3(256), 0, s, offsets, order, lens, keys, keys2, status, orig, sort_radix_min(),
+                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr, n_tiles);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
