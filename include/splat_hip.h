@@ -243,6 +243,14 @@ int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
                                             never does pays nothing, the first such frame after a quiet stretch is skipped and
                                             reported as before and arms the redo; 2 = on every frame of a moving camera (five
                                             near-empty launches per frame on the binning stream).  SPLAT_OVERFLOW_REDO           */
+#define SPLAT_OPT_START_HINTS 18         /* where a compositor wave's exact walk starts is normally found by a scan of its tile's list
+                                            from the near end (the early-out).  With a camera at rest the lists are the previous
+                                            frame's lists: the walk starts where that frame's did (one word per wave, kept from
+                                            frame to frame) and the scan is skipped; with a camera that moved by less than about
+                                            half a degree since the last frame, where it did plus an eighth, three frames of four.
+                                            A start that turns out too shallow is retried deeper, as after any scan: exactness
+                                            never rests on the hint.  0 = scan every frame; 1 = camera at rest only; 2 = at rest
+                                            and in slow motion (default 2; SPLAT_START_HINTS)                                    */
 int splat_set_option(splat_ctx* ctx, int32_t option, double value);
 int splat_get_option(const splat_ctx* ctx, int32_t option, double* value);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */

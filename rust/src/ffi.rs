@@ -31,6 +31,7 @@ pub const SPLAT_OPT_PRIORITY_LIST_LEN: i32 = 14;
 pub const SPLAT_OPT_FRAME_OVERLAP: i32 = 15;
 pub const SPLAT_OPT_NEAR_SELECT_KEYS: i32 = 16;
 pub const SPLAT_OPT_OVERFLOW_REDO: i32 = 17;
+pub const SPLAT_OPT_START_HINTS: i32 = 18;
 
 #[repr(C)] pub struct SplatCtx { _private: [u8; 0] }
 #[repr(C)] pub struct SplatMulti { _private: [u8; 0] }

@@ -119,6 +119,7 @@ OPT_PRIORITY_LIST_LEN = 14
 OPT_FRAME_OVERLAP = 15
 OPT_NEAR_SELECT_KEYS = 16
 OPT_OVERFLOW_REDO = 17
+OPT_START_HINTS = 18
 
 _LIB = None
 

@@ -191,6 +191,11 @@ struct splat_ctx {
     // skipped and reported as before, and arms the redo); 2 = on every moving frame.
     int overflow_redo = 1;
     int redo_armed = 0;                    // moving frames left that still carry the redo launches (adaptive)
+    int start_hints = 2;                   // SPLAT_OPT_START_HINTS / SPLAT_START_HINTS: 0 the compositor scans for its walks' starts on every frame; 1 not with
+                                           // a camera at rest; 2 nor, three frames of four, with one in slow motion (see enqueue_frame)
+    float last_view[16] = {};              // the previous frame's view matrix: how far did the camera move?
+    uint64_t last_cam_hash = 0;            // the previous frame's camera (and slab) ...
+    unsigned int still_frames = 0;         // ... and how many frames in a row it has been the same
     bool one_pass_select = true;           // SPLAT_DBG_ONE_PASS_SELECT=0: near selection always takes its two passes (histogram, compaction)
     unsigned int* need_hint = nullptr;     // 4 x m_alloc words: per tile and wave, the nearest keys its walk needed in the most recent frame
     bool last_near = false;                // the most recent frame ran with near selection: its long lists are unordered in memory
@@ -429,8 +434,8 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     HIP_TRY(c, dmalloc(c, &c->zero_layout, sizeof(unsigned int) * (size_t)(m + 1)));
     HIP_TRY(c, hipMemset(c->zero_layout, 0, sizeof(unsigned int) * (size_t)(m + 1)));
     dfree(c->need_hint);
-    HIP_TRY(c, dmalloc(c, &c->need_hint, sizeof(unsigned int) * 5u * (size_t)(m + 1)));      // (+ one word per tile behind them: the depth its last selection began at)
-    HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 5u * (size_t)(m + 1)));
+    HIP_TRY(c, dmalloc(c, &c->need_hint, sizeof(unsigned int) * 9u * (size_t)(m + 1)));      // (+ one word per tile behind them: the depth its last selection began at; + four: where its waves' walks started)
+    HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
         dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_counts); dfree(s.redo_layout); dfree(s.redo_cursors);
@@ -529,6 +534,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->bucket_cap = 0;
     fc->corrected = (c->cfg.mode & SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
     fc->redo_only = 0;
+    fc->start_hints = 0;
     // (a singular cov2d needs lowpass == 0 or a non-PSD cov3d; with lowpass == 0 every Gaussian is
     // looked at so that n_singular stays what the reference would have panicked on)
     fc->cull_blocks = (c->cull_blocks && c->bounds && cam->lowpass > 0.0f) ? 1 : 0;
@@ -594,6 +600,28 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         mix(c->fc.view, sizeof c->fc.view); mix(c->fc.proj, sizeof c->fc.proj); mix(&c->fc.w, sizeof(float) * 5); mix(c->fc.cam, sizeof c->fc.cam);
         mix(&c->fc.lowpass, sizeof(float)); mix(&c->fc.tile_row0, sizeof(int) * 2);
         if (cam_hash == 0) cam_hash = 1;
+    }
+    // (a camera at rest for a few frames -- frames overlap on the device: the hints a frame reads must come from the same camera
+    // whichever of the frames before it wrote them last: the compositor's walks start where they started then)
+    c->still_frames = (cam_hash == c->last_cam_hash) ? std::min(c->still_frames + 1u, 1000u) : 0u;
+    c->last_cam_hash = cam_hash;
+    {
+        // START HINTS (SPLAT_OPT_START_HINTS).  At rest for three frames: every hint in the table comes from this camera -> the
+        // walks start exactly where they did (1).  The first frames at rest, and a camera that moves fast: scan (0), which
+        // also refreshes the hints.  A camera that moved by less than ~half a degree (the view matrix's entries differ by less
+        // than 0.009, translations relative to their size): where they did plus a margin, and every fourth frame the scan,
+        // tiles taking turns (>= 2: the frame number rides along).
+        float delta = 0.0f;
+        for (int q = 0; q < 16; ++q) {
+            const float a = c->fc.view[q], b = c->last_view[q];
+            const float d = std::fabs(a - b) / std::max(1.0f, std::max(std::fabs(a), std::fabs(b)));
+            delta = (d == d) ? std::max(delta, d) : 1.0f;
+        }
+        std::memcpy(c->last_view, c->fc.view, sizeof c->last_view);
+        int mode = 0;
+        if (c->start_hints >= 1 && c->still_frames >= 3u) mode = 1;
+        else if (c->start_hints >= 2 && c->still_frames == 0u && delta < 0.009f) mode = 2 + (int)(c->frame_idx & 0xffffull);
+        c->fc.start_hints = mode;
     }
     bool moved = false;
     if (c->fc.bucket_cap) {
@@ -750,7 +778,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
                                              : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
     launch_composite(cs, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
                      pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr, near_cap ? s.near_m : nullptr,
-                     s.repair_mask, s.repair_list, c->need_hint);
+                     s.repair_mask, s.repair_list, c->need_hint, c->need_hint ? c->need_hint + 5u * (size_t)c->m_alloc : nullptr);
     c->last_near = near_cap != 0u;
     HIP_TRY(c, mark(6, cs));
     // the scan has already delivered this frame's status to h_status[r]; a statistics frame refreshes it with the late
@@ -854,7 +882,7 @@ int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
             sl.layout_valid = false; sl.flip = 0;
             if (sl.counts) HIP_TRY(c, hipMemsetAsync(sl.counts, 0, sizeof(unsigned int) * (size_t)(m + 1), c->stream));
         }
-        if (c->need_hint) HIP_TRY(c, hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 5u * (size_t)c->m_alloc, c->stream));   // another grid: another tile under every index
+        if (c->need_hint) HIP_TRY(c, hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc, c->stream));   // another grid: another tile under every index
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->last_one_pass = one_pass; c->layout_m = m;
     }
@@ -1012,6 +1040,7 @@ bool store_option(splat_ctx* c, int opt, double v) {
         case SPLAT_OPT_FRAME_OVERLAP: if (v != 1.0 && v != 2.0) return false; c->overlap = (int)v; return true;    // (lanes: splat_set_option / splat_create make them)
         case SPLAT_OPT_NEAR_SELECT_KEYS: if (v != 0.0 && (v < 64.0 || v > 2048.0)) return false; c->near_cap = (unsigned int)v; return true;
         case SPLAT_OPT_OVERFLOW_REDO: if (v != 0.0 && v != 1.0 && v != 2.0) return false; c->overflow_redo = (int)v; return true;
+        case SPLAT_OPT_START_HINTS: if (v != 0.0 && v != 1.0 && v != 2.0) return false; c->start_hints = (int)v; return true;
         default: return false;
     }
 }
@@ -1034,6 +1063,7 @@ bool load_option(const splat_ctx* c, int opt, double* v) {
         case SPLAT_OPT_FRAME_OVERLAP: *v = c->overlap; return true;
         case SPLAT_OPT_NEAR_SELECT_KEYS: *v = c->near_cap; return true;
         case SPLAT_OPT_OVERFLOW_REDO: *v = c->overflow_redo; return true;
+        case SPLAT_OPT_START_HINTS: *v = c->start_hints; return true;
         default: return false;
     }
 }
@@ -1114,6 +1144,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
     if (const char* k8 = std::getenv("SPLAT_DBG_SELECT_STRIDE")) c->knobs.dbg_select_stride = (unsigned int)std::max(0, std::atoi(k8));
+    if (const char* k10 = std::getenv("SPLAT_START_HINTS")) { c->start_hints = std::min(2, std::max(0, std::atoi(k10))); c->env_pinned |= 1u << SPLAT_OPT_START_HINTS; }
     if (const char* k7 = std::getenv("SPLAT_DBG_ONE_PASS_SELECT")) c->one_pass_select = std::atoi(k7) != 0;
     if (const char* k6 = std::getenv("SPLAT_DBG_REPAIR_GRID")) c->knobs.dbg_repair_grid = (unsigned int)std::max(0, std::atoi(k6));
     if (const char* k5 = std::getenv("SPLAT_DBG_STARTS")) c->knobs.dbg_starts = std::atoi(k5) != 0 ? 1u : 0u;
@@ -1231,7 +1262,7 @@ int splat_set_option(splat_ctx* c, int32_t option, double value) {
     if (!store_option(c, option, value)) return fail(c, SPLAT_ERR_INVALID, "option value out of range");
     // (another selection size: what the tiles' walks needed under the old one is forgotten)
     if (option == SPLAT_OPT_NEAR_SELECT_KEYS && c->need_hint && c->m_alloc)
-        HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 5u * (size_t)c->m_alloc));
+        HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc));
     return SPLAT_OK;
 }
 
@@ -1344,7 +1375,7 @@ int splat_set_slab(splat_ctx* c, int32_t tile_row0, int32_t tile_row1) {
     for (Slot& sl : c->slots) sl.layout_valid = false;
     c->sort_hint = false;
     c->hint_pairs = 0; c->hint_maxlen = 0;
-    if (c->need_hint && c->m_alloc) (void)hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 5u * (size_t)c->m_alloc, c->stream);
+    if (c->need_hint && c->m_alloc) (void)hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc, c->stream);
     c->slab0 = tile_row0; c->slab1 = tile_row1;
     return rc;
 }

@@ -42,6 +42,7 @@ struct FrameConst {
     unsigned int bucket_cap; // one-pass binning: entries of the key buffer the tiles' regions live in (0: two-pass binning with exact lists)
     int corrected;         // SPLAT_MODE_CORRECTED_PROJECTION: J enters transposed (perspective-shear terms kept)
     int cull_blocks;       // K1 skips 256-Gaussian blocks whose bounds cannot reach the slab (needs lowpass > 0)
+    int start_hints;       // compositor: the camera is at rest -- a wave's exact walk may start where the previous frame's did (start_hint) instead of scanning for it
     int redo_only;         // K1 as a REDO launch: leaves at once unless the frame's scan flagged a tile that outgrew its region
 };
 
@@ -148,7 +149,9 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       unsigned int* repair_mask = nullptr /* per tile: waves whose walk needed more than the selection (zeroed by the scan) */,
                       unsigned int* repair_list = nullptr /* n_tiles entries: the tiles the repair launch takes again */,
                       unsigned int* need_hint = nullptr /* 4 words per tile, kept from frame to frame: how many of its list's nearest
-                                                           keys each wave's walk needed (sizes the next frame's selection) */);
+                                                           keys each wave's walk needed (sizes the next frame's selection) */,
+                      unsigned int* start_hint = nullptr /* 4 words per tile, kept from frame to frame: where each wave's exact walk
+                                                            started, in keys from the list's near end (fc.start_hints) */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 // ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)

@@ -2285,7 +2285,8 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                                                const unsigned int* __restrict__ orig, const unsigned int clear_first,
                                                unsigned long long* __restrict__ keys2, const unsigned int* __restrict__ near_m,
                                                unsigned int* __restrict__ repair_mask, unsigned int* __restrict__ repair_list,
-                                               const unsigned int wave_mask, unsigned int* __restrict__ need_hint) {
+                                               const unsigned int wave_mask, unsigned int* __restrict__ need_hint,
+                                               unsigned int* __restrict__ start_hint) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -2533,7 +2534,25 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // ---------------- phase A: where must the exact walk start? ----------------
     unsigned int ws = lb;                        // this wave's start position (uniform)
     unsigned int nA = 0;                         // batches (from the end of the list) whose staging verdicts the scan saved
-    if (fc.early_eps > 0.0f && (has_far || end - beg >= (unsigned int)fc.early_min) && !need_far) {
+    const bool early = fc.early_eps > 0.0f && (has_far || end - beg >= (unsigned int)fc.early_min);
+    // A camera at rest: the lists are the previous frame's lists, and so is the start its walk took -- start_hint, one word
+    // per wave, left by the last frame that scanned (or had to retry deeper).  The walk from there closes its bracket as it
+    // did then; if it ever did not (a hint from another camera: frames overlap on the device), the retry below takes over
+    // as after any scan that stopped short.  Exactness never rests on the hint, only the scan's time does.
+    bool scanned = false, hinted = false;
+    if (early && !need_far && fc.start_hints != 0 && start_hint != nullptr) {
+        unsigned int h = (unsigned int)__builtin_amdgcn_readfirstlane((int)start_hint[tile * 4u + wave]);
+        if (fc.start_hints >= 2 && h != 0u) {
+            // a camera in slow motion: the previous frames' start with a margin, and every fourth frame (tiles take turns) the scan
+            h = (((unsigned int)fc.start_hints + tile) & 3u) == 0u ? 0u : h + (h >> 3) + 32u;
+        }
+        if (h != 0u) {
+            if (h < end - lb) { ws = end - h; hinted = true; }
+            else if (!has_far) { ws = lb; hinted = true; }       // (the whole list, as last time: no scan needed to find that out again)
+        }
+    }
+    if (early && !need_far && !hinted) {
+        scanned = true;
         float T = 1.0f;
         unsigned int sp = inside ? lb : 0xffffffffu;     // per lane: first layer the lane needs
         bool done = !inside;
@@ -2697,6 +2716,9 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         // what this wave's walk needed of the list's near end, for the next frame's selection (see the prologue)
         if (need_hint != nullptr && end - beg > 2048u && lane == 0u) need_hint[tile * 4u + wave] = need_far ? 0xffffffffu : end - max(start, lb);
     }
+    // ... and where it started, for the next frame of a camera at rest (phase A): after a scan, or when the hinted start
+    // did not do and the retry went deeper
+    if (start_hint != nullptr && early && !need_far && (scanned || start != ws) && lane == 0u) start_hint[tile * 4u + wave] = max(end - max(start, lb), 1u);
     if constexpr (LONGM == 2) {
         if (need_far) {
             // the first wave of a tile to ask puts the tile on the repair list; the mask says which waves to walk again
@@ -2840,7 +2862,8 @@ __global__ __launch_bounds__(256, LONGM == 1 ? 7 : SPLAT_COMP_WAVES) __attribute
                                                               unsigned int keep_keys, const unsigned int* __restrict__ orig,
                                                               unsigned int clear_first, unsigned long long* __restrict__ keys2,
                                                               const unsigned int* __restrict__ near_m, unsigned int* __restrict__ repair_mask,
-                                                              unsigned int* __restrict__ repair_list, unsigned int* __restrict__ need_hint) {
+                                                              unsigned int* __restrict__ repair_list, unsigned int* __restrict__ need_hint,
+                                                              unsigned int* __restrict__ start_hint) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
@@ -2850,7 +2873,7 @@ __global__ __launch_bounds__(256, LONGM == 1 ? 7 : SPLAT_COMP_WAVES) __attribute
         __syncthreads();
     }
     composite_tile<PAIR, LIBM, LONGM>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig, clear_first, keys2,
-                                      near_m, repair_mask, repair_list, 0xfu, need_hint);
+                                      near_m, repair_mask, repair_list, 0xfu, need_hint, start_hint);
 }
 
 // The repair launch behind a near-selection frame: the tiles whose selected nearest keys did not do for every wave
@@ -2867,7 +2890,7 @@ __global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, co
                                                                unsigned int clear_first, unsigned long long* __restrict__ keys2,
                                                                const unsigned int* __restrict__ repair_mask,
                                                                const unsigned int* __restrict__ repair_list,
-                                                               unsigned int* __restrict__ need_hint) {
+                                                               unsigned int* __restrict__ need_hint, unsigned int* __restrict__ start_hint) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
@@ -2884,7 +2907,7 @@ __global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, co
         const unsigned int item = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_list[i]);
         const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_mask[order[item]]);
         composite_tile<PAIR, LIBM, 1>(smem, exptab, item, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, nullptr, 0u, orig, clear_first, keys2,
-                                      nullptr, nullptr, nullptr, mask, need_hint);
+                                      nullptr, nullptr, nullptr, mask, need_hint, start_hint);
         __syncthreads();          // the workspace is the next tile's: every wave has finished its walk
     }
 }
@@ -3009,7 +3032,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
                       bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2, const unsigned int* near_m,
-                      unsigned int* repair_mask, unsigned int* repair_list, unsigned int* need_hint) {
+                      unsigned int* repair_mask, unsigned int* repair_list, unsigned int* need_hint, unsigned int* start_hint) {
     if (!n_tiles) return;
     if (g_knobs->dbg_ntiles) n_tiles = std::min(n_tiles, g_knobs->dbg_ntiles);   // debug: composite only the N longest tiles
     // SPLAT_COMP_LDS_PAD: extra dynamic LDS per workgroup, i.e. an occupancy cap (12 KB are in use:
@@ -3019,7 +3042,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
     const unsigned int flags = (keep_keys ? 1u : 0u) | (g_knobs->dbg_starts ? 2u : 0u);
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                           sort_radix_min(), iters, flags, orig, clear_first ? 1u : 0u, keys2, near_m, repair_mask, repair_list, near ? need_hint : nullptr);
+                           sort_radix_min(), iters, flags, orig, clear_first ? 1u : 0u, keys2, near_m, repair_mask, repair_list, near ? need_hint : nullptr, start_hint);
     };
     if (near) {
         if (libm_exp) go(composite_exact_kernel<false, true, 2>);
@@ -3028,7 +3051,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
         // the repair launch: tiles the selection did not serve (normally none: its workgroups read one word and leave)
         auto fix = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(std::min(n_tiles, g_knobs->dbg_repair_grid ? g_knobs->dbg_repair_grid : 64u)), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                               sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list, need_hint);
+                               sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list, need_hint, start_hint);
         };
         if (libm_exp) fix(composite_repair_kernel<false, true>);
         else if (pair_walk) fix(composite_repair_kernel<true, false>);

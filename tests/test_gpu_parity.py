@@ -798,7 +798,8 @@ def test_options_set_from_code_change_the_schedule_not_the_pixels():
                     [(L.OPT_PAIR_WALK, 1), (L.OPT_BLOCK_CULLING, 0), (L.OPT_REGION_SPARE, 1.0)],
                     [(L.OPT_PAIR_WALK, 0), (L.OPT_ONE_PASS_BINNING, 0), (L.OPT_TIMING_EVERY, 1)],
                     [(L.OPT_ONE_PASS_BINNING, 1), (L.OPT_KEY_BUFFER_BYTES, 1 << 20)],            # too small for regions: two-pass
-                    [(L.OPT_KEY_BUFFER_BYTES, float(128 << 30)), (L.OPT_PRIORITY_LIST_LEN, 512), (L.OPT_FRAME_OVERLAP, 2)]]
+                    [(L.OPT_KEY_BUFFER_BYTES, float(128 << 30)), (L.OPT_PRIORITY_LIST_LEN, 512), (L.OPT_FRAME_OVERLAP, 2)],
+                    [(L.OPT_START_HINTS, 0)], [(L.OPT_START_HINTS, 1)], [(L.OPT_START_HINTS, 2), (L.OPT_FRAME_OVERLAP, 1)]]
         for opts in settings:
             for o, v in opts:
                 r.set_option(o, v)
@@ -811,7 +812,7 @@ def test_options_set_from_code_change_the_schedule_not_the_pixels():
                 r.render_stream(cam_c, buf)
                 r.stream_wait(buf)
                 assert np.array_equal(buf, base), opts
-        for o, v in ((L.OPT_PIPELINE_DEPTH, 7), (L.OPT_FUSED_SORT_MAX, 4096), (L.OPT_REGION_SPARE, 0.5), (L.OPT_FRAME_OVERLAP, 3), (99, 1), (0, 1)):
+        for o, v in ((L.OPT_PIPELINE_DEPTH, 7), (L.OPT_FUSED_SORT_MAX, 4096), (L.OPT_REGION_SPARE, 0.5), (L.OPT_FRAME_OVERLAP, 3), (L.OPT_START_HINTS, 3), (99, 1), (0, 1)):
             with pytest.raises(splat_amd.renderer.SplatError):
                 r.set_option(o, v)
     finally:
@@ -1098,3 +1099,47 @@ def test_fuzzed_scenes_match_the_oracle():
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def test_start_hints_skip_the_scan_and_never_change_a_pixel():
+    """SPLAT_OPT_START_HINTS: with a camera at rest the compositor's walks start where the previous frame's did instead of
+    scanning for it; with one in slow motion, where they did plus a margin.  The bracket that proves a walk exact is
+    closed anew in every frame (and a start that does not do is retried deeper), so every frame -- at rest, creeping,
+    stopping, jumping, in libm-exp mode -- is the frame rendered with the hints off, byte for byte; the at-rest frames of
+    the default mode stay within 1 LSB of the oracle, the libm-exp ones equal it."""
+    from splat_amd import _lib as L
+    g = splat_amd.synthetic_scene(90000, 52)
+    g.positions[:, :3] *= 0.3                                  # dense: lists beyond 2048 keys, early-out in play
+    H, W = 200, 296
+    def pose(k):
+        # rest (8 frames), creep by 0.2 degrees a frame (12), rest (6), a jump, rest (5), creep (6)
+        yaw = 0.3 + np.radians(0.2) * (min(max(k - 8, 0), 12) + max(k - 32, 0)) + (1.0 if k >= 27 else 0.0)
+        return make_camera(H, W, (0.0, 0.1, 3.0), yaw=float(yaw))
+    poses = [pose(k) for k in range(38)]
+    for mode in (0, splat_amd.MODE_LIBM_EXP):
+        frames = {}
+        for hints in (0, 2, 1):
+            r = splat_amd.Renderer(mode=mode) if mode else splat_amd.Renderer()
+            try:
+                g.compute_cov3d(r)
+                r.upload(g)
+                r.set_option(L.OPT_START_HINTS, hints)
+                imgs = [r.device_image(np.zeros((H, W), np.uint32)) for _ in range(len(poses))]
+                for cam, img in zip(poses, imgs):               # asynchronous, several frames in flight
+                    r.render_frame_device(cam.to_c(0.01), img)
+                r.sync()
+                frames[hints] = [r.device_download(img, H, W) for img in imgs]
+                st = r.render_frame_device(poses[-1].to_c(0.01), imgs[-1], sync=True, want_stats=True)
+                assert st.max_tile_len > 2048
+                for img in imgs:
+                    r.device_free(img)
+            finally:
+                r.close()
+        for hints in (1, 2):
+            for k in range(len(poses)):
+                assert np.array_equal(frames[hints][k], frames[0][k]), (mode, hints, k, int((frames[hints][k] != frames[0][k]).sum()))
+        for k in (7, 26, 31):                                   # frames at rest, against the oracle
+            ref = np.zeros((H, W), np.uint32)
+            ref, _ = O.render(scene_dict(g), oracle_camera(poses[k], 0.01), O.default_conventions(), ref, nthreads=8)
+            mx, cnt = image_diff(frames[2][k], ref)
+            assert (mx == 0) if mode else (mx <= 1), (mode, k, mx, cnt)
