@@ -601,6 +601,42 @@ def main():
                         R.render_frame_device(cam_c, image.data_ptr())
                     torch.cuda.synchronize()
                     legs["steady_state_400_frames_device_resident_fps"] = 400 / (time.perf_counter() - t1)
+            # (1d) `value`'s step with the start hints off (SPLAT_OPT_START_HINTS 0): with a camera at rest the compositor's
+            # exact walks start where the previous frame's did instead of scanning their lists for the place -- this is the
+            # same fixed pose with the scan in every frame, as every frame of a fast-moving camera has it
+            from splat_amd import _lib as _L
+            hints_before = R.get_option(_L.OPT_START_HINTS)
+            R.set_option(_L.OPT_START_HINTS, 0)
+            for k in range(10):
+                R.render_frame_device(cam_c, image.data_ptr())
+            torch.cuda.synchronize()
+            with counted("fixed_pose_scanning_every_frame_fps"):
+                t1 = time.perf_counter()
+                for k in range(200):
+                    R.render_frame_device(cam_c, image.data_ptr())
+                torch.cuda.synchronize()
+                legs["fixed_pose_scanning_every_frame_fps"] = 200 / (time.perf_counter() - t1)
+            legs["fixed_pose_scanning_frame_equals_value_frame"] = bool(torch.equal(image, final)) if len(poses) == 1 else None
+            R.set_option(_L.OPT_START_HINTS, hints_before)
+            # (1e) a camera in slow motion: a yaw of 0.1 degrees a frame (a 90 degrees/s pan at 900 frames/s; the 10-degree steps
+            # of leg (1) are key presses, src/main.rs:57-60)
+            if not args.orbit:
+                slow_cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0))
+                slow_cam.update_camera_pose()
+                slow = []
+                for k in range(210):
+                    slow.append(slow_cam.to_c(pipe.LOWPASS, pipe.SH_DIM))
+                    slow_cam.update_yaw_angle(0.1 * np.pi / 180.0)
+                    slow_cam.update_camera_pose()
+                for k in range(10):
+                    R.render_frame_device(slow[k], image.data_ptr())
+                torch.cuda.synchronize()
+                with counted("slow_pan_0p1_deg_per_frame_fps"):
+                    t1 = time.perf_counter()
+                    for k in range(10, 210):
+                        R.render_frame_device(slow[k], image.data_ptr())
+                    torch.cuda.synchronize()
+                    legs["slow_pan_0p1_deg_per_frame_fps"] = 200 / (time.perf_counter() - t1)
             # (1c) a two-image swap chain (splat_set_frame_overlap(2)): the compositors of consecutive frames share the chip.
             # Nothing for a frame that fills the chip (C3, C5); a frame bound by its densest tile's lone wave (C1, C2, a
             # multi-GPU slab) runs a third faster.  Both images must hold the frame `value` rendered.
@@ -772,6 +808,7 @@ def main():
                                         "consecutive frames share the chip)" if swap_chain else ""))
                                     if world > 1 else "single GPU",
                        "frame_overlap": 2 if swap_chain else 1,
+                       "start_hints": int(R.get_option(18)),
                        "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len),
                        "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback),
                        "k1_blocks_culled": int(st.n_blocks_culled),

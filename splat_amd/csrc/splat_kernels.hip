@@ -2718,7 +2718,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     }
     // ... and where it started, for the next frame of a camera at rest (phase A): after a scan, or when the hinted start
     // did not do and the retry went deeper
-    if (start_hint != nullptr && early && !need_far && (scanned || start != ws) && lane == 0u) start_hint[tile * 4u + wave] = max(end - max(start, lb), 1u);
+    if (start_hint != nullptr && early && !need_far && (scanned || start != ws) && lane == 0u) {
+        unsigned int used = max(end - max(start, lb), 1u);
+        if (!has_far && used > (end - beg) - ((end - beg) >> 2)) used = end - beg;     // (most of the list anyway: all of it, without a bracket)
+        start_hint[tile * 4u + wave] = used;
+    }
     if constexpr (LONGM == 2) {
         if (need_far) {
             // the first wave of a tile to ask puts the tile on the repair list; the mask says which waves to walk again
