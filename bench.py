@@ -565,6 +565,11 @@ def main():
     key_entries = R.binning_mode()
     last_pose = poses[(frame_no[0] - 1) % len(poses)]
     final = images[(frame_no[0] - 1) % len(images)].clone()
+    # the compositor's (wave, record) iteration counts of a frame LIKE THE TIMED ONES (the first frame above scanned for its
+    # walks' starts; the frames of a camera at rest start where the previous frame did: SPLAT_OPT_START_HINTS)
+    with torch.cuda.stream(stream):
+        st_steady = R.render_frame_device(last_pose, images[(frame_no[0] - 1) % len(images)].data_ptr(), sync=True, want_stats=True)
+    R.timing(reset=True)
     # The context overlaps the binning + sort of frame N+1 (its own stream) with the compositor of
     # frame N, so the durations above include time shared with a neighbouring frame's kernels.  For
     # reference, a few frames with a sync after each (nothing overlaps): every kernel alone on the chip.
@@ -616,7 +621,11 @@ def main():
                     R.render_frame_device(cam_c, image.data_ptr())
                 torch.cuda.synchronize()
                 legs["fixed_pose_scanning_every_frame_fps"] = 200 / (time.perf_counter() - t1)
-            legs["fixed_pose_scanning_frame_equals_value_frame"] = bool(torch.equal(image, final)) if len(poses) == 1 else None
+            # (the exact modes render the same bytes wherever a walk starts; SPLAT_MODE_FAST is within 1 of the exact frame from any start)
+            legs["fixed_pose_scanning_frame_max_channel_diff_vs_value_frame"] = (
+                int(np.abs(((image.cpu().numpy().view(np.uint32)[..., None] >> np.array([0, 8, 16, 24], np.uint32)) & 255).astype(np.int16)
+                           - ((final.cpu().numpy().view(np.uint32)[..., None] >> np.array([0, 8, 16, 24], np.uint32)) & 255).astype(np.int16)).max())
+                if len(poses) == 1 else None)
             R.set_option(_L.OPT_START_HINTS, hints_before)
             # (1e) a camera in slow motion: a yaw of 0.1 degrees a frame (a 90 degrees/s pan at 900 frames/s; the 10-degree steps
             # of leg (1) are key presses, src/main.rs:57-60)
@@ -726,7 +735,7 @@ def main():
     dropped_all = int(dr.item())             # frames any rank's device skipped inside the timed region
 
     # per-rank stats -> whole-frame totals
-    tot = torch.tensor([st.n_visible, st.n_pairs, st.bytes_algorithmic, st.flops_algorithmic, st.n_iter_scan, st.n_iter_blend],
+    tot = torch.tensor([st.n_visible, st.n_pairs, st.bytes_algorithmic, st.flops_algorithmic, st_steady.n_iter_scan, st_steady.n_iter_blend],
                        dtype=torch.int64, device="cuda")
     comp = torch.tensor([kern_ms["composite"] / max(frames, 1)], dtype=torch.float64, device="cuda")
     if world > 1:

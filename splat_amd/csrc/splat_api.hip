@@ -713,6 +713,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         // the previous frame's compositor its LDS (C3 +2 %, C3s +4 %; a sixteenth: C3 +1 %, C3s -1 %; a 64th: -15 %).  A frame
         // the caller waits for gets a workgroup per long list (their number a frame ago, plus an eighth).
         unsigned int grid = (m + 7u) / 8u;
+        if (c->sort_hint) grid = std::max<unsigned int>(grid, c->hint_ge2048 / 2u + 16u);       // (at most ~two long lists per workgroup: a close-up has thousands)
         if (awaited) grid = c->sort_hint ? std::max<unsigned int>(grid, c->hint_ge2048 + c->hint_ge2048 / 8u + 16u) : m;
         launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m,
                       (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows, c->one_pass_select ? c->need_hint + 4u * (size_t)c->m_alloc : nullptr,
@@ -1252,6 +1253,7 @@ int splat_set_frame_overlap(splat_ctx* c, int32_t n) {
 int splat_set_option(splat_ctx* c, int32_t option, double value) {
     if (!c) return SPLAT_ERR_INVALID;
     if (option < 1 || option > 31) return fail(c, SPLAT_ERR_INVALID, "unknown option");
+    c->still_frames = 0; c->last_cam_hash = 0;      // (the next frames scan for their walks' starts again: thresholds may have changed)
     double cur;
     if (!load_option(c, option, &cur)) return fail(c, SPLAT_ERR_INVALID, "unknown option");
     if (c->env_pinned & (1u << option)) return SPLAT_OK;      // the operator's environment variable stays in force
@@ -1336,6 +1338,9 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     c->bucket_failed = false;              // key storage is sized at the first frame (prepare_binning)
     for (Slot& sl : c->slots) sl.layout_valid = false;
     c->sort_hint = false;
+    // another scene under every tile: what the walks of the old one needed says nothing (near selection, start hints)
+    if (c->need_hint && c->m_alloc) (void)hipMemset(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc);
+    c->still_frames = 0; c->last_cam_hash = 0;
     return SPLAT_OK;
 }
 
