@@ -495,8 +495,12 @@ bool near_selection(const splat_ctx* c) {
 // ... and is only worth its repair launch on frames that have such lists at all (the previous harvested frame's longest
 // list; nothing known yet: assume so).  A frame without the selection falls back on the sort launches / the compositor's
 // full sort as before.
+// (... and a list of 8192 keys or a few hundred above 2048: on C2 -- 300 k Gaussians at 720p, a few dozen lists barely above 2048 keys, a 0.12-ms frame -- the
+// selection's launch and the repair launch on the compositor's stream cost 9 us more than the sort launches they replace)
 bool near_selection_for_frame(const splat_ctx* c) {
-    return near_selection(c) && (!c->sort_hint || c->hint_maxlen == 0u || c->hint_maxlen > 2048u);
+    if (!near_selection(c)) return false;
+    if (!c->sort_hint || c->hint_maxlen == 0u) return true;
+    return c->hint_maxlen > 2048u && (c->hint_ge8192 != 0u || c->hint_ge2048 >= 256u);
 }
 bool compositor_sorts_long_lists(const splat_ctx* c, unsigned int m) {
     if (c->fused_sort_max < 2048u) return false;

@@ -232,10 +232,10 @@ def test_sort_launch_miss_with_tight_grids():
                 ref, ost = oracle_frame(g, cam)
                 assert st.n_pairs == ost.n_tile_pairs
                 assert image_diff(img, ref)[0] <= 1
-            if near:
-                assert r.frames_dropped() == d0, "near selection has no launch sizes to miss"
-            else:
-                assert r.frames_dropped() > d0, "expected at least one sort-launch miss"
+            # (near selection is taken only by frames with a list of 8192 keys or a few hundred lists beyond 2048 -- this scene's
+            # poses have neither, so both settings size sort launches here; a frame that does select has no launch size to miss:
+            # test_near_selection_renders_the_fully_sorted_frame, the full-size tests)
+            assert r.frames_dropped() > d0, "expected at least one sort-launch miss"
     finally:
         r.close()
 
