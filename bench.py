@@ -764,6 +764,12 @@ def main():
             R.render_device(last_pose, full.data_ptr(), sync=True)
         torch.cuda.synchronize()
         slab_check = bool(torch.equal(full, final))
+        if not slab_check:      # which rows? (a slab's rows that did not arrive look different from pixels rendered differently)
+            bad = (full != final)
+            rows = torch.nonzero(bad.any(dim=1)).flatten().tolist()
+            print("[bench] gathered frame differs from the single-GPU frame: %d pixels in rows %d..%d (%d rows); slabs (tile rows) %s; "
+                  "gathered image all zero in %d of those rows" % (int(bad.sum()), rows[0], rows[-1], len(rows), slabs,
+                                                                    sum(1 for r_ in rows if not bool(final[r_].any()))), file=sys.stderr, flush=True)
         R.set_slab(*slabs[rank])
     if rank == 0:
         per = {k: v / max(frames, 1) for k, v in kern_ms.items()}

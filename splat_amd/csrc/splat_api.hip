@@ -336,6 +336,15 @@ void dfree(T*& p) {
     if (p) { ledger_del((void*)p); (void)hipFree(p); p = nullptr; }
 }
 
+// hipMemset on device memory is ENQUEUED (on the legacy default stream) and may return before the fill has run -- and the
+// context's streams are non-blocking: nothing on them waits for that stream.  A fill that the next launches depend on is
+// waited for here.  (Found with eight processes on one GPU, where the default stream's fill arrives late: the first
+// splat_tile_row_loads of two ranks in eight counted into counters that were zeroed afterwards -- tools/row_loads_stress.py.)
+hipError_t fill_now(void* p, int value, size_t bytes) {
+    hipError_t e = hipMemset(p, value, bytes);
+    return e == hipSuccess ? hipStreamSynchronize(nullptr) : e;
+}
+
 const float* ev_times(const EvSet& s, float t[N_TIMES]) {
     static const int pairs[N_TIMES][2] = {{0, 1}, {1, 2}, {8, 3}, {3, 4}, {5, 6}, {6, 7}};
     for (int k = 0; k < N_TIMES; ++k) {
@@ -432,10 +441,10 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     c->sort_hint = false;                  // another target geometry: the list-length profile is unknown again
     dfree(c->zero_layout);
     HIP_TRY(c, dmalloc(c, &c->zero_layout, sizeof(unsigned int) * (size_t)(m + 1)));
-    HIP_TRY(c, hipMemset(c->zero_layout, 0, sizeof(unsigned int) * (size_t)(m + 1)));
+    HIP_TRY(c, fill_now(c->zero_layout, 0, sizeof(unsigned int) * (size_t)(m + 1)));
     dfree(c->need_hint);
     HIP_TRY(c, dmalloc(c, &c->need_hint, sizeof(unsigned int) * 9u * (size_t)(m + 1)));      // (+ one word per tile behind them: the depth its last selection began at; + four: where its waves' walks started)
-    HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)(m + 1)));
+    HIP_TRY(c, fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
         dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_counts); dfree(s.redo_layout); dfree(s.redo_cursors);
@@ -454,7 +463,7 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
         HIP_TRY(c, dmalloc(c, &s.offsets, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.cursor, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.order, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, hipMemset(s.counts, 0, sizeof(unsigned int) * (size_t)(m + 1)));
+        HIP_TRY(c, fill_now(s.counts, 0, sizeof(unsigned int) * (size_t)(m + 1)));
     }
     c->m_alloc = m + 1;
     return SPLAT_OK;
@@ -721,7 +730,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         if (awaited) grid = c->sort_hint ? std::max<unsigned int>(grid, c->hint_ge2048 + c->hint_ge2048 / 8u + 16u) : m;
         launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m,
                       (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows, c->one_pass_select ? c->need_hint + 4u * (size_t)c->m_alloc : nullptr,
-                      std::min(grid, m));
+                      std::min(grid, m), c->fc.start_hints == 1);
     }
     else if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
@@ -1181,12 +1190,12 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (c->overlap >= 2 && c->pipeline) { if ((e = ensure_copy_stream(c)) != hipSuccess) return bail("hipStreamCreate", e); c->comp2 = c->copy_stream; }
     for (Slot& s : c->slots) {
         if ((e = dmalloc(c, &s.d_status, sizeof(FrameStatus))) != hipSuccess) return bail("hipMalloc(status)", e);
-        if ((e = hipMemset(s.d_status, 0, sizeof(FrameStatus))) != hipSuccess) return bail("hipMemset(status)", e);
+        if ((e = fill_now(s.d_status, 0, sizeof(FrameStatus))) != hipSuccess) return bail("fill_now(status)", e);
         if ((e = hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_binned, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     if ((e = dmalloc(c, &c->d_status_ring, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMalloc(status ring)", e);
-    if ((e = hipMemset(c->d_status_ring, 0, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("hipMemset(status ring)", e);
+    if ((e = fill_now(c->d_status_ring, 0, sizeof(FrameStatus) * EV_RING)) != hipSuccess) return bail("fill_now(status ring)", e);
     if ((e = hipHostMalloc(&c->h_status, sizeof(FrameStatus) * EV_RING, hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc(status)", e);
     std::memset(c->h_status, 0, sizeof(FrameStatus) * EV_RING);
     for (auto& s : c->ring)
@@ -1271,7 +1280,7 @@ int splat_set_option(splat_ctx* c, int32_t option, double value) {
     if (!store_option(c, option, value)) return fail(c, SPLAT_ERR_INVALID, "option value out of range");
     // (another selection size: what the tiles' walks needed under the old one is forgotten)
     if (option == SPLAT_OPT_NEAR_SELECT_KEYS && c->need_hint && c->m_alloc)
-        HIP_TRY(c, hipMemset(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc));
+        HIP_TRY(c, fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc));
     return SPLAT_OK;
 }
 
@@ -1343,7 +1352,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     for (Slot& sl : c->slots) sl.layout_valid = false;
     c->sort_hint = false;
     // another scene under every tile: what the walks of the old one needed says nothing (near selection, start hints)
-    if (c->need_hint && c->m_alloc) (void)hipMemset(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc);
+    if (c->need_hint && c->m_alloc) (void)fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc);
     c->still_frames = 0; c->last_cam_hash = 0;
     return SPLAT_OK;
 }
@@ -1542,7 +1551,7 @@ int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_ou
         for (int k = 0; k < splat_ctx::S_IMGS; ++k) {
             dfree(c->s_img[k]); c->s_used[k] = false;
             HIP_TRY(c, dmalloc(c, &c->s_img[k], bytes));
-            HIP_TRY(c, hipMemset(c->s_img[k], 0, bytes));      // a slab context renders its own rows only: the rest reads as zeros
+            HIP_TRY(c, fill_now(c->s_img[k], 0, bytes));      // a slab context renders its own rows only: the rest reads as zeros
         }
         c->s_cap = bytes;
     }

@@ -131,7 +131,8 @@ void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offs
                    const unsigned int* need_hint, unsigned int* near_m /* per tile: how many of the nearest keys are in order */,
                    unsigned int tiles_x, unsigned int tile_rows /* the tile grid: a tile's selection also looks at its neighbours' hints */,
                    unsigned int* near_thr = nullptr /* one word per tile, kept from frame to frame: the depth its last selection began at */,
-                   unsigned int grid = 0 /* workgroups (each strides over the tile order); 0 = an eighth of the tiles */);
+                   unsigned int grid = 0 /* workgroups (each strides over the tile order); 0 = an eighth of the tiles */,
+                   bool at_rest = false /* the camera of the last frames: selections sized tightly */);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max = 0,

@@ -2755,7 +2755,7 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
                                                           const unsigned int* __restrict__ orig, unsigned int radix_min, unsigned int near_cap,
                                                           const unsigned int* __restrict__ need_hint, unsigned int* __restrict__ near_m,
                                                           unsigned int tiles_x, unsigned int tile_rows, unsigned int* __restrict__ near_thr,
-                                                          unsigned int n_slots) {
+                                                          unsigned int n_slots, unsigned int at_rest) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
     // (an eighth as many workgroups as tiles, each taking the slots blockIdx.x, + gridDim.x, ... of the longest-first order until it
@@ -2806,8 +2806,13 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
         // (While the hint leaves room, the selection is the full workspace: this kernel runs beside the previous frame's
         // compositor, its time is hidden, and a moving camera puts other Gaussians under the tile than the hint saw -- a
         // 36-pose orbit, 10 degrees a frame, lost a third of its rate to repairs with selections sized tightly.)
+        // (A camera at rest needs no room for surprises: half as much again as the walks took, in steps of 256 keys -- what is not
+        // selected is not sorted.)
         if (deepest == 0xffffffffu) want = n;
-        else if (deepest != 0u) want = (deepest + (deepest >> 1) + 128u <= near_cap) ? near_cap : 2u * deepest + 256u;
+        else if (deepest != 0u) {
+            const unsigned int room = deepest + (deepest >> 1) + 128u;
+            want = room <= near_cap ? (at_rest ? min(near_cap, max(512u, (room + 255u) & ~255u)) : near_cap) : 2u * deepest + 256u;
+        }
         if (want > n - (n >> 2)) want = n;      // (three quarters of the list: the whole list, then, and no repair to fear)
     }
     unsigned int m = 0u;
@@ -2817,9 +2822,10 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
         // those are still a workspace-full at most and three quarters of one at least (a moving camera finds its margin in
         // the size of the selection); else the two passes
         // (histogram over a sampled depth range, compaction), which leave the depth for the next frame
-        if (thr != 0u && deepest != 0u && want == near_cap) {
+        if (thr != 0u && deepest != 0u) {
             m = select_by_depth<256>(smem, keys + beg, n, thr, &smn, &smx);
-            if (m > near_cap || m < max(deepest + (deepest >> 1) + 128u, near_cap - (near_cap >> 2)) || m >= n) m = 0u;
+            const unsigned int least = at_rest ? deepest + (deepest >> 3) : max(deepest + (deepest >> 1) + 128u, near_cap - (near_cap >> 2));
+            if (m > near_cap || m < least || m >= n) m = 0u;
         }
         if (m == 0u) {
             unsigned int thr_new = 0u;
@@ -3025,12 +3031,12 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 }
 void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
                    unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
-                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows, unsigned int* near_thr, unsigned int grid) {
+                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows, unsigned int* near_thr, unsigned int grid, bool at_rest) {
     if (!n_tiles) return;
     if (g_knobs->dbg_select_stride) grid = (n_tiles + g_knobs->dbg_select_stride - 1u) / g_knobs->dbg_select_stride;
     if (!grid) grid = (n_tiles + 7u) / 8u;
     hipLaunchKernelGGL(select_near_kernel, dim3(std::min(grid, n_tiles)), dim3(256), 0, s, offsets, order, lens, keys, keys2, status, orig, sort_radix_min(),
-                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr, n_tiles);
+                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr, n_tiles, at_rest ? 1u : 0u);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,

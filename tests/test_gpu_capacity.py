@@ -250,3 +250,18 @@ def test_fuzzed_pose_sequences_through_the_frame_pipeline():
                        timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "15 cases, 0 failures" in r.stdout
+
+
+def test_first_call_after_allocation_counts_into_zeroed_counters_under_contention():
+    """tools/row_loads_stress.py: six processes share the GPU and each asks for the C3 frame's per-tile-row pair counts right
+    after its upload, then again between frames.  The context's fills at allocation time are hipMemset calls, which are
+    only ENQUEUED (on the legacy default stream) when they return, and the context's streams are non-blocking: with the
+    device busy the fill used to land after the first count pass had run (two ranks of eight partitioned the frame from
+    counts of 7.4 M and 44 pairs instead of 8 025 623 -- bench.py's gather then died of a size mismatch).  Every answer of
+    every process must be the frame's."""
+    import subprocess, sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "row_loads_stress.py"), "6", "4"], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert "exit codes [0, 0, 0, 0, 0, 0]" in r.stdout
