@@ -27,6 +27,14 @@ for pos, yaw, pitch in poses:
     cam.update_camera_pose()
     img = np.zeros((H, W), np.uint32)
     st = R.render(cam.to_c(0.01, 15), img)
+    # ... and the frame of a camera AT REST at this pose (the sixth in a row: start hints instead of the early-out's scan, the
+    # selection sized tightly and in one pass) -- it must be the same frame, byte for byte
+    rest = R.device_image(np.zeros((H, W), np.uint32))
+    for _ in range(5):
+        R.render_frame_device(cam.to_c(0.01, 15), rest)
+    st_rest = R.render_frame_device(cam.to_c(0.01, 15), rest, sync=True, want_stats=True)
+    at_rest = R.device_download(rest, H, W)
+    R.device_free(rest)
     t0 = time.time()
     ref, ost = O.render(sd, oracle_camera(cam, 0.01), nthreads=os.cpu_count() or 8)
     mx, cnt = image_diff(img, ref)
@@ -34,12 +42,14 @@ for pos, yaw, pitch in poses:
                pairs_equal=bool(st.n_pairs == ost.n_tile_pairs and st.n_visible == ost.n_visible),
                max_tile_len=int(st.max_tile_len), binning_mode=R.binning_mode(), near_selection_tiles=int(st.n_near_tiles),
                near_selection_repaired=int(st.n_near_fallback), max_channel_diff_lsb=int(mx),
-               pixels_differing=int(cnt), pixels=W * H, oracle_s=round(time.time() - t0, 2))
+               pixels_differing=int(cnt), pixels=W * H, oracle_s=round(time.time() - t0, 2),
+               frame_at_rest_equals_first_frame=bool(np.array_equal(at_rest, img)), scan_iterations_first_frame=int(st.n_iter_scan),
+               scan_iterations_at_rest=int(st_rest.n_iter_scan), near_selection_repaired_at_rest=int(st_rest.n_near_fallback))
     rows.append(row)
     print(row, flush=True)
 R.close()
 summary = dict(workload=wl, poses=rows, worst_lsb=max(r["max_channel_diff_lsb"] for r in rows),
-               worst_pixels=max(r["pixels_differing"] for r in rows))
+               worst_pixels=max(r["pixels_differing"] for r in rows), frames_at_rest_equal=all(r["frame_at_rest_equals_first_frame"] for r in rows))
 print(json.dumps(summary))
 if out:
     json.dump(summary, open(out, "w"), indent=1)
