@@ -193,7 +193,7 @@ struct splat_ctx {
     int redo_armed = 0;                    // moving frames left that still carry the redo launches (adaptive)
     int start_hints = 2;                   // SPLAT_OPT_START_HINTS / SPLAT_START_HINTS: 0 the compositor scans for its walks' starts on every frame; 1 not with
                                            // a camera at rest; 2 nor, three frames of four, with one in slow motion (see enqueue_frame)
-    float last_view[16] = {};              // the previous frame's view matrix: how far did the camera move?
+    float last_view[32] = {};              // the previous frame's view and projection matrices: how far did the camera move?
     uint64_t last_cam_hash = 0;            // the previous frame's camera (and slab) ...
     unsigned int still_frames = 0;         // ... and how many frames in a row it has been the same
     bool one_pass_select = true;           // SPLAT_DBG_ONE_PASS_SELECT=0: near selection always takes its two passes (histogram, compaction)
@@ -625,12 +625,13 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         // than 0.009, translations relative to their size): where they did plus a margin, and every fourth frame the scan,
         // tiles taking turns (>= 2: the frame number rides along).
         float delta = 0.0f;
-        for (int q = 0; q < 16; ++q) {
-            const float a = c->fc.view[q], b = c->last_view[q];
+        for (int q = 0; q < 32; ++q) {          // (view and projection: a zoom is motion too)
+            const float a = q < 16 ? c->fc.view[q] : c->fc.proj[q - 16], b = c->last_view[q];
             const float d = std::fabs(a - b) / std::max(1.0f, std::max(std::fabs(a), std::fabs(b)));
             delta = (d == d) ? std::max(delta, d) : 1.0f;
         }
-        std::memcpy(c->last_view, c->fc.view, sizeof c->last_view);
+        std::memcpy(c->last_view, c->fc.view, sizeof c->fc.view);
+        std::memcpy(c->last_view + 16, c->fc.proj, sizeof c->fc.proj);
         int mode = 0;
         if (c->start_hints >= 1 && c->still_frames >= 3u) mode = 1;
         else if (c->start_hints >= 2 && c->still_frames == 0u && delta < 0.009f) mode = 2 + (int)(c->frame_idx & 0xffffull);
