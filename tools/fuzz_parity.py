@@ -62,7 +62,7 @@ for case in range(ncases if __name__ == "__main__" else 0):
     H, W = int(cam.h), int(cam.w)
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(variant)
-    frames = {}
+    frames, rest = {}, {}
     for mode in (0, splat_amd.MODE_FAST, splat_amd.MODE_LIBM_EXP, splat_amd.MODE_FAST | splat_amd.MODE_LIBM_EXP):
         conv = dict(CONVS[(seed0_case // 7) % len(CONVS)])
         corrected = splat_amd.MODE_CORRECTED_PROJECTION if conv.pop("corrected_projection", 0) else 0
@@ -73,6 +73,12 @@ for case in range(ncases if __name__ == "__main__" else 0):
             img = init.copy()
             st = R.render(cam.to_c(lp, SH_DIMS[seed0_case % len(SH_DIMS)]), img)
             frames[mode] = (img, st)
+            # the same camera again and again: from the fourth frame on it is AT REST (start hints instead of the scan, the
+            # selection sized tightly and in one pass) -- the exact modes must render the same bytes, the fast ones stay within 1
+            for _ in range(5):
+                again = init.copy()
+                R.render(cam.to_c(lp, SH_DIMS[seed0_case % len(SH_DIMS)]), again)
+            rest[mode] = again
         finally:
             R.close()
     # A Gaussian whose view depth is NaN (a non-finite position) is never drawn, but in the reference it takes part in the
@@ -95,6 +101,14 @@ for case in range(ncases if __name__ == "__main__" else 0):
         ok = False
         print("   libm-exp frame == oracle: %s (%d px differ); fast + libm-exp max diff vs oracle %d" %
               (libm_exact, int((frames[splat_amd.MODE_LIBM_EXP][0] != ref).sum()), mx_fl))
+    for mode in (0, splat_amd.MODE_LIBM_EXP):
+        if not np.array_equal(rest[mode], frames[mode][0]):
+            ok = False
+            print("   mode %d: the frame at rest differs from the first frame in %d pixels" % (mode, int((rest[mode] != frames[mode][0]).sum())))
+    dr = np.abs(np.stack([((rest[splat_amd.MODE_FAST] >> sh) & 255).astype(np.int32) - ((img >> sh) & 255).astype(np.int32) for sh in (24, 16, 8, 0)]))
+    if dr[0].max() != 0 or dr[1:].max() > 1:
+        ok = False
+        print("   fast mode at rest vs the exact frame: %d (alpha %d)" % (int(dr[1:].max()), int(dr[0].max())))
     if not ok:
         bad += 1
         print("CASE %d FAILED: %s: pairs %d vs %d, visible %d vs %d, max diff %d (%d px), fast vs exact %d (alpha %d)"
