@@ -823,7 +823,7 @@ def main():
                                         "consecutive frames share the chip)" if swap_chain else ""))
                                     if world > 1 else "single GPU",
                        "frame_overlap": 2 if swap_chain else 1,
-                       "start_hints": int(R.get_option(18)),
+                       "start_hints": int(R.get_option(_abi.OPT_START_HINTS)),
                        "n_visible": int(tot[0]), "n_pairs": int(tot[1]), "max_tile_len": int(st.max_tile_len),
                        "early_out_fallback_waves": int(st.n_fallback), "sort_fallback_tiles": int(st.n_sort_fallback),
                        "k1_blocks_culled": int(st.n_blocks_culled),

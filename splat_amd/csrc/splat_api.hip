@@ -548,6 +548,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->corrected = (c->cfg.mode & SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
     fc->redo_only = 0;
     fc->start_hints = 0;
+    fc->start_light = 0;
     // (a singular cov2d needs lowpass == 0 or a non-PSD cov3d; with lowpass == 0 every Gaussian is
     // looked at so that n_singular stays what the reference would have panicked on)
     fc->cull_blocks = (c->cull_blocks && c->bounds && cam->lowpass > 0.0f) ? 1 : 0;
@@ -636,6 +637,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         if (c->start_hints >= 1 && c->still_frames >= 3u) mode = 1;
         else if (c->start_hints >= 2 && c->still_frames == 0u && delta < 0.009f) mode = 2 + (int)(c->frame_idx & 0xffffull);
         c->fc.start_hints = mode;
+        c->fc.start_light = delta < 0.003f ? 1 : 0;
         // (at rest the scan is paid once, in the first frames after the camera stopped: lists from half the usual length take the
         // early-out then -- 384 instead of 768 keys: C3 3060 -> 3120 frames/s, below that nothing more)
         if (c->start_hints >= 1 && c->still_frames >= 1u) c->fc.early_min = std::min(c->fc.early_min, std::max(c->early_min / 2, 1));

@@ -43,6 +43,7 @@ struct FrameConst {
     int corrected;         // SPLAT_MODE_CORRECTED_PROJECTION: J enters transposed (perspective-shear terms kept)
     int cull_blocks;       // K1 skips 256-Gaussian blocks whose bounds cannot reach the slab (needs lowpass > 0)
     int start_hints;       // compositor: the camera is at rest -- a wave's exact walk may start where the previous frame's did (start_hint) instead of scanning for it
+    int start_light;       // ... in very slow motion: half the margin on a hinted start, the scan every eighth frame instead of every fourth
     int redo_only;         // K1 as a REDO launch: leaves at once unless the frame's scan flagged a tile that outgrew its region
 };
 

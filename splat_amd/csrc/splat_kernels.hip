@@ -2543,8 +2543,10 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     if (early && !need_far && fc.start_hints != 0 && start_hint != nullptr) {
         unsigned int h = (unsigned int)__builtin_amdgcn_readfirstlane((int)start_hint[tile * 4u + wave]);
         if (fc.start_hints >= 2 && h != 0u) {
-            // a camera in slow motion: the previous frames' start with a margin, and every fourth frame (tiles take turns) the scan
-            h = (((unsigned int)fc.start_hints + tile) & 3u) == 0u ? 0u : h + (h >> 3) + 32u;
+            // a camera in slow motion: the previous frames' start with a margin, and every fourth frame (tiles take turns) the scan;
+            // in very slow motion (under ~0.15 degrees a frame: start_light) half the margin, every eighth frame
+            if (fc.start_light) h = (((unsigned int)fc.start_hints + tile) & 7u) == 0u ? 0u : h + (h >> 4) + 16u;
+            else h = (((unsigned int)fc.start_hints + tile) & 3u) == 0u ? 0u : h + (h >> 3) + 32u;
         }
         if (h != 0u) {
             if (h < end - lb) { ws = end - h; hinted = true; }
