@@ -8,6 +8,7 @@ import sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import splat_amd
+from splat_amd import _lib
 from splat_amd.renderer import SplatError
 from helpers import make_camera
 
@@ -24,10 +25,18 @@ for case in range(ncases):
     H, W = int(rng.choice([96, 160, 240])), int(rng.choice([128, 200, 320]))
     R = splat_amd.Renderer()
     g.compute_cov3d(R); R.upload(g)
+    # jumps, and between them stretches of a camera at rest and of one that creeps (0.03-0.35 degrees a frame): the frames
+    # whose exact walks start from the previous frames' hints (SPLAT_OPT_START_HINTS) and whose selections are sized tightly
     poses = []
-    for k in range(12):
-        pos = [(0, 0, 5.0), (0, 0, 1.5), (0.3, 0.2, 0.4), (0, 0, 25.0), (2.0, -1.0, 3.0), (0, 0, 9.0)][int(rng.integers(0, 6))]
-        poses.append(make_camera(H, W, pos, yaw=float(rng.uniform(0, 6.28)), pitch=float(rng.uniform(-0.5, 0.5))).to_c(float(rng.choice([0.01, 0.3])), 15))
+    pos, yaw, pitch, lp = (0, 0, 5.0), 0.0, 0.0, 0.01
+    for k in range(18):
+        r = rng.uniform()
+        if k == 0 or r >= 0.55:
+            pos = [(0, 0, 5.0), (0, 0, 1.5), (0.3, 0.2, 0.4), (0, 0, 25.0), (2.0, -1.0, 3.0), (0, 0, 9.0)][int(rng.integers(0, 6))]
+            yaw, pitch, lp = float(rng.uniform(0, 6.28)), float(rng.uniform(-0.5, 0.5)), float(rng.choice([0.01, 0.3]))
+        elif r >= 0.3:
+            yaw += float(rng.uniform(0.0005, 0.006))
+        poses.append(make_camera(H, W, pos, yaw=yaw, pitch=pitch).to_c(lp, 15))
     garbage = rng.integers(1, 2**32, (H, W), dtype=np.uint64).astype(np.uint32)
     imgs = [R.device_image(garbage) for _ in poses]
     d0 = R.frames_dropped()
@@ -44,6 +53,8 @@ for case in range(ncases):
     got = [R.device_download(im, H, W) for im in imgs]
     wrong = 0
     refs = []
+    hints = R.get_option(_lib.OPT_START_HINTS)
+    R.set_option(_lib.OPT_START_HINTS, 0)                   # (the references: every walk scans for its start)
     for k, p in enumerate(poses):
         ref = np.zeros((H, W), np.uint32)
         R.render(p, ref)
@@ -53,6 +64,7 @@ for case in range(ncases):
             else:
                 bad += 1
                 print("CASE %d seed %d: frame %d differs from its synchronous render (%d px) and is not an untouched skip" % (case, seed0 + case, k, int((got[k] != ref).sum())))
+    R.set_option(_lib.OPT_START_HINTS, hints)
     if wrong > dropped:
         bad += 1
         print("CASE %d seed %d: %d frames untouched but only %d reported dropped" % (case, seed0 + case, wrong, dropped))
