@@ -494,6 +494,13 @@ int ensure_keys(splat_ctx* c, uint64_t want, bool need_keys2) {
 uint64_t default_pair_capacity(const splat_ctx* c) {
     return c->cfg.pair_capacity ? c->cfg.pair_capacity : std::max<uint64_t>(1ull << 22, 16 * c->n);
 }
+// One-pass binning: twice that.  What the tiles' regions do not ask for is handed out to them as room to grow (build_layout),
+// and that room is what a moving camera lives on: with 16 N entries the trained-like surface scene's lists (10-13.5 M pairs,
+// regions asking for 1.5 x + 512 a tile) left none -- C3s at 3 degrees a frame 1450 -> 1650 frames/s with 32 N, a third
+// of the frames no longer binned twice; 2.3 -> 3.4 GB of device memory on C3, 14.8 -> 21 GB on C5, of 288.
+uint64_t default_region_capacity(const splat_ctx* c) {
+    return std::max<uint64_t>(1ull << 22, 32 * c->n);
+}
 
 // Who sorts the lists of more than 2048 keys (see splat_ctx::sort_in_comp).
 // Near selection needs the early-out (a walk that must start at the list's first key needs the whole list in order) and the
@@ -912,7 +919,7 @@ int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
         // (always with the second buffer: a region may hold a list of any length, and a list beyond 16384 keys sorts as
         // runs merged through it -- fixed-stride buckets could cap the lists at what the buffers at hand could sort)
         const bool need2 = true;
-        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, default_pair_capacity(c)), KEY_ENTRIES_MAX);
+        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, default_region_capacity(c)), KEY_ENTRIES_MAX);
         int rc = (want * 8ull * (need2 ? 2u : 1u) * (uint64_t)slots_in_use(c) > c->bucket_bytes) ? SPLAT_ERR_CAPACITY : ensure_keys(c, want, need2);
         if (rc == SPLAT_OK) { fc->bucket_cap = (unsigned int)std::min<uint64_t>(c->cap, KEY_ENTRIES_MAX); return rc; }
         if (rc != SPLAT_ERR_CAPACITY) return rc;
