@@ -494,12 +494,21 @@ int ensure_keys(splat_ctx* c, uint64_t want, bool need_keys2) {
 uint64_t default_pair_capacity(const splat_ctx* c) {
     return c->cfg.pair_capacity ? c->cfg.pair_capacity : std::max<uint64_t>(1ull << 22, 16 * c->n);
 }
-// One-pass binning: twice that.  What the tiles' regions do not ask for is handed out to them as room to grow (build_layout),
-// and that room is what a moving camera lives on: with 16 N entries the trained-like surface scene's lists (10-13.5 M pairs,
-// regions asking for 1.5 x + 512 a tile) left none -- C3s at 3 degrees a frame 1450 -> 1650 frames/s with 32 N, a third
-// of the frames no longer binned twice; 2.3 -> 3.4 GB of device memory on C3, 14.8 -> 21 GB on C5, of 288.
+// One-pass binning: four times that while the key buffers of all frame slots together stay under 8 GiB, twice under 64 GiB (C5 --
+// 6 M Gaussians at 4K -- would take 24 GB at 64 N for nothing measurable at rest).
+// What the tiles' regions do not ask for is handed out to them as room to grow (build_layout), and that room is what a moving
+// camera lives on: with 16 N entries the trained-like surface scene's lists (10-13.5 M pairs, regions asking for 1.5 x + 512 a
+// tile) left none.  C3s at 3 / 10 degrees a frame: 1450 / 1340 frames/s with 16 N, 1650 / 1340 with 32 N, 1725 / 1460 with 64 N
+// (frames no longer binned twice); 36 uncorrelated synchronous poses 602 -> 811 -> 825 frames/s.  2.3 -> 6.1 GB of device
+// memory on C3, 14.8 -> 15.4 GB on C5 (32 N), of 288.
+int slots_in_use(const splat_ctx* c);
 uint64_t default_region_capacity(const splat_ctx* c) {
-    return std::max<uint64_t>(1ull << 22, 32 * c->n);
+    const uint64_t per_entry = 8ull * 2ull * (uint64_t)slots_in_use(c);        // two key buffers in every frame slot
+    const uint64_t GiB = 1ull << 30;
+    uint64_t mult = 16;
+    if (64 * c->n * per_entry <= 8 * GiB) mult = 64;
+    else if (32 * c->n * per_entry <= 64 * GiB) mult = 32;
+    return std::max<uint64_t>(1ull << 22, mult * c->n);
 }
 
 // Who sorts the lists of more than 2048 keys (see splat_ctx::sort_in_comp).

@@ -175,7 +175,7 @@ def test_overflowing_async_frame_is_binned_again_on_the_device(scene_and_poses):
 
 def test_regions_that_ask_for_more_than_the_key_buffer_give_up_their_margins():
     """A frame whose lists FIT the key buffer while their regions with the usual margins (1.5 x + 512 keys a tile) do not
-    -- here: 9216 tiles, whose 512-key margins alone exceed the 4 M entries a small scene starts with: the layout squeezes
+    -- here: 16 384 tiles, whose 512-key margins alone exceed the 7.7 M entries (64 N) this small scene starts with: the layout squeezes
     the margins in proportion instead of cutting the last tiles off (build_layout).  Asynchronous frames from the very
     first one, a moving camera with the redo launches on: every frame is rendered; the buffer grows at the first sync."""
     r = splat_amd.Renderer()
@@ -184,7 +184,7 @@ def test_regions_that_ask_for_more_than_the_key_buffer_give_up_their_margins():
         g = splat_amd.synthetic_scene(120000, 71)
         g.compute_cov3d(r)
         r.upload(g)
-        S, m = 1536, 96 * 96
+        S, m = 2048, 128 * 128
         cams = [make_camera(S, S, (0.0, 0.0, 5.0 - 0.02 * k)) for k in range(6)]
         img = r.device_image(np.zeros((S, S), np.uint32))
         for cam in cams:
