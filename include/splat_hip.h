@@ -240,8 +240,9 @@ int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
                                             region -- so that such a frame is binned again ON THE DEVICE instead of being skipped and
                                             reported (SPLAT_ERR_CAPACITY at the next splat_sync).  0 = off; 1 = adaptive (default):
                                             only while a list has outgrown its region within the last 256 frames -- a scene that
-                                            never does pays nothing, the first such frame after a quiet stretch is skipped and
-                                            reported as before and arms the redo; 2 = on every frame of a moving camera (five
+                                            never does pays nothing; the frame of a camera JUMP carries it too; the first frame of a
+                                            smooth path that outgrows a region after a quiet stretch is skipped and reported as
+                                            before and arms the redo; 2 = on every frame of a moving camera (five
                                             near-empty launches per frame on the binning stream).  SPLAT_OVERFLOW_REDO           */
 #define SPLAT_OPT_START_HINTS 18         /* where a compositor wave's exact walk starts is normally found by a scan of its tile's list
                                             from the near end (the early-out).  With a camera at rest the lists are the previous

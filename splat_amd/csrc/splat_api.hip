@@ -193,6 +193,7 @@ struct splat_ctx {
     int redo_armed = 0;                    // moving frames left that still carry the redo launches (adaptive)
     int start_hints = 2;                   // SPLAT_OPT_START_HINTS / SPLAT_START_HINTS: 0 the compositor scans for its walks' starts on every frame; 1 not with
                                            // a camera at rest; 2 nor, three frames of four, with one in slow motion (see enqueue_frame)
+    bool cam_jumped = false;               // this frame's camera is a jump away from the last frame's: its lists may outgrow any region sized before
     float last_view[32] = {};              // the previous frame's view and projection matrices: how far did the camera move?
     uint64_t last_cam_hash = 0;            // the previous frame's camera (and slab) ...
     unsigned int still_frames = 0;         // ... and how many frames in a row it has been the same
@@ -654,6 +655,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         else if (c->start_hints >= 2 && c->still_frames == 0u && delta < 0.009f) mode = 2 + (int)(c->frame_idx & 0xffffull);
         c->fc.start_hints = mode;
         c->fc.start_light = delta < 0.003f ? 1 : 0;
+        c->cam_jumped = delta >= 0.2f;          // (a cut, not a pan: ~12 degrees or more since the last frame)
         // (at rest the scan is paid once, in the first frames after the camera stopped: lists from half the usual length take the
         // early-out then -- 384 instead of 768 keys: C3 3060 -> 3120 frames/s, below that nothing more)
         if (c->start_hints >= 1 && c->still_frames >= 1u) c->fc.early_min = std::min(c->fc.early_min, std::max(c->early_min / 2, 1));
@@ -712,7 +714,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
             if (hs->overflow == 2u || hs->pad_ == 1u) { c->redo_armed = 256; break; }
         }
     }
-    const bool redo = c->fc.bucket_cap && moved && (c->overflow_redo >= 2 || (c->overflow_redo == 1 && c->redo_armed > 0));
+    // (adaptive: while a list has outgrown its region lately -- or on the frame of a camera JUMP, whose lists have nothing to do with
+    // the ones its regions were sized from: the first such frame used to be the one that was skipped and armed the rest)
+    const bool redo = c->fc.bucket_cap && moved && (c->overflow_redo >= 2 || (c->overflow_redo == 1 && (c->redo_armed > 0 || c->cam_jumped)));
     if (redo && c->redo_armed > 0) --c->redo_armed;
     if (redo) {
         // OVERFLOW REDO.  The regions this frame was binned into were sized for another camera (two frames back on a moving

@@ -153,22 +153,22 @@ def test_overflowing_async_frame_is_binned_again_on_the_device(scene_and_poses):
     assert r.frames_dropped() == d0
     assert image_diff(r.device_download(b, 256, 256), clear_far)[0] <= 1
     assert image_diff(r.device_download(c, 256, 256), clear_near)[0] <= 1
-    # the default (adaptive): quiet so far, the first far frame is skipped and reported as before -- and arms the redo: the next is not
+    # the default (adaptive): the launches ride while a list has outgrown its region lately -- and on the frame of a camera JUMP
+    # (the view matrix differs by 0.2 or more from the last frame's: this far pose), which used to be the frame that was
+    # skipped, reported, and armed the rest.  Quiet for 300 moving frames first (256 disarm; a still camera never counts).
     r.set_option(_lib.OPT_OVERFLOW_REDO, 1)
     wiggle = [near.to_c(0.01), make_camera(256, 256, (0.0, 0.0, 5.001)).to_c(0.01), make_camera(256, 256, (0.0, 0.0, 5.002)).to_c(0.01)]
-    for k in range(300):                                      # (256 moving frames disarm; a still camera never counts)
+    for k in range(300):
         r.render_frame_device(wiggle[k % 3], c)
     r.sync()
     d1 = r.frames_dropped()
     r.render_frame_device(far.to_c(0.01), b)
-    with pytest.raises(SplatError):
-        r.sync()
-    assert r.frames_dropped() == d1 + 1
     r.render_frame_device(near.to_c(0.01), c)
     r.render_frame_device(far.to_c(0.01), b)
     r.sync()
-    assert r.frames_dropped() == d1 + 1
+    assert r.frames_dropped() == d1
     assert image_diff(r.device_download(b, 256, 256), clear_far)[0] <= 1
+    assert image_diff(r.device_download(c, 256, 256), clear_near)[0] <= 1
     for p in (a, b, c):
         r.device_free(p)
 
