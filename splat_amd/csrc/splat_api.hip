@@ -716,6 +716,8 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     }
     // (adaptive: while a list has outgrown its region lately -- or on the frame of a camera JUMP, whose lists have nothing to do with
     // the ones its regions were sized from: the first such frame used to be the one that was skipped and armed the rest)
+    // (... and the frames right behind it: the slots' regions are sized two frames ahead, from lists of before the jump)
+    if (c->cam_jumped && c->overflow_redo == 1) c->redo_armed = std::max(c->redo_armed, 8);
     const bool redo = c->fc.bucket_cap && moved && (c->overflow_redo >= 2 || (c->overflow_redo == 1 && (c->redo_armed > 0 || c->cam_jumped)));
     if (redo && c->redo_armed > 0) --c->redo_armed;
     if (redo) {
