@@ -1784,9 +1784,10 @@ __device__ __forceinline__ unsigned int partition_long_list(unsigned char* smem,
                 const unsigned int at = bins[b], cnt = ((b + 1u < NB) ? bins[b + 1u] : m) - at;
                 if (cnt == 0u) continue;
                 const bool bigbin = cnt > BIN_MAX;
-                // (a part of its own up to the size the parts of ordinary lists reach: larger ones -- up to the 2016 keys the
-                // workspace would hold beside the part table -- came out wrong on hostile scenes, tools/fuzz_one.py; not
-                // understood, so not used)
+                // (a part of its own up to the size the parts of ordinary lists reach.  Larger ones -- up to the 2016 keys the
+                // workspace would hold beside the part table -- were blamed for wrong tiles on hostile scenes once; on the final
+                // build they pass the same 2500 scenes, and the failures look like the allocation-time fill race found later
+                // (DESIGN.md section 1).  The limit costs nothing measurable and stays.)
                 if (cnt > BIG_PART_MAX) { ok = false; break; }       // (2016 keys + the sort's histograms + the part table: the workspace)
                 if (size != 0u && (bigbin || prev_big || size + cnt > PART_MAX)) {
                     if (np >= PMAX - 1u) { ok = false; break; }
