@@ -234,6 +234,26 @@ def surface_leg(R0, image, stream, device, args, counted, leg_drops):
                                  "pairs_equal": bool(int(st.n_pairs) == int(ost.n_tile_pairs) and int(st.n_visible) == int(ost.n_visible)),
                                  "oracle_frames_per_sec": 1.0 / cdt}
             out[name] = leg
+        # ... and in MOTION: yaw steps of 3 and 10 degrees a frame from the bench pose, 100 frames each,
+        # device resident and asynchronous; every frame must be rendered (a skipped one costs nothing)
+        for deg in (3.0, 10.0):
+            cam = splat_amd.Camera(H, W, (0.0, 0.0, 5.0))
+            poses = []
+            for k in range(120):
+                cam.update_camera_pose()
+                poses.append(cam.to_c(0.01, 15))
+                cam.update_yaw_angle(deg * np.pi / 180.0)
+            for k in range(20):
+                R.render_frame_device(poses[k], image.data_ptr())
+            torch.cuda.synchronize()
+            name = "c3s_orbit_%g_deg_per_frame" % deg
+            with counted(name, R):
+                t1 = time.perf_counter()
+                for k in range(20, 120):
+                    R.render_frame_device(poses[k], image.data_ptr())
+                torch.cuda.synchronize()
+                fps = 100 / (time.perf_counter() - t1)
+            out["orbit_%g_deg_per_frame" % deg] = {"frames_per_sec": fps, "frames_dropped": leg_drops[name]}
     finally:
         R.close()
     return out
@@ -690,6 +710,46 @@ def main():
                 splat_amd.Renderer.host_unregister(himg)
             except Exception as e:      # (a driver that will not pin this allocation: the leg is informative only)
                 legs["host_visible_splat_render_registered_fps"] = "unavailable: %s" % e
+            # (2c) splat_render_frame: the same frame as ONE call that ships no zeros (clear fused, pixels cross PCIe once; a
+            # page-locked image is written by the compositor itself) -- fixed pose, then (2d) THE REFERENCE'S LOOP, literally
+            # (src/main.rs:43-78): for each of the 36 orbit poses a pose update (C++ host mirror: splat::Camera, as the Rust
+            # loop's update_camera_pose), one synchronous host-visible frame, wait.  Three forms: render_frame into the
+            # caller's page-locked image, into a pageable one, and the literal pair `clear; render_to_buffer` (splat_render).
+            import ctypes as _C
+            hostlib = _C.CDLL(os.path.join(ROOT, "splat_amd", "libsplat_host.so"))
+            hostlib.splat_host_camera.argtypes = [_C.c_float, _C.c_float, _C.POINTER(_C.c_float), _C.c_float, _C.c_float, _C.c_int,
+                                                  _C.c_float, _C.POINTER(_abi.CameraC)]
+            cam_pos = (_C.c_float * 3)(0.0, 0.0, 5.0)
+            loop_cam = _abi.CameraC()
+            step_rad = np.float32(10.0 * np.pi / 180.0)
+
+            def pose_update(k):      # Camera::update_yaw_angle x k + update_camera_pose (src/camera.rs:41-68, 94-126), in C++
+                hostlib.splat_host_camera(float(H), float(W), cam_pos, float(np.float32(k % 36) * step_rad), 0.0, 1, pipe.LOWPASS,
+                                          _C.byref(loop_cam))
+                return loop_cam
+            pinned_img = R.host_image(H, W)
+            page_img = np.zeros((H, W), np.uint32)
+            for name, buf, literal, fixed in (("host_visible_splat_render_frame_fps", pinned_img, False, True),
+                                              ("reference_loop_fps", pinned_img, False, False),
+                                              ("reference_loop_pageable_image_fps", page_img, False, False),
+                                              ("reference_loop_literal_clear_and_render_to_buffer_fps", page_img, True, False)):
+                for k in range(8):
+                    R.render_frame(cam_c if fixed else pose_update(k), buf)
+                with counted(name):
+                    t1 = time.perf_counter()
+                    for k in range(K):
+                        c_k = cam_c if fixed else pose_update(k)
+                        if literal:
+                            buf[:] = 0                  # color.clear(0), src/main.rs:73
+                            R.render(c_k, buf, want_stats=False)
+                        else:
+                            R.render_frame(c_k, buf)
+                    legs[name] = K / (time.perf_counter() - t1)
+            # the loop's last frame (pose 71 % 36 = 35) must be the device-resident frame of that pose
+            R.render_frame(orbit[35], pinned_img)
+            R.render_frame_device(orbit[35], image.data_ptr(), sync=True)
+            legs["reference_loop_frame_equals_device_frame"] = bool(np.array_equal(pinned_img, image.cpu().numpy().view(np.uint32)))
+            legs["reference_loop_zero_copy"] = int(R.get_option(_abi.OPT_HOST_ZERO_COPY))
             # (3) host-visible: the viewer loop (clear, render, present) with pinned frames in flight: frame k is presented
             # (waited for) while frames k+1.. render and cross PCIe.  Two buffers are what a double-buffered window has;
             # four keep the device's frame pipeline (two binning chains + a compositor) full
@@ -871,6 +931,12 @@ def main():
         }
         if legs:
             out["extra_legs"] = legs
+            # the frame of a MOVING camera -- the only frame the reference renders (src/main.rs:69: `if is_pose_dirty`) -- beside
+            # `value`: device resident and asynchronous like it (the 10-degree steps of src/main.rs:57-60), and the reference's
+            # own loop (pose update + one synchronous host-visible frame)
+            out["value_orbit"] = legs.get("orbit_36_poses_device_resident_fps")
+            out["value_reference_loop"] = legs.get("reference_loop_fps")
+            out["device_bytes_peak_over_scene_bytes"] = dev_peak / float(n * 276)
         if per_rank is not None:
             out["kernel_ms_per_rank"] = per_rank
             out["kernel_ms_slowest_rank"] = {k: max(r[k] for r in per_rank) for k in per}
@@ -970,6 +1036,8 @@ def main():
                 parity_ok = False
         if out.get("extra_legs", {}).get("swap_chain_frames_equal_value_frame") is False:
             parity_ok = False                  # (frames composited side by side must be the frame composited alone)
+        if out.get("extra_legs", {}).get("reference_loop_frame_equals_device_frame") is False:
+            parity_ok = False                  # (a frame the compositor stored into host memory must be the device image's frame)
         print(json.dumps(out))
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY MISS against the oracle: %s\n" % json.dumps(out["parity"]))

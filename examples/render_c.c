@@ -26,6 +26,10 @@ int main(int argc, char** argv) {
         rot[4 * g + 0] = rot[4 * g + 1] = rot[4 * g + 2] = 0.0f; rot[4 * g + 3] = 1.0f;   /* (i,j,k,w) */
         opacity[g] = 1.0f;
     }
+    if (splat_abi_version() != SPLAT_ABI_VERSION || splat_stats_size() != sizeof(splat_stats)) {
+        fprintf(stderr, "libsplat_hip.so was built from another splat_hip.h (ABI %u, this client %d)\n", splat_abi_version(), SPLAT_ABI_VERSION);
+        return 1;
+    }
     splat_ctx* ctx = NULL;
     if (splat_create(NULL, &ctx) != SPLAT_OK) { fprintf(stderr, "splat_create: %s\n", splat_last_error(NULL)); return 1; }
     if (splat_compute_cov3d(ctx, 4, scales, rot, cov3d) != SPLAT_OK ||
@@ -59,6 +63,21 @@ int main(int argc, char** argv) {
     unsigned long long lit = 0;
     for (int i = 0; i < W * H; ++i) lit += (argb[i] & 0xffffff) != 0;
     printf("%llu pixels lit\n", lit);
+    /* the viewer loop's frame (clear + render_to_buffer, src/main.rs:73-74) as one call: the image is written, never read --
+     * into a pageable image (a copy behind the frame) and into a page-locked one (the compositor stores into it directly);
+     * both must be the frame above, which started from zeros */
+    uint32_t* again = (uint32_t*)malloc((size_t)W * H * 4);
+    uint32_t* pinned = (uint32_t*)splat_host_alloc((uint64_t)W * H * 4);
+    if (!again || !pinned) { fprintf(stderr, "out of memory\n"); return 1; }
+    memset(again, 0xab, (size_t)W * H * 4); memset(pinned, 0xcd, (size_t)W * H * 4);
+    if (splat_render_frame(ctx, &cam, again, NULL) != SPLAT_OK || splat_render_frame(ctx, &cam, pinned, NULL) != SPLAT_OK) {
+        fprintf(stderr, "%s\n", splat_last_error(ctx)); return 1;
+    }
+    if (memcmp(again, argb, (size_t)W * H * 4) != 0 || memcmp(pinned, argb, (size_t)W * H * 4) != 0) {
+        fprintf(stderr, "splat_render_frame differs from clear + splat_render\n"); return 3;
+    }
+    printf("splat_render_frame: same frame (pageable and page-locked image)\n");
+    free(again); splat_host_free(pinned);
     free(argb);
     splat_destroy(ctx);
     return lit ? 0 : 2;

@@ -32,6 +32,12 @@ extern "C" {
 
 #define SPLAT_TILE 16            /* 16x16 pixel tiles                                     */
 
+/* Version of this header's struct layouts and entry points.  splat_abi_version() returns the one the LIBRARY was built
+ * with: a binding compiled against another header (splat_stats grew by two fields between versions 4 and 5; a caller that
+ * passes the shorter struct has 16 bytes written past it) compares the two before its first call -- the ctypes binding,
+ * rust/src/pipelines_hip.rs and the C++ host mirror all do -- and splat_stats_size() tells the byte count it will write. */
+#define SPLAT_ABI_VERSION 6
+
 /* modes: bit flags, 0 = the default */
 #define SPLAT_MODE_EXACT 0       /* back-to-front, 8-bit truncation per splat as blend() does it; the exponential of
                                     fragment() is the device's (~1.5 ulp): within 1 LSB of libm's on ~1e-5 of the pixels */
@@ -103,6 +109,8 @@ typedef struct {
     int32_t px0, px1, py0, py1;     /* exactly covered inclusive pixel range; px0>px1 = culled */
 } splat_record;
 
+uint32_t splat_abi_version(void);    /* SPLAT_ABI_VERSION of the library */
+uint64_t splat_stats_size(void);     /* sizeof(splat_stats) as the library writes it */
 void splat_default_config(splat_config* cfg);
 int splat_create(const splat_config* cfg, splat_ctx** out);
 void splat_destroy(splat_ctx* ctx);
@@ -161,6 +169,16 @@ int splat_device_download(splat_ctx* ctx, void* h_dst, const void* d_src, uint64
 /* render_to_buffer: blends the scene onto `argb` (in/out, host, w*h u32).  stats may be NULL. */
 int splat_render(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb, splat_stats* stats);
 
+/* The viewer loop's frame, host-visible: `color.clear(0); pipeline.render_to_buffer(&mut color)` (src/main.rs:73-74) as ONE
+ * synchronous call.  The clear is fused into the compositor and the pixels cross PCIe once, device -> host -- splat_render
+ * (in/out blending, the literal render_to_buffer) ships the caller's zeros up first: 8.3 MB each way at 1080p.  `argb_out`
+ * (w*h u32) is WRITTEN, never read.  A page-locked `argb_out` (splat_host_alloc, or the caller's long-lived buffer after
+ * splat_host_register: the reference's `color`, src/main.rs:62) that the device can address is written by the compositor
+ * itself while the frame is being composited (zero copy, SPLAT_OPT_HOST_ZERO_COPY); any other one is filled by a copy
+ * behind the compositor.  With a slab set only the slab's rows of `argb_out` are written.  stats may be NULL (and should be
+ * in a loop: a statistics frame reads counters back). */
+int splat_render_frame(splat_ctx* ctx, const splat_camera* cam, uint32_t* argb_out, splat_stats* stats);
+
 /* Same with a device-resident image (in/out, w*h u32 in HBM).  Work is enqueued on the
  * context's stream; with sync != 0 (or stats != NULL) the call waits for completion. */
 int splat_render_device(splat_ctx* ctx, const splat_camera* cam, void* d_argb, int32_t sync,
@@ -194,8 +212,9 @@ uint64_t splat_device_bytes(const splat_ctx* ctx, uint64_t* peak);
  * hardware queue with a busy one). */
 int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
 /* Tuning options of a context, for hosts that cannot (or should not) reach them through the environment -- a Rust or C
- * application sets them after splat_create.  None of them changes a pixel: they choose between equivalent schedules
- * and storage sizes.  The SPLAT_* environment variable of the same purpose, when set, is read at splat_create and
+ * application sets them after splat_create.  None of them changes a pixel of an exact-mode frame: they choose between equivalent schedules
+ * and storage sizes (SPLAT_MODE_FAST frames stay within 1 of the exact frame per colour byte whatever
+ * SPLAT_OPT_EARLY_OUT_EPS / SPLAT_OPT_FAST_CLOSE_WIDTH say, but which of those frames it is depends on them).  The SPLAT_* environment variable of the same purpose, when set, is read at splat_create and
  * PINS the option: a later splat_set_option on it leaves the operator's value in force and returns SPLAT_OK
  * (splat_get_option tells what is in force).  splat_set_option waits for the frames in flight; options that size
  * storage (pipeline depth, key buffer bytes, one-pass binning) take effect with the next frame, which re-allocates.
@@ -252,6 +271,12 @@ int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
                                             A start that turns out too shallow is retried deeper, as after any scan: exactness
                                             never rests on the hint.  0 = scan every frame; 1 = camera at rest only; 2 = at rest
                                             and in slow motion (default 2; SPLAT_START_HINTS)                                    */
+#define SPLAT_OPT_HOST_ZERO_COPY 19      /* splat_render_frame into a page-locked image the device can address: 1 = the compositor
+                                            stores its pixels straight into host memory (the image crosses PCIe under the frame),
+                                            0 = device image + a copy behind the frame (default 1; SPLAT_HOST_ZERO_COPY)           */
+#define SPLAT_OPT_KEYS_PER_GAUSSIAN 20   /* one-pass binning: entries of a frame slot's key buffer per Gaussian of the scene, 4..256,
+                                            0 = by the scene's size (default; SPLAT_KEYS_PER_GAUSSIAN).  What the tiles' regions do
+                                            not ask for is their room to grow under a moving camera (SPLAT_OPT_REGION_SPARE)       */
 int splat_set_option(splat_ctx* ctx, int32_t option, double value);
 int splat_get_option(const splat_ctx* ctx, int32_t option, double* value);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */

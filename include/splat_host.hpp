@@ -95,6 +95,11 @@ public:
     // queued; the pixels are in `color` after wait_frame(color).  Keep two buffers in flight
     // (pinned ones from alloc_frame make the copy truly asynchronous).
     void wait_frame(const uint32_t* color);
+    // `color.clear(0); render_to_buffer(&mut color)` (src/main.rs:73-74) as one synchronous call (splat_render_frame): `color` is
+    // written, never read.  pin_frame(color, pixels) once (the reference's buffer lives as long as the window, src/main.rs:62)
+    // lets the compositor write straight into it; unpin_frame before the memory goes away.
+    static void pin_frame(uint32_t* color, size_t pixels);
+    static void unpin_frame(uint32_t* color);
     // The scene is uploaded to the GPU once, at the first frame, and cached (the reference re-reads its
     // public `gaussians` field on every render_to_buffer, src/pipelines.rs:67-79).  After mutating
     // `gaussians` (edits, compute_cov3d after the first frame, ...) call this: the next frame uploads again.
@@ -107,6 +112,7 @@ public:
 protected:
     PipelineBase() = default;
     void render(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color);
+    void render_frame(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color);
     void stream(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color);
     void ensure(const GaussianList& g);
     splat_ctx* ctx_ = nullptr;
@@ -120,6 +126,7 @@ public:
     GaussianSplatPipeline01(std::vector<Gaussian> gaussians, Camera camera);
     // Blends onto `color` (w*h u32, 0xAARRGGBB) exactly as src/pipelines.rs:66-86 does.
     void render_to_buffer(uint32_t* color);
+    void render_frame_to_buffer(uint32_t* color);   // clear + render_to_buffer, src/main.rs:73-74, in one call (see PipelineBase)
     void stream_frame(uint32_t* color);        // cleared frame, asynchronous (see PipelineBase)
     std::vector<Gaussian> gaussians;   // pub
     Camera camera;                     // pub
@@ -131,6 +138,7 @@ class GaussianSplatPipeline02 : public detail::PipelineBase {
 public:
     GaussianSplatPipeline02(GaussianList gaussians, Camera camera);
     void render_to_buffer(uint32_t* color);    // src/pipelines.rs:260-280
+    void render_frame_to_buffer(uint32_t* color);
     void stream_frame(uint32_t* color);
     GaussianList gaussians;            // pub
     Camera camera;                     // pub

@@ -32,6 +32,10 @@ pub const SPLAT_OPT_FRAME_OVERLAP: i32 = 15;
 pub const SPLAT_OPT_NEAR_SELECT_KEYS: i32 = 16;
 pub const SPLAT_OPT_OVERFLOW_REDO: i32 = 17;
 pub const SPLAT_OPT_START_HINTS: i32 = 18;
+pub const SPLAT_OPT_HOST_ZERO_COPY: i32 = 19;
+pub const SPLAT_OPT_KEYS_PER_GAUSSIAN: i32 = 20;
+/// SPLAT_ABI_VERSION of the header this file mirrors; compared with splat_abi_version() before the first call
+pub const SPLAT_ABI_VERSION: u32 = 6;
 
 #[repr(C)] pub struct SplatCtx { _private: [u8; 0] }
 #[repr(C)] pub struct SplatMulti { _private: [u8; 0] }
@@ -70,6 +74,8 @@ pub struct SplatRecord {
 }
 
 extern "C" {
+    pub fn splat_abi_version() -> u32;
+    pub fn splat_stats_size() -> u64;
     pub fn splat_default_config(cfg: *mut SplatConfig);
     pub fn splat_create(cfg: *const SplatConfig, out: *mut *mut SplatCtx) -> c_int;
     pub fn splat_destroy(ctx: *mut SplatCtx);
@@ -81,6 +87,8 @@ extern "C" {
     pub fn splat_set_slab(ctx: *mut SplatCtx, tile_row0: i32, tile_row1: i32) -> c_int;
     pub fn splat_tile_row_loads(ctx: *mut SplatCtx, cam: *const SplatCamera, row_pairs: *mut u64, n_rows: i32) -> c_int;
     pub fn splat_render(ctx: *mut SplatCtx, cam: *const SplatCamera, argb: *mut u32, stats: *mut SplatStats) -> c_int;
+    // `color.clear(0); render_to_buffer(&mut color)` (src/main.rs:73-74) in one call: argb_out is written, never read
+    pub fn splat_render_frame(ctx: *mut SplatCtx, cam: *const SplatCamera, argb_out: *mut u32, stats: *mut SplatStats) -> c_int;
     pub fn splat_render_device(ctx: *mut SplatCtx, cam: *const SplatCamera, d_argb: *mut c_void,
                                sync: i32, stats: *mut SplatStats) -> c_int;
     pub fn splat_render_frame_device(ctx: *mut SplatCtx, cam: *const SplatCamera, d_argb: *mut c_void,

@@ -50,6 +50,9 @@ fn check(ctx: *mut ffi::SplatCtx, rc: i32, what: &str) {
 
 fn create_and_upload(pos4: &[f32], cov3d: &[f32], opacity: &[f32], sh: &[f32]) -> Gpu {
     unsafe {
+        // a libsplat_hip.so built from another header would write a splat_stats of another size into ours
+        assert!(ffi::splat_abi_version() == ffi::SPLAT_ABI_VERSION && ffi::splat_stats_size() as usize == std::mem::size_of::<ffi::SplatStats>(),
+                "libsplat_hip.so speaks ABI version {}, this crate {}", ffi::splat_abi_version(), ffi::SPLAT_ABI_VERSION);
         let mut cfg: ffi::SplatConfig = std::mem::zeroed();
         ffi::splat_default_config(&mut cfg);
         let mut ctx = std::ptr::null_mut();
@@ -63,6 +66,15 @@ fn create_and_upload(pos4: &[f32], cov3d: &[f32], opacity: &[f32], sh: &[f32]) -
 fn render(gpu: &Gpu, cam: &ffi::SplatCamera, color: &mut euc::Buffer<u32, 2>) {
     let rc = unsafe { ffi::splat_render(gpu.0, cam, color.raw_mut().as_mut_ptr(), std::ptr::null_mut()) };
     check(gpu.0, rc, "splat_render");
+}
+
+/// The viewer loop's pair `color.clear(0); pipeline.render_to_buffer(&mut color)` (src/main.rs:73-74) as one call: `color` is
+/// written, never read -- no upload of the cleared image, the clear fused into the compositor.  Pin `color`'s storage once
+/// (`ffi::splat_host_register(color.raw_mut().as_mut_ptr() as *mut _, 4 * w * h)` next to its creation, src/main.rs:62;
+/// unregister before it is dropped) and the compositor writes the pixels straight into it.
+fn render_frame(gpu: &Gpu, cam: &ffi::SplatCamera, color: &mut euc::Buffer<u32, 2>) {
+    let rc = unsafe { ffi::splat_render_frame(gpu.0, cam, color.raw_mut().as_mut_ptr(), std::ptr::null_mut()) };
+    check(gpu.0, rc, "splat_render_frame");
 }
 
 /// GaussianSplatPipeline02 (src/pipelines.rs:172-175): the SoA scene IS the ABI's layout.
@@ -82,6 +94,12 @@ impl GaussianSplatPipeline02Hip {
         let gpu = self.gpu.get_or_init(|| create_and_upload(g.positions_slice(), g.cov3d_slice(), g.opacities_slice(), g.sh_slice()));
         render(gpu, &camera_constants(&self.camera, 0.3), color);
     }
+    /// replaces the pair at src/main.rs:73-74 (clear + render_to_buffer); the result is the same image
+    pub fn render_frame_to_buffer(&self, color: &mut euc::Buffer<u32, 2>) {
+        let g = &self.gaussians;
+        let gpu = self.gpu.get_or_init(|| create_and_upload(g.positions_slice(), g.cov3d_slice(), g.opacities_slice(), g.sh_slice()));
+        render_frame(gpu, &camera_constants(&self.camera, 0.3), color);
+    }
 }
 
 /// GaussianSplatPipeline01 (src/pipelines.rs:54-57): Vec<Gaussian> is AoS and not repr(C), so the four arrays are
@@ -97,9 +115,8 @@ impl GaussianSplatPipeline01Hip {
     pub fn new(gaussians: Vec<Gaussian>, camera: Camera) -> Self {
         Self { gaussians, camera, gpu: OnceCell::new() }
     }
-    /// src/pipelines.rs:66-86
-    pub fn render_to_buffer(&self, color: &mut euc::Buffer<u32, 2>) {
-        let gpu = self.gpu.get_or_init(|| {
+    fn gpu(&self) -> &Gpu {
+        self.gpu.get_or_init(|| {
             let n = self.gaussians.len();
             let (mut pos4, mut cov, mut op, mut sh) = (vec![0f32; 4 * n], vec![0f32; 9 * n], vec![0f32; n], vec![0f32; 48 * n]);
             for (i, g) in self.gaussians.iter().enumerate() {
@@ -110,7 +127,14 @@ impl GaussianSplatPipeline01Hip {
                 sh[48 * i..48 * i + 48].copy_from_slice(g.sh.as_slice());
             }
             create_and_upload(&pos4, &cov, &op, &sh)
-        });
-        render(gpu, &camera_constants(&self.camera, 0.01), color);
+        })
+    }
+    /// src/pipelines.rs:66-86
+    pub fn render_to_buffer(&self, color: &mut euc::Buffer<u32, 2>) {
+        render(self.gpu(), &camera_constants(&self.camera, 0.01), color);
+    }
+    /// replaces the pair at src/main.rs:73-74 (clear + render_to_buffer); the result is the same image
+    pub fn render_frame_to_buffer(&self, color: &mut euc::Buffer<u32, 2>) {
+        render_frame(self.gpu(), &camera_constants(&self.camera, 0.01), color);
     }
 }

@@ -44,6 +44,8 @@ class Record(C.Structure):
 # every symbol include/splat_hip.h declares: (name, restype, argtypes)
 _fp = C.POINTER(C.c_float)
 SYMBOLS = [
+    ("splat_abi_version", C.c_uint32, []),
+    ("splat_stats_size", C.c_uint64, []),
     ("splat_default_config", None, [C.POINTER(Config)]),
     ("splat_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     ("splat_destroy", None, [C.c_void_p]),
@@ -53,6 +55,7 @@ SYMBOLS = [
     ("splat_set_slab", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     ("splat_tile_row_loads", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint64), C.c_int32]),
     ("splat_render", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
+    ("splat_render_frame", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
     ("splat_render_device", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     ("splat_render_frame_device", C.c_int, [C.c_void_p, C.POINTER(CameraC), C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     ("splat_sync", C.c_int, [C.c_void_p]),
@@ -120,6 +123,9 @@ OPT_FRAME_OVERLAP = 15
 OPT_NEAR_SELECT_KEYS = 16
 OPT_OVERFLOW_REDO = 17
 OPT_START_HINTS = 18
+OPT_HOST_ZERO_COPY = 19
+OPT_KEYS_PER_GAUSSIAN = 20
+ABI_VERSION = 6          # SPLAT_ABI_VERSION of the header these structures were written against
 
 _LIB = None
 
@@ -137,5 +143,9 @@ def lib():
             fn = getattr(L, name)   # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        # a library built from another header would write a splat_stats of another size into ours
+        if L.splat_abi_version() != ABI_VERSION or L.splat_stats_size() != C.sizeof(Stats):
+            raise RuntimeError("splat_amd: %s speaks ABI version %d (splat_stats of %d bytes), this binding %d (%d bytes): rebuild"
+                               % (LIB_PATH, L.splat_abi_version(), L.splat_stats_size(), ABI_VERSION, C.sizeof(Stats)))
         _LIB = L
     return _LIB

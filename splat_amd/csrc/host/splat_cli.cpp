@@ -13,7 +13,7 @@
 int main(int argc, char** argv) {
     const char* ply = nullptr; const char* out = nullptr;
     int W = 800, H = 600, frames = 36;
-    bool streaming = false, fast = false;
+    bool streaming = false, fast = false, one_call = false;
     int in_flight = 2;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--ply") && i + 1 < argc) ply = argv[++i];
@@ -22,8 +22,9 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--stream")) streaming = true;
         else if (!std::strcmp(argv[i], "--in-flight") && i + 1 < argc) in_flight = std::max(1, std::min(4, std::atoi(argv[++i])));
+        else if (!std::strcmp(argv[i], "--frame")) one_call = true;   // clear + render_to_buffer as ONE call (render_frame_to_buffer) into a pinned `color`
         else if (!std::strcmp(argv[i], "--fast")) fast = true;      // SPLAT_MODE_FAST: every colour byte within 1 of the exact frame
-        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--stream [--in-flight 1..4]] [--fast] [--out frame.ppm]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: splat_cli [--ply file] [--size W H] [--frames N] [--frame | --stream [--in-flight 1..4]] [--fast] [--out frame.ppm]\n"); return 2; }
     }
     try {
         std::printf("Loading gaussians from %s\n", ply ? ply : "naive_gaussians()");
@@ -54,16 +55,21 @@ int main(int argc, char** argv) {
             for (auto* b : buf) splat::GaussianSplatPipeline01::free_frame(b);
             frames = 0;
         }
+        if (one_call && !streaming) splat::GaussianSplatPipeline01::pin_frame(color.data(), color.size());
         for (int f = 0; f < frames; ++f) {
             auto t0 = std::chrono::steady_clock::now();
             pipeline.camera.update_camera_pose();
-            std::fill(color.begin(), color.end(), 0u);        // Buffer2d::fill([W,H], 0)
-            pipeline.render_to_buffer(color.data());
+            if (one_call) pipeline.render_frame_to_buffer(color.data());      // src/main.rs:73-74 as one call: nothing uploaded
+            else {
+                std::fill(color.begin(), color.end(), 0u);    // Buffer2d::fill([W,H], 0)
+                pipeline.render_to_buffer(color.data());
+            }
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::printf("Rendering took %.3f ms (gpu %.3f ms, %llu visible, %llu pairs)\n", ms, pipeline.last_stats.ms_total,
                         (unsigned long long)pipeline.last_stats.n_visible, (unsigned long long)pipeline.last_stats.n_pairs);
             pipeline.camera.update_yaw_angle(10.0f * 3.14159265f / 180.0f);   // Key::Right
         }
+        if (one_call && !streaming) splat::GaussianSplatPipeline01::unpin_frame(color.data());
         if (out) {
             FILE* fp = std::fopen(out, "wb");
             if (!fp) { std::perror(out); return 1; }

@@ -348,6 +348,9 @@ void PipelineBase::set_mode(int mode) {
 }
 void PipelineBase::ensure(const GaussianList& g) {
     if (!ctx_) {
+        // (a libsplat_hip.so built from another header would write a splat_stats of another size into last_stats)
+        if (splat_abi_version() != SPLAT_ABI_VERSION || splat_stats_size() != sizeof(splat_stats))
+            throw std::runtime_error("libsplat_hip.so was built from another include/splat_hip.h (ABI version mismatch)");
         splat_config cfg;
         splat_default_config(&cfg);
         cfg.mode = mode_;
@@ -364,6 +367,15 @@ void PipelineBase::render(const GaussianList& g, const Camera& cam, float lowpas
     splat_camera c = cam.constants(lowpass, 15);   // the literal at src/pipelines.rs:100,189
     check(splat_render(ctx_, &c, color, &last_stats), ctx_, "splat_render");
 }
+void PipelineBase::render_frame(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color) {
+    ensure(g);
+    splat_camera c = cam.constants(lowpass, 15);
+    check(splat_render_frame(ctx_, &c, color, nullptr), ctx_, "splat_render_frame");      // (no statistics: they are read back from the device)
+}
+void PipelineBase::pin_frame(uint32_t* color, size_t pixels) {
+    if (splat_host_register(color, (uint64_t)pixels * 4) != SPLAT_OK) throw std::runtime_error("splat_host_register: the driver cannot page-lock this memory");
+}
+void PipelineBase::unpin_frame(uint32_t* color) { (void)splat_host_unregister(color); }
 void PipelineBase::stream(const GaussianList& g, const Camera& cam, float lowpass, uint32_t* color) {
     ensure(g);
     splat_camera c = cam.constants(lowpass, 15);
@@ -388,6 +400,10 @@ void GaussianSplatPipeline01::render_to_buffer(uint32_t* color) {
     if (soa_.num_gaussians != gaussians.size() || uploaded_ == nullptr) soa_ = GaussianList::from_vec(gaussians, false);
     render(soa_, camera, 0.01f, color);
 }
+void GaussianSplatPipeline01::render_frame_to_buffer(uint32_t* color) {
+    if (soa_.num_gaussians != gaussians.size() || uploaded_ == nullptr) soa_ = GaussianList::from_vec(gaussians, false);
+    render_frame(soa_, camera, 0.01f, color);
+}
 void GaussianSplatPipeline01::stream_frame(uint32_t* color) {
     if (soa_.num_gaussians != gaussians.size() || uploaded_ == nullptr) soa_ = GaussianList::from_vec(gaussians, false);
     stream(soa_, camera, 0.01f, color);
@@ -395,6 +411,7 @@ void GaussianSplatPipeline01::stream_frame(uint32_t* color) {
 void GaussianSplatPipeline02::stream_frame(uint32_t* color) { stream(gaussians, camera, 0.3f, color); }
 GaussianSplatPipeline02::GaussianSplatPipeline02(GaussianList g, Camera cam) : gaussians(std::move(g)), camera(std::move(cam)) {}
 void GaussianSplatPipeline02::render_to_buffer(uint32_t* color) { render(gaussians, camera, 0.3f, color); }
+void GaussianSplatPipeline02::render_frame_to_buffer(uint32_t* color) { render_frame(gaussians, camera, 0.3f, color); }
 
 }  // namespace splat
 
@@ -459,13 +476,14 @@ int splat_host_render(int pipeline, const char* ply_path, float h, float w, cons
         splat::Vec3 p{pos[0], pos[1], pos[2]};
         splat::Camera cam(h, w, &p);
         cam.update_camera_pose();
-        if (pipeline == 1) {
+        // pipeline 1 / 2: render_to_buffer (blends onto `color`); 11 / 12: render_frame_to_buffer (`color` is written, never read)
+        if (pipeline == 1 || pipeline == 11) {
             for (auto& g : v) g.compute_cov3d();               // src/main.rs:24-26
             splat::GaussianSplatPipeline01 pl(v, cam);
-            pl.render_to_buffer(color);
+            if (pipeline == 1) pl.render_to_buffer(color); else pl.render_frame_to_buffer(color);
         } else {
             splat::GaussianSplatPipeline02 pl(splat::GaussianList::from_vec(v), cam);
-            pl.render_to_buffer(color);
+            if (pipeline == 2) pl.render_to_buffer(color); else pl.render_frame_to_buffer(color);
         }
         return 0;
     } catch (const std::exception& e) {

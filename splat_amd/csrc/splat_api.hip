@@ -54,8 +54,7 @@ struct Slot {                  // everything one frame writes before the image
     unsigned int* order = nullptr;
     unsigned int* lens = nullptr;           // list length per tile (the list starts at offsets[tile])
     // Binning again on the device (overflow redo): counters, regions and cursors of a frame whose lists outgrew the regions
-    // it was given -- its count pass and second binning pass write here, not into the copies the pipeline hands on
-    unsigned int* redo_counts = nullptr;
+    // it was given -- its second binning pass writes here, not into the copies the pipeline hands on
     unsigned int* redo_layout = nullptr;
     unsigned int* redo_cursors = nullptr;
     uint64_t layout_cam[2] = {0, 0};        // per copy of the layout: a hash of the camera whose lists sized it
@@ -222,6 +221,8 @@ struct splat_ctx {
     bool streamed_call = false;            // splat_render_stream is rendering: its frames stay on lane 0 (lane 1's stream carries their copies)
     hipEvent_t pre_wait = nullptr;         // one-shot: the next frame's compositor waits for it (splat_render_stream: its image is still crossing PCIe)
     uint32_t env_pinned = 0;               // bit k: SPLAT_OPT_k was set from the environment at splat_create (splat_set_option leaves it alone)
+    int host_zero_copy = 1;                // SPLAT_OPT_HOST_ZERO_COPY: splat_render_frame's compositor stores into a device-addressable host image
+    unsigned int keys_per_gaussian = 0;    // SPLAT_OPT_KEYS_PER_GAUSSIAN: 0 = default_region_capacity decides
     splat::CommState* comm = nullptr;      // multi-GPU: RCCL communicator + partition (splat_multi.hip)
     std::string err;
 };
@@ -369,7 +370,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow) c->frames_dropped++;
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) c->bucket_overflow = true;           // a tile's list outgrew its region: the layouts are stale
-    if (st.overflow == 2 || st.pad_ == 1u) c->redo_armed = 256;  // ... or did and was binned again on the device: keep the redo launches on
+    if (st.overflow == 2 || st.redone == 1u) c->redo_armed = 256;  // ... or did and was binned again on the device: keep the redo launches on
     if (st.layout_total > c->cap) c->layout_want = std::max<uint64_t>(c->layout_want, st.layout_total);   // the regions were cut off
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
@@ -448,10 +449,9 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     HIP_TRY(c, fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
-        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_counts); dfree(s.redo_layout); dfree(s.redo_cursors);
+        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_layout); dfree(s.redo_cursors);
         s.layout_valid = false; s.flip = 0;
         HIP_TRY(c, dmalloc(c, &s.near_m, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, dmalloc(c, &s.redo_counts, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.redo_layout, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.redo_cursors, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.repair_mask, sizeof(unsigned int) * (size_t)(m + 1)));
@@ -503,13 +503,21 @@ uint64_t default_pair_capacity(const splat_ctx* c) {
 // (frames no longer binned twice); 36 uncorrelated synchronous poses 602 -> 811 -> 825 frames/s.  2.3 -> 6.1 GB of device
 // memory on C3, 14.8 -> 15.4 GB on C5 (32 N), of 288.
 int slots_in_use(const splat_ctx* c);
-uint64_t default_region_capacity(const splat_ctx* c) {
+uint64_t region_capacity_for(const splat_ctx* c, uint64_t mult) { return std::max<uint64_t>(1ull << 22, mult * c->n); }
+uint64_t default_region_multiplier(const splat_ctx* c) {
+    if (c->keys_per_gaussian) return c->keys_per_gaussian;
     const uint64_t per_entry = 8ull * 2ull * (uint64_t)slots_in_use(c);        // two key buffers in every frame slot
     const uint64_t GiB = 1ull << 30;
     uint64_t mult = 16;
     if (64 * c->n * per_entry <= 8 * GiB) mult = 64;
     else if (32 * c->n * per_entry <= 64 * GiB) mult = 32;
-    return std::max<uint64_t>(1ull << 22, mult * c->n);
+    // ... and never more than a quarter of what the device has free right now: a GPU shared with other contexts (eight slab
+    // ranks on one device, a host application's own allocations) takes the smaller buffer at once instead of failing the large one
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b != 0)
+        while (mult > 16 && region_capacity_for(c, mult) * per_entry > (uint64_t)free_b / 4u) mult >>= 1;
+    else (void)hipGetLastError();
+    return mult;
 }
 
 // Who sorts the lists of more than 2048 keys (see splat_ctx::sort_in_comp).
@@ -711,7 +719,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         for (int q = 0; q < EV_RING; ++q) {
             if (!c->ring[q].used || q == r) continue;
             const volatile FrameStatus* hs = &c->h_status[q];
-            if (hs->overflow == 2u || hs->pad_ == 1u) { c->redo_armed = 256; break; }
+            if (hs->overflow == 2u || hs->redone == 1u) { c->redo_armed = 256; break; }
         }
     }
     // (adaptive: while a list has outgrown its region lately -- or on the frame of a camera JUMP, whose lists have nothing to do with
@@ -722,15 +730,16 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     if (redo && c->redo_armed > 0) --c->redo_armed;
     if (redo) {
         // OVERFLOW REDO.  The regions this frame was binned into were sized for another camera (two frames back on a moving
-        // path): if the scan above found a list beyond its region, the frame is binned again right here -- count pass
-        // against the empty layout, regions that fit exactly this camera, K1, scan -- into copies of their own; if not
+        // path): if the scan above found a list beyond its region, the frame is binned again right here -- regions that
+        // fit exactly this camera (from the counts the first pass left), K1, scan -- into copies of their own; if not
         // (the usual case) every one of these launches reads one word and leaves.  Either way the kernels behind see a
         // complete frame: nothing is skipped, nothing to report, nothing for the caller to render again.
+        // (No count pass: K1's reservations keep counting past a region's end -- cursor minus region start IS the tile's exact
+        // pair count, overflowed or not (the scan's `raw`) -- and the scan leaves cursors and regions alone: the regions that
+        // fit this camera are built straight from them.  One K1 where round 5 ran two.)
         FrameConst fr = c->fc;
         fr.redo_only = 1;
-        HIP_TRY(c, hipMemsetAsync(s.redo_counts, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));
-        launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_counts, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout);
-        launch_layout(bs, m, s.redo_counts, c->zero_layout, s.redo_layout, s.redo_cursors, c->fc.bucket_cap, nullptr, nullptr, c->region_spare, d_st);
+        launch_layout(bs, m, cursors, layout, s.redo_layout, s.redo_cursors, c->fc.bucket_cap, nullptr, nullptr, c->region_spare, d_st);
         launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, s.redo_layout);
         launch_scan(bs, m, s.redo_cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], s.redo_layout,
                     nullptr, nullptr, c->region_spare, near_cap ? s.repair_mask : nullptr, true);
@@ -934,8 +943,16 @@ int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
         // (always with the second buffer: a region may hold a list of any length, and a list beyond 16384 keys sorts as
         // runs merged through it -- fixed-stride buckets could cap the lists at what the buffers at hand could sort)
         const bool need2 = true;
-        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, default_region_capacity(c)), KEY_ENTRIES_MAX);
-        int rc = (want * 8ull * (need2 ? 2u : 1u) * (uint64_t)slots_in_use(c) > c->bucket_bytes) ? SPLAT_ERR_CAPACITY : ensure_keys(c, want, need2);
+        // The buffer that does not fit (the byte budget, or the allocation itself fails: a device with less free memory than
+        // the default assumes) is tried again at half the size, down to the 16 entries per Gaussian the two-pass path would
+        // start with, before one-pass binning is given up for the scene.
+        int rc = SPLAT_ERR_CAPACITY;
+        for (uint64_t mult = default_region_multiplier(c); ; mult >>= 1) {
+            const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, region_capacity_for(c, mult)), KEY_ENTRIES_MAX);
+            rc = (want * 8ull * (need2 ? 2u : 1u) * (uint64_t)slots_in_use(c) > c->bucket_bytes) ? SPLAT_ERR_CAPACITY : ensure_keys(c, want, need2);
+            if (rc != SPLAT_ERR_CAPACITY || mult <= 16 || want <= c->cap) break;
+            (void)hipGetLastError();
+        }
         if (rc == SPLAT_OK) { fc->bucket_cap = (unsigned int)std::min<uint64_t>(c->cap, KEY_ENTRIES_MAX); return rc; }
         if (rc != SPLAT_ERR_CAPACITY) return rc;
         c->bucket_failed = true;                          // no room: exactly sized lists instead
@@ -1051,40 +1068,56 @@ void free_scene(splat_ctx* c) {
 namespace {
 // One option, validated and stored (include/splat_hip.h SPLAT_OPT_*).  The caller has quiesced the context where that
 // matters.  false: unknown option or value out of range.
-bool store_option(splat_ctx* c, int opt, double v) {
+// dry: validate only (splat_set_option checks the value before it touches anything, pinned options included)
+bool store_option(splat_ctx* c, int opt, double v, bool dry = false) {
     if (!(v == v)) return false;
+#define SPLAT_DRY_ if (dry) return true
     switch (opt) {
         case SPLAT_OPT_PIPELINE_DEPTH: {
             if (v < 1.0 || v > 6.0) return false;
+            SPLAT_DRY_;
             const int p = (int)v <= 1 ? 0 : (int)v;
             if (p != c->pipeline) {
                 // another number of frame slots: the key buffers exist per slot in use and are made again by the next frame
                 for (Slot& sl : c->slots) { dfree(sl.keys); dfree(sl.keys2); sl.layout_valid = false; sl.flip = 0; sl.used = false; sl.free_ring = -1; }
                 c->cap = 0; c->have_keys2 = false; c->frame_idx = 0;
                 c->pipeline = p;
-                if (p == 0) { c->comp2 = nullptr; c->overlap = 1; }
+                // One stream for everything has no compositor lanes: the lane state goes as splat_set_frame_overlap(1) leaves it
+                // (unless the operator pinned the overlap from the environment: then only the second lane's stream is dropped, and
+                // the lanes come back -- ensure_lane, at the next frame that may overlap -- when the depth goes up again).  A depth
+                // raised again does NOT restore an overlap of 2 set from code: set it again.
+                if (p == 0) {
+                    c->comp2 = nullptr;
+                    if (!(c->env_pinned & (1u << SPLAT_OPT_FRAME_OVERLAP))) c->overlap = 1;
+                    c->lane[0] = splat_ctx::Lane{}; c->lane[1] = splat_ctx::Lane{};
+                    for (auto& e : c->img_tab) e = splat_ctx::ImgRec{};
+                    c->last_lane = 0;
+                }
             }
             return true;
         }
-        case SPLAT_OPT_FUSED_SORT_MAX: if (v < 0.0 || v > 2048.0) return false; c->fused_sort_max = (unsigned int)v; return true;
-        case SPLAT_OPT_REGION_SPARE: if (v < 1.0) return false; c->region_spare = (float)v; return true;
-        case SPLAT_OPT_EARLY_OUT_EPS: if (v < 0.0 || v > 1.0) return false; c->early_eps = (float)v; return true;
-        case SPLAT_OPT_EARLY_OUT_MIN_LIST: if (v < 0.0 || v > 1e9) return false; c->early_min = (int)v; return true;
-        case SPLAT_OPT_EARLY_OUT_SCAN_EIGHTHS: if (v < 1.0 || v > 8.0) return false; c->early_scan8 = (int)v; return true;
-        case SPLAT_OPT_SORT_IN_COMPOSITOR: if (v < -1.0 || v > 1.0) return false; c->sort_in_comp = v < 0.0 ? -1 : (v != 0.0 ? 1 : 0); return true;
-        case SPLAT_OPT_PAIR_WALK: if (v < -1.0 || v > 1.0) return false; c->pair_mode = v < 0.0 ? -1 : (v != 0.0 ? 1 : 0); return true;
-        case SPLAT_OPT_TIMING_EVERY: if (v < 1.0 || v > 1e9) return false; c->timing_every = (int)v; return true;
-        case SPLAT_OPT_BLOCK_CULLING: if (v != 0.0 && v != 1.0) return false; c->cull_blocks = v != 0.0; return true;
-        case SPLAT_OPT_ONE_PASS_BINNING: if (v != 0.0 && v != 1.0) return false; c->use_buckets = v != 0.0; return true;
-        case SPLAT_OPT_KEY_BUFFER_BYTES: if (v < 0.0 || v > 1.8e19) return false; c->bucket_bytes = (uint64_t)v; c->bucket_failed = false; return true;
-        case SPLAT_OPT_FAST_CLOSE_WIDTH: if (v != 1.0 && v != 2.0) return false; c->fast_width = (float)v; return true;
-        case SPLAT_OPT_PRIORITY_LIST_LEN: if (v < 1.0 || v > 1073741823.0) return false; c->prio_len = (int)v; return true;
-        case SPLAT_OPT_FRAME_OVERLAP: if (v != 1.0 && v != 2.0) return false; c->overlap = (int)v; return true;    // (lanes: splat_set_option / splat_create make them)
-        case SPLAT_OPT_NEAR_SELECT_KEYS: if (v != 0.0 && (v < 64.0 || v > 2048.0)) return false; c->near_cap = (unsigned int)v; return true;
-        case SPLAT_OPT_OVERFLOW_REDO: if (v != 0.0 && v != 1.0 && v != 2.0) return false; c->overflow_redo = (int)v; return true;
-        case SPLAT_OPT_START_HINTS: if (v != 0.0 && v != 1.0 && v != 2.0) return false; c->start_hints = (int)v; return true;
+        case SPLAT_OPT_FUSED_SORT_MAX: if (v < 0.0 || v > 2048.0) return false; SPLAT_DRY_; c->fused_sort_max = (unsigned int)v; return true;
+        case SPLAT_OPT_REGION_SPARE: if (v < 1.0) return false; SPLAT_DRY_; c->region_spare = (float)v; return true;
+        case SPLAT_OPT_EARLY_OUT_EPS: if (v < 0.0 || v > 1.0) return false; SPLAT_DRY_; c->early_eps = (float)v; return true;
+        case SPLAT_OPT_EARLY_OUT_MIN_LIST: if (v < 0.0 || v > 1e9) return false; SPLAT_DRY_; c->early_min = (int)v; return true;
+        case SPLAT_OPT_EARLY_OUT_SCAN_EIGHTHS: if (v < 1.0 || v > 8.0) return false; SPLAT_DRY_; c->early_scan8 = (int)v; return true;
+        case SPLAT_OPT_SORT_IN_COMPOSITOR: if (v < -1.0 || v > 1.0) return false; SPLAT_DRY_; c->sort_in_comp = v < 0.0 ? -1 : (v != 0.0 ? 1 : 0); return true;
+        case SPLAT_OPT_PAIR_WALK: if (v < -1.0 || v > 1.0) return false; SPLAT_DRY_; c->pair_mode = v < 0.0 ? -1 : (v != 0.0 ? 1 : 0); return true;
+        case SPLAT_OPT_TIMING_EVERY: if (v < 1.0 || v > 1e9) return false; SPLAT_DRY_; c->timing_every = (int)v; return true;
+        case SPLAT_OPT_BLOCK_CULLING: if (v != 0.0 && v != 1.0) return false; SPLAT_DRY_; c->cull_blocks = v != 0.0; return true;
+        case SPLAT_OPT_ONE_PASS_BINNING: if (v != 0.0 && v != 1.0) return false; SPLAT_DRY_; c->use_buckets = v != 0.0; return true;
+        case SPLAT_OPT_KEY_BUFFER_BYTES: if (v < 0.0 || v > 1.8e19) return false; SPLAT_DRY_; c->bucket_bytes = (uint64_t)v; c->bucket_failed = false; return true;
+        case SPLAT_OPT_FAST_CLOSE_WIDTH: if (v != 1.0 && v != 2.0) return false; SPLAT_DRY_; c->fast_width = (float)v; return true;
+        case SPLAT_OPT_PRIORITY_LIST_LEN: if (v < 1.0 || v > 1073741823.0) return false; SPLAT_DRY_; c->prio_len = (int)v; return true;
+        case SPLAT_OPT_FRAME_OVERLAP: if (v != 1.0 && v != 2.0) return false; SPLAT_DRY_; c->overlap = (int)v; return true;    // (lanes: splat_set_option / splat_create make them)
+        case SPLAT_OPT_NEAR_SELECT_KEYS: if (v != 0.0 && (v < 64.0 || v > 2048.0)) return false; SPLAT_DRY_; c->near_cap = (unsigned int)v; return true;
+        case SPLAT_OPT_OVERFLOW_REDO: if (v != 0.0 && v != 1.0 && v != 2.0) return false; SPLAT_DRY_; c->overflow_redo = (int)v; return true;
+        case SPLAT_OPT_START_HINTS: if (v != 0.0 && v != 1.0 && v != 2.0) return false; SPLAT_DRY_; c->start_hints = (int)v; return true;
+        case SPLAT_OPT_HOST_ZERO_COPY: if (v != 0.0 && v != 1.0) return false; SPLAT_DRY_; c->host_zero_copy = (int)v; return true;
+        case SPLAT_OPT_KEYS_PER_GAUSSIAN: if (v != 0.0 && (v < 4.0 || v > 256.0)) return false; SPLAT_DRY_; c->keys_per_gaussian = (unsigned int)v; return true;
         default: return false;
     }
+#undef SPLAT_DRY_
 }
 bool load_option(const splat_ctx* c, int opt, double* v) {
     switch (opt) {
@@ -1106,6 +1139,8 @@ bool load_option(const splat_ctx* c, int opt, double* v) {
         case SPLAT_OPT_NEAR_SELECT_KEYS: *v = c->near_cap; return true;
         case SPLAT_OPT_OVERFLOW_REDO: *v = c->overflow_redo; return true;
         case SPLAT_OPT_START_HINTS: *v = c->start_hints; return true;
+        case SPLAT_OPT_HOST_ZERO_COPY: *v = c->host_zero_copy; return true;
+        case SPLAT_OPT_KEYS_PER_GAUSSIAN: *v = c->keys_per_gaussian; return true;
         default: return false;
     }
 }
@@ -1127,6 +1162,9 @@ int ctx_quiesce(splat_ctx* c) { return finish_quiet(c); }
 }  // namespace splat
 
 extern "C" {
+
+uint32_t splat_abi_version(void) { return SPLAT_ABI_VERSION; }
+uint64_t splat_stats_size(void) { return sizeof(splat_stats); }
 
 void splat_default_config(splat_config* cfg) {
     if (!cfg) return;
@@ -1181,6 +1219,12 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         const int v = std::atoi(en);
         c->near_cap = v <= 0 ? 0u : (unsigned int)std::min(2048, std::max(64, v));
         c->env_pinned |= 1u << SPLAT_OPT_NEAR_SELECT_KEYS;
+    }
+    option_from_env(c, SPLAT_OPT_HOST_ZERO_COPY, "SPLAT_HOST_ZERO_COPY", 0, 1);
+    if (const char* kg = std::getenv("SPLAT_KEYS_PER_GAUSSIAN")) {
+        const int v = std::atoi(kg);
+        c->keys_per_gaussian = v <= 0 ? 0u : (unsigned int)std::min(256, std::max(4, v));
+        c->env_pinned |= 1u << SPLAT_OPT_KEYS_PER_GAUSSIAN;
     }
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
@@ -1242,7 +1286,7 @@ void splat_destroy(splat_ctx* c) {
     dfree(c->zero_layout); dfree(c->need_hint);
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
-        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_counts); dfree(s.redo_layout); dfree(s.redo_cursors);
+        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_layout); dfree(s.redo_cursors);
         dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
         if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);
@@ -1291,16 +1335,22 @@ int splat_set_frame_overlap(splat_ctx* c, int32_t n) {
 int splat_set_option(splat_ctx* c, int32_t option, double value) {
     if (!c) return SPLAT_ERR_INVALID;
     if (option < 1 || option > 31) return fail(c, SPLAT_ERR_INVALID, "unknown option");
-    c->still_frames = 0; c->last_cam_hash = 0;      // (the next frames scan for their walks' starts again: thresholds may have changed)
     double cur;
     if (!load_option(c, option, &cur)) return fail(c, SPLAT_ERR_INVALID, "unknown option");
+    // the value is checked before anything else happens: an invalid one is an error whether or not the option is pinned, and
+    // leaves the context as it was
+    if (option == SPLAT_OPT_FRAME_OVERLAP ? (value != 1.0 && value != 2.0) : !store_option(c, option, value, true))
+        return fail(c, SPLAT_ERR_INVALID, "option value out of range");
     if (c->env_pinned & (1u << option)) return SPLAT_OK;      // the operator's environment variable stays in force
+    c->still_frames = 0; c->last_cam_hash = 0;      // (the next frames scan for their walks' starts again: thresholds may have changed)
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc = finish_quiet(c);
     if (rc != SPLAT_OK) return rc;
-    if (option == SPLAT_OPT_FRAME_OVERLAP) {
-        if (value != 1.0 && value != 2.0) return fail(c, SPLAT_ERR_INVALID, "frame overlap is 1 or 2");
-        return splat_set_frame_overlap(c, (int32_t)value);
+    if (option == SPLAT_OPT_FRAME_OVERLAP) return splat_set_frame_overlap(c, (int32_t)value);
+    if (option == SPLAT_OPT_KEYS_PER_GAUSSIAN) {
+        // another key buffer size: the buffers are made again by the next frame (prepare_binning), the regions with them
+        for (Slot& sl : c->slots) { dfree(sl.keys); dfree(sl.keys2); sl.layout_valid = false; sl.flip = 0; }
+        c->cap = 0; c->have_keys2 = false; c->bucket_failed = false;
     }
     if (!store_option(c, option, value)) return fail(c, SPLAT_ERR_INVALID, "option value out of range");
     // (another selection size: what the tiles' walks needed under the old one is forgotten)
@@ -1463,7 +1513,10 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
 }  // extern "C"
 
 namespace {
-int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats, bool clear_first);
+// host_out != nullptr (splat_render_frame): the rendered rows also travel to host memory behind the compositor, on its stream,
+// BEFORE the host waits -- one wait per frame; a frame the device skipped is redone and copied again
+int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats, bool clear_first,
+                       uint32_t* host_out = nullptr);
 }
 
 extern "C" {
@@ -1478,7 +1531,8 @@ int splat_render_frame_device(splat_ctx* c, const splat_camera* cam, void* d_arg
 }  // extern "C"
 
 namespace {
-int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats, bool clear_first) {
+int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int32_t sync, splat_stats* stats, bool clear_first,
+                       uint32_t* host_out) {
     if (!c) return SPLAT_ERR_INVALID;
     if (!d_argb) return fail(c, SPLAT_ERR_INVALID, "d_argb is NULL");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -1494,6 +1548,7 @@ int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int3
             HIP_TRY(c, hipMemsetAsync((uint32_t*)d_argb + (size_t)c->fc.row_px0 * c->fc.W, 0,
                                       (size_t)(c->fc.row_px1 - c->fc.row_px0) * c->fc.W * 4, c->stream));
             if (sync || stats) HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (host_out) std::memset(host_out + (size_t)c->fc.row_px0 * c->fc.W, 0, (size_t)(c->fc.row_px1 - c->fc.row_px0) * c->fc.W * 4);
         }
         if (stats) { c->last = FrameStatus{}; c->last_ring = -1; fill_stats(c, stats); }
         return SPLAT_OK;
@@ -1512,6 +1567,10 @@ int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int3
                            sync || stats != nullptr);
         c->clear_first = false;
         if (rc != SPLAT_OK) return rc;
+        if (host_out && c->fc.row_px1 > c->fc.row_px0) {
+            const size_t first = (size_t)c->fc.row_px0 * (size_t)c->fc.W, count = (size_t)(c->fc.row_px1 - c->fc.row_px0) * (size_t)c->fc.W;
+            HIP_TRY(c, hipMemcpyAsync(host_out + first, (const uint32_t*)d_argb + first, count * 4u, hipMemcpyDeviceToHost, frame_stream(c)));
+        }
         if (!sync && !stats) return SPLAT_OK;
         bool skipped = false;
         rc = finish_frame(c, &skipped);
@@ -1559,6 +1618,40 @@ int splat_render(splat_ctx* c, const splat_camera* cam, uint32_t* argb, splat_st
     HIP_TRY(c, hipMemcpyAsync(argb, c->d_img, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPLAT_OK;
+}
+
+// The viewer loop's frame, host-visible and synchronous: `color.clear(0); render_to_buffer(&mut color)` (src/main.rs:73-74)
+// as ONE call that ships no zeros.  splat_render uploads the caller's image (8.3 MB of zeros at 1080p), blends, downloads;
+// here the clear is fused into the compositor and the pixels cross PCIe once, device -> host:
+//   * a page-locked `argb_out` (splat_host_alloc / splat_host_register) whose memory the device can address is written by the
+//     COMPOSITOR ITSELF (zero copy: the image crosses PCIe while the frame is still being composited; SPLAT_OPT_HOST_ZERO_COPY),
+//   * any other `argb_out` gets a copy behind the compositor on its stream (page-locked: DMA at the PCIe rate; pageable: the
+//     driver's staged copy).
+int splat_render_frame(splat_ctx* c, const splat_camera* cam, uint32_t* argb_out, splat_stats* stats) {
+    if (!c) return SPLAT_ERR_INVALID;
+    if (!argb_out || !cam) return fail(c, SPLAT_ERR_INVALID, "NULL argument");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    FrameConst fc; unsigned int nt;
+    int rc = build_frame_const(c, cam, &fc, &nt);
+    if (rc != SPLAT_OK) return rc;
+    const size_t bytes = (size_t)fc.W * fc.H * 4;
+    if (c->host_zero_copy) {
+        // is this image page-locked and mapped into the device's address space?  (pageable memory: the query fails)
+        hipPointerAttribute_t at;
+        std::memset(&at, 0, sizeof at);
+        void* dev = nullptr;
+        if (hipPointerGetAttributes(&at, argb_out) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dev, argb_out, 0) == hipSuccess && dev != nullptr)
+            return render_device_impl(c, cam, dev, 1, stats, true);      // the sync at the end of the frame makes the stores visible
+        (void)hipGetLastError();
+    }
+    if (bytes > c->img_cap) {
+        (void)finish_quiet(c);
+        dfree(c->d_img); c->img_cap = 0;
+        HIP_TRY(c, dmalloc(c, &c->d_img, bytes));
+        c->img_cap = bytes;
+    }
+    return render_device_impl(c, cam, c->d_img, 1, stats, true, argb_out);
 }
 
 int splat_render_stream(splat_ctx* c, const splat_camera* cam, uint32_t* argb_out) {

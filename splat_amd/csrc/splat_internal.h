@@ -65,7 +65,8 @@ struct FrameStatus {
     unsigned int n_near_fallback;    // ... and those among them that needed the whole list sorted after all
     unsigned long long n_iter_blend; //                                       phase B (exact blend)
     unsigned int n_ge8192, n_ge2048;    // tiles whose list has >= 8192 / >= 2048 keys: in `order` they are a prefix
-    unsigned int n_ge16384, pad_;       // likewise >= 16384 (the lists sorted as several runs and merged)
+    unsigned int n_ge16384;             // likewise >= 16384 (the lists sorted as several runs and merged)
+    unsigned int redone;                // 1: the frame outgrew its regions and was binned again on the device (overflow redo); written by every scan
     unsigned long long n_blocks_culled; // K1 blocks skipped by the bounds test (filled on the host from the block flags)
     unsigned long long layout_total;    // one-pass binning: key-buffer entries the regions built from this frame ask for (layout_kernel)
 };

@@ -1015,6 +1015,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         status->n_ge8192 = ge8192; status->n_ge2048 = ge2048; status->n_ge16384 = ge16384;
         if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid || ge16384 > grid_long)) status->overflow = 3u;
         status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
+        status->redone = 0u;                          // (the ring entry may have carried a redone one-pass frame before)
         if (host_status) *host_status = *status;      // (n_visible / n_singular: K1's atomics, complete before this kernel)
     }
     __syncthreads();   // lens[] written above by this workgroup are visible to it
@@ -1239,7 +1240,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
         status->n_visible = 0; status->n_singular = 0;
         status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
-        status->pad_ = redo_only ? 1u : 0u;    // (1: this frame outgrew its regions and was binned again on the device)
+        status->redone = redo_only ? 1u : 0u;  // (1: this frame outgrew its regions and was binned again on the device)
         status->n_blocks_culled = 0;
         // ... and delivers it to the host: everything an asynchronous frame reports is decided here (layout_total, the
         // last word, belongs to the workgroup that builds the layout: both copies are its to write)
@@ -2435,6 +2436,12 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // every pass, so the verdicts of one pass serve the next: the scan saves its ballot (save_k), the exact walk
     // takes it (reuse_k; reuse_shift = records of the batch below the walk's start) instead of running the two
     // coverage tests and the contribution bound again -- 60 of the 76 instructions of a staging.
+    // (One near -> far walk for the alpha pass AND the scan -- every covering record staged once with its rectangle, the
+    // scan's form of the conic and the conic itself; a step serves both until every pixel has met a covering record -- was
+    // built and measured in round 6: SLOWER, orbit 2530 vs 2640 frames/s on C3 (profiles/r06_fused_scan_ab.txt).  The alpha
+    // pass is cheap as it is: its staging runs no contribution bound and its loop leaves after the handful of records that
+    // cover the block, where the fused batches carry the third of the covering records that contribute nothing through
+    // every scan step.)
     auto stage = [&](const Rec& r, unsigned int cnt, unsigned int base, bool only_contributing, bool scan_layout = false,
                      bool pair_layout = false, int reuse_k = -1, unsigned int reuse_shift = 0u, int save_k = -1) -> unsigned int {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier LDS reads of this wave are done
@@ -2713,8 +2720,12 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // statistics frames only (iters != nullptr): this wave's (scan, blend) iteration counts as one plain store
     // (atomics on two frame-wide counters cost ~0.2 ms per frame)
     // (keep_keys bit 1, SPLAT_DBG_STARTS: the list's length and how many of its nearest keys this wave's walk needed instead)
-    if (iters != nullptr && lane == 0)
-        iters[item * 4u + wave] = (keep_keys & 2u) ? make_uint2(end - beg, end - max(start, beg)) : make_uint2(itA, itB);
+    // (the repair launch ADDS: its wave walked this tile once already, with the selection, and left its counts here)
+    if (iters != nullptr && lane == 0) {
+        uint2 v = (keep_keys & 2u) ? make_uint2(end - beg, end - max(start, beg)) : make_uint2(itA, itB);
+        if ((keep_keys & 4u) && !(keep_keys & 2u)) { const uint2 o = iters[item * 4u + wave]; v.x += o.x; v.y += o.y; }
+        iters[item * 4u + wave] = v;
+    }
     if constexpr (LONGM != 0) {
         // what this wave's walk needed of the list's near end, for the next frame's selection (see the prologue)
         if (need_hint != nullptr && end - beg > 2048u && lane == 0u) need_hint[tile * 4u + wave] = need_far ? 0xffffffffu : end - max(start, lb);
@@ -2903,7 +2914,8 @@ __global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, co
                                                                unsigned int clear_first, unsigned long long* __restrict__ keys2,
                                                                const unsigned int* __restrict__ repair_mask,
                                                                const unsigned int* __restrict__ repair_list,
-                                                               unsigned int* __restrict__ need_hint, unsigned int* __restrict__ start_hint) {
+                                                               unsigned int* __restrict__ need_hint, unsigned int* __restrict__ start_hint,
+                                                               uint2* __restrict__ iters, unsigned int flags) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
     if (status->overflow) return;
@@ -2919,7 +2931,7 @@ __global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, co
     for (unsigned int i = blockIdx.x; i < count; i += gridDim.x) {
         const unsigned int item = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_list[i]);
         const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_mask[order[item]]);
-        composite_tile<PAIR, LIBM, 1>(smem, exptab, item, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, nullptr, 0u, orig, clear_first, keys2,
+        composite_tile<PAIR, LIBM, 1>(smem, exptab, item, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, (flags & 2u) | 4u, orig, clear_first, keys2,
                                       nullptr, nullptr, nullptr, mask, need_hint, start_hint);
         __syncthreads();          // the workspace is the next tile's: every wave has finished its walk
     }
@@ -3064,7 +3076,7 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
         // the repair launch: tiles the selection did not serve (normally none: its workgroups read one word and leave)
         auto fix = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(std::min(n_tiles, g_knobs->dbg_repair_grid ? g_knobs->dbg_repair_grid : 64u)), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                               sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list, need_hint, start_hint);
+                               sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list, need_hint, start_hint, iters, flags);
         };
         if (libm_exp) fix(composite_repair_kernel<false, true>);
         else if (pair_walk) fix(composite_repair_kernel<true, false>);

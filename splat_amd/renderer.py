@@ -112,6 +112,17 @@ class Renderer:
                                          C.byref(st) if want_stats else None))
         return st
 
+    def render_frame(self, cam_c, argb_out, want_stats=False):
+        """splat_render_frame: the viewer loop's `clear; render_to_buffer` (src/main.rs:73-74) as one synchronous call; argb_out
+        (uint32 [h,w], host) is written, never read.  A page-locked image (host_image / host_register) is written by the
+        compositor itself."""
+        assert argb_out.dtype == np.uint32 and argb_out.flags.c_contiguous
+        assert argb_out.shape == (int(cam_c.h), int(cam_c.w))
+        st = _lib.Stats() if want_stats else None
+        self._check(self._L.splat_render_frame(self._h, C.byref(cam_c), argb_out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               C.byref(st) if want_stats else None))
+        return st
+
     def render_device(self, cam_c, d_ptr, sync=False, want_stats=False):
         """d_ptr: device address of a w*h u32 image (e.g. torch_tensor.data_ptr())."""
         st = _lib.Stats() if want_stats else None

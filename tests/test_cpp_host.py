@@ -116,6 +116,34 @@ def test_cpp_pipelines_render_to_buffer(H, tmp_path, pipeline, lowpass):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_cpp_render_frame_to_buffer_is_clear_plus_render_to_buffer(H, pipeline):
+    """GaussianSplatPipeline01/02::render_frame_to_buffer (the pair at src/main.rs:73-74 as one call, selector 11 / 12 of the
+    C shim) writes the image render_to_buffer blends onto zeros, whatever the buffer held"""
+    pos = np.asarray((0, 0, 5), np.float32)
+    err = C.create_string_buffer(256)
+    want = np.zeros((150, 200), np.uint32)
+    assert H.splat_host_render(pipeline, None, 150.0, 200.0, _fp(pos), want.ctypes.data_as(C.POINTER(C.c_uint32)), err, 256) == 0, err.value
+    got = np.full((150, 200), 0xdeadbeef, np.uint32)
+    assert H.splat_host_render(10 + pipeline, None, 150.0, 200.0, _fp(pos), got.ctypes.data_as(C.POINTER(C.c_uint32)), err, 256) == 0, err.value
+    assert want.any() and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_cli_one_call_frames_give_the_same_last_frame(tmp_path):
+    """splat_cli --frame: the loop with render_frame_to_buffer into a pinned `color` ends on the frame the literal loop ends on"""
+    outs = []
+    for extra in ([], ["--frame"]):
+        out = str(tmp_path / ("g%d.ppm" % len(outs)))
+        r = subprocess.run([os.path.join(ROOT, "splat_amd", "splat_cli"), "--frames", "5", "--size", "160", "120", "--out", out] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.count("Rendering took") == 5
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
 def test_cli_main_loop(tmp_path):
     out = str(tmp_path / "f.ppm")
     r = subprocess.run([os.path.join(ROOT, "splat_amd", "splat_cli"), "--frames", "3", "--size", "160", "120", "--out", out],
@@ -160,6 +188,7 @@ def test_plain_c_client(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "splat_amd", "render_c"), out], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "4 visible" in r.stdout and os.path.getsize(out) == len("P6\n320 240\n255\n") + 320 * 240 * 3
+    assert "splat_render_frame: same frame" in r.stdout       # the one-call viewer-loop frame, pageable and page-locked image
 
 
 GOLD_KAT = None

@@ -836,6 +836,46 @@ def test_options_set_from_code_change_the_schedule_not_the_pixels():
             os.environ["SPLAT_FUSED_SORT"] = saved
 
 
+def test_set_option_checks_the_value_first_and_leaves_pinned_options_alone(monkeypatch):
+    """an invalid value is SPLAT_ERR_INVALID whether or not the operator pinned the option from the environment,
+    and is refused before the context's state is touched; a valid one on a pinned option is accepted and ignored.  Pipeline
+    depth 1 leaves no compositor lanes behind; the depth raised again does not bring an overlap of 2 back."""
+    from splat_amd import _lib as L
+    from splat_amd.renderer import SplatError
+    monkeypatch.setenv("SPLAT_START_HINTS", "1")
+    r = splat_amd.Renderer()
+    try:
+        assert r.get_option(L.OPT_START_HINTS) == 1
+        r.set_option(L.OPT_START_HINTS, 0)                      # pinned: accepted, the operator's value stays
+        assert r.get_option(L.OPT_START_HINTS) == 1
+        for opt, bad in ((L.OPT_START_HINTS, 7), (L.OPT_EARLY_OUT_EPS, 2.0), (L.OPT_FRAME_OVERLAP, 3), (L.OPT_HOST_ZERO_COPY, 2),
+                         (L.OPT_KEYS_PER_GAUSSIAN, 2), (L.OPT_PIPELINE_DEPTH, 0), (99, 1)):
+            with pytest.raises(SplatError) as e:
+                r.set_option(opt, bad)
+            assert e.value.code == L.ERR_INVALID, (opt, bad)
+        g = gpu_scene(r, 20000, 3)
+        r.upload(g)
+        cam_c = make_camera(160, 240).to_c(0.01)
+        want = np.zeros((160, 240), np.uint32)
+        r.render(cam_c, want)
+        r.set_frame_overlap(2)
+        r.set_option(L.OPT_PIPELINE_DEPTH, 1)
+        assert r.get_option(L.OPT_FRAME_OVERLAP) == 1
+        a = np.zeros((160, 240), np.uint32)
+        r.render(cam_c, a)
+        r.set_option(L.OPT_PIPELINE_DEPTH, 6)
+        assert r.get_option(L.OPT_FRAME_OVERLAP) == 1           # (set it again: documented)
+        b = np.zeros((160, 240), np.uint32)
+        r.render(cam_c, b)
+        r.set_option(L.OPT_KEYS_PER_GAUSSIAN, 16)
+        c = np.zeros((160, 240), np.uint32)
+        r.render(cam_c, c)
+        assert r.binning_mode() == max(1 << 22, 16 * 20000)
+        assert np.array_equal(a, want) and np.array_equal(b, want) and np.array_equal(c, want)
+    finally:
+        r.close()
+
+
 def test_paired_walk_gives_the_same_bytes():
     """The compositor has two flavours of the exact walk -- one record per step, and two records per step with packed
     f32 math (fewer issue slots for latency-bound waves; chosen per frame by the host) -- which must be the same
@@ -941,6 +981,70 @@ def test_frame_with_fused_clear_equals_clear_then_render(R):
     R.render_frame_device(make_camera(h, w).to_c(0.01), d, sync=True)
     assert not R.device_download(d, h, w).any()
     R.device_free(d)
+
+
+def test_render_frame_host_call_is_clear_plus_render_to_buffer(R):
+    """splat_render_frame -- `color.clear(0); render_to_buffer(&mut color)` (src/main.rs:73-74) as one synchronous call whose
+    image is written, never read -- gives the bytes of zeros + splat_render (the literal pair) for a pageable image (a copy
+    behind the frame), a page-locked one from splat_host_alloc and a caller's array after splat_host_register (the
+    compositor stores straight into host memory), with the zero copy switched off, on a 36-pose orbit against the oracle,
+    for a slab (rows outside it untouched) and for an empty scene."""
+    from splat_amd import _lib as L
+    g = gpu_scene(R, 30000, 45)
+    R.upload(g)
+    rng = np.random.default_rng(9)
+    h, w = 200, 312
+    garbage = rng.integers(0, 2**32, (h, w), dtype=np.uint64).astype(np.uint32)
+    cam = make_camera(h, w)
+    cam_c = cam.to_c(0.01)
+    want = np.zeros((h, w), np.uint32)
+    st0 = R.render(cam_c, want)
+    assert want.any()
+    pinned = R.host_image(h, w)
+    reg = garbage.copy()
+    splat_amd.Renderer.host_register(reg)
+    try:
+        for zero_copy in (1, 0):
+            R.set_option(L.OPT_HOST_ZERO_COPY, zero_copy)
+            assert R.get_option(L.OPT_HOST_ZERO_COPY) == zero_copy
+            for name, buf in (("pageable", garbage.copy()), ("host_alloc", pinned), ("registered", reg)):
+                buf[:] = garbage
+                st = R.render_frame(cam_c, buf, want_stats=True)
+                assert np.array_equal(buf, want), (zero_copy, name, int((buf != want).sum()))
+                assert (st.n_pairs, st.n_visible) == (st0.n_pairs, st0.n_visible)
+                buf[:] = garbage
+                assert R.render_frame(cam_c, buf) is None          # the loop's form: no statistics
+                assert np.array_equal(buf, want), (zero_copy, name)
+        R.set_option(L.OPT_HOST_ZERO_COPY, 1)
+        # the reference's loop (src/main.rs:43-78): a 10-degree yaw step, then the frame; every fourth pose against the oracle
+        orbit = splat_amd.Camera(h, w, (0.0, 0.0, 5.0))
+        for k in range(36):
+            orbit.update_camera_pose()
+            for buf in (pinned, reg):
+                buf[:] = garbage
+                R.render_frame(orbit.to_c(0.01), buf)
+            assert np.array_equal(pinned, reg), k
+            if k % 4 == 0:
+                ref, _ = O.render(scene_dict(g), oracle_camera(orbit, 0.01), O.default_conventions(), np.zeros((h, w), np.uint32), nthreads=8)
+                assert image_diff(pinned, ref)[0] <= TOL_LSB, (k, image_diff(pinned, ref))
+            orbit.update_yaw_angle(10.0 * np.pi / 180.0)
+        # a slab: only its rows are written
+        R.set_slab(3, 9)
+        for buf in (garbage.copy(), pinned):
+            buf[:] = garbage
+            R.render_frame(cam_c, buf)
+            assert np.array_equal(buf[:48], garbage[:48]) and np.array_equal(buf[144:], garbage[144:])
+            assert np.array_equal(buf[48:144], want[48:144])
+        R.set_slab(0, -1)
+        empty = splat_amd.GaussianList(np.zeros((0, 4)), np.zeros((0, 3)), np.zeros(0), np.zeros((0, 4)), np.zeros((0, 48)))
+        R.upload(empty)
+        for buf in (garbage.copy(), pinned):
+            buf[:] = garbage
+            R.render_frame(cam_c, buf)
+            assert not buf.any()
+    finally:
+        splat_amd.Renderer.host_unregister(reg)
+        R.set_slab(0, -1)
 
 
 def _channels(a):
