@@ -59,10 +59,10 @@ struct Slot {                  // everything one frame writes before the image
     unsigned int* redo_cursors = nullptr;
     uint64_t layout_cam[2] = {0, 0};        // per copy of the layout: a hash of the camera whose lists sized it
     unsigned int* near_m = nullptr;         // near selection: per tile, how many of its list's nearest keys launch_select put in order
-    unsigned int* repair_mask = nullptr;    // ... the waves whose walk needed more than that
-    unsigned int* repair_list = nullptr;    // ... and the tiles (slots of `order`) the repair launch takes again
     unsigned long long* keys = nullptr;
-    unsigned long long* keys2 = nullptr;   // scatter target of the global-memory radix passes (lists > 16384)
+    unsigned long long* keys2 = nullptr;   // the second key buffer: sorted near selections, scatter space of the long lists' sorts and merges
+    unsigned int* off2 = nullptr;          // one-pass binning: per tile, where its room in keys2 starts (handed out by the frame's scan to the
+                                           // lists of more than 2048 keys; two-pass binning mirrors the first buffer instead)
     unsigned int* blockinfo = nullptr;     // per K1 block: the info word this slot's last K1 wrote (see launch_preprocess);
                                            // per slot, because the K1s of consecutive frames run concurrently
     FrameStatus* d_status = nullptr;
@@ -92,7 +92,9 @@ struct splat_ctx {
     Slot slots[N_SLOTS];
     unsigned int m_alloc = 0;
     uint64_t cap = 0;                      // entries in each used slot's keys buffer
-    bool have_keys2 = false;               // keys2 (two-pass path only) is allocated at the same size
+    uint64_t cap2 = 0;                     // entries in each used slot's second key buffer (0: none).  Two-pass binning: a mirror of the first
+                                           // (cap2 == cap); one-pass: room for the lists of more than 2048 keys only (default_keys2_capacity)
+    uint64_t keys2_want = 0;               // a harvested frame's long lists outgrew the second key buffer: grow to this
     // one-pass binning (per-tile buckets): on unless SPLAT_BUCKETS=0, the caller fixed pair_capacity,
     // the buckets would not fit bucket_bytes, or a tile outgrew the largest LDS-sortable bucket
     // one-pass binning (per-tile regions of the key buffer, sized from earlier frames' lists): on unless SPLAT_BUCKETS=0, the
@@ -373,6 +375,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow == 2 || st.redone == 1u) c->redo_armed = 256;  // ... or did and was binned again on the device: keep the redo launches on
     if (st.layout_total > c->cap) c->layout_want = std::max<uint64_t>(c->layout_want, st.layout_total);   // the regions were cut off
     if (st.overflow == 3) c->sort_grid_miss = true;
+    if (st.overflow == 4) c->keys2_want = std::max<uint64_t>(c->keys2_want, st.n_long_keys);
     if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
     if (st.overflow == 0) { c->hint_pairs = st.n_pairs; c->hint_maxlen = st.max_tile_len; }
     s.used = false;
@@ -449,13 +452,12 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
     HIP_TRY(c, fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)(m + 1)));
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
-        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_layout); dfree(s.redo_cursors);
+        dfree(s.near_m); dfree(s.redo_layout); dfree(s.redo_cursors); dfree(s.off2);
         s.layout_valid = false; s.flip = 0;
+        HIP_TRY(c, dmalloc(c, &s.off2, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.near_m, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.redo_layout, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.redo_cursors, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, dmalloc(c, &s.repair_mask, sizeof(unsigned int) * (size_t)(m + 1)));
-        HIP_TRY(c, dmalloc(c, &s.repair_list, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.counts_b, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.lay_a, sizeof(unsigned int) * (size_t)(m + 1)));
         HIP_TRY(c, dmalloc(c, &s.lay_b, sizeof(unsigned int) * (size_t)(m + 1)));
@@ -472,23 +474,30 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
 
 int slots_in_use(const splat_ctx* c);
 
-// keys (and, for the two-pass path whose longest lists sort through global memory, keys2) of at
-// least `want` entries in every slot that frames rotate through
-int ensure_keys(splat_ctx* c, uint64_t want, bool need_keys2) {
-    if (want <= c->cap && (!need_keys2 || c->have_keys2)) return SPLAT_OK;
-    if (want >= 0xFFFFFFF0ull) return fail(c, SPLAT_ERR_CAPACITY, "pair count exceeds 2^32");
+// keys of at least `want` entries, and a second key buffer of at least `want2`, in every slot that frames rotate through
+// (a buffer that is large enough is kept)
+int ensure_keys(splat_ctx* c, uint64_t want, uint64_t want2) {
+    if (want <= c->cap && want2 <= c->cap2) return SPLAT_OK;
+    if (want >= 0xFFFFFFF0ull || want2 >= 0xFFFFFFF0ull) return fail(c, SPLAT_ERR_CAPACITY, "pair count exceeds 2^32");
     int rc = sync_all(c);
     if (rc != SPLAT_OK) return rc;
-    if (need_keys2 == c->have_keys2) want = std::max(want, c->cap);
-    c->cap = 0; c->have_keys2 = false;
-    for (Slot& s : c->slots) { dfree(s.keys); dfree(s.keys2); }
+    want = std::max(want, c->cap); want2 = std::max(want2, c->cap2);
+    const bool grow1 = want > c->cap, grow2 = want2 > c->cap2;
+    if (grow1) { c->cap = 0; for (Slot& s : c->slots) dfree(s.keys); }
+    if (grow2) { c->cap2 = 0; for (Slot& s : c->slots) dfree(s.keys2); }
     for (int k = 0; k < slots_in_use(c); ++k) {
         Slot& s = c->slots[k];
-        hipError_t e = dmalloc(c, &s.keys, sizeof(unsigned long long) * want);
-        if (e == hipSuccess && need_keys2) e = dmalloc(c, &s.keys2, sizeof(unsigned long long) * want);
-        if (e != hipSuccess) return fail(c, SPLAT_ERR_CAPACITY, std::string("cannot allocate pair buffer: ") + hipGetErrorString(e));
+        hipError_t e = hipSuccess;
+        if (grow1) e = dmalloc(c, &s.keys, sizeof(unsigned long long) * want);
+        if (e == hipSuccess && grow2) e = dmalloc(c, &s.keys2, sizeof(unsigned long long) * want2);
+        if (e != hipSuccess) {
+            // (all or nothing: a half-made set would leave slots without buffers behind capacities that say otherwise)
+            for (Slot& t : c->slots) { dfree(t.keys); dfree(t.keys2); }
+            c->cap = 0; c->cap2 = 0;
+            return fail(c, SPLAT_ERR_CAPACITY, std::string("cannot allocate pair buffer: ") + hipGetErrorString(e));
+        }
     }
-    c->cap = want; c->have_keys2 = need_keys2;
+    c->cap = want; c->cap2 = want2;
     return SPLAT_OK;
 }
 
@@ -504,13 +513,17 @@ uint64_t default_pair_capacity(const splat_ctx* c) {
 // memory on C3, 14.8 -> 15.4 GB on C5 (32 N), of 288.
 int slots_in_use(const splat_ctx* c);
 uint64_t region_capacity_for(const splat_ctx* c, uint64_t mult) { return std::max<uint64_t>(1ull << 22, mult * c->n); }
+// The second key buffer of a one-pass frame slot: room for the lists of more than 2048 keys (the scan hands it out).  16
+// entries per Gaussian hold every frame measured (C3's bench pose asks for 5.3 M of 24 M, the surface scene from inside
+// for 15 M); a frame that asks for more is skipped once and the buffer grown (finish_frame).
+uint64_t default_keys2_capacity(const splat_ctx* c) { return std::max<uint64_t>(1ull << 22, 16 * c->n); }
 uint64_t default_region_multiplier(const splat_ctx* c) {
     if (c->keys_per_gaussian) return c->keys_per_gaussian;
-    const uint64_t per_entry = 8ull * 2ull * (uint64_t)slots_in_use(c);        // two key buffers in every frame slot
+    const uint64_t per_entry = 8ull * (uint64_t)slots_in_use(c);               // a key buffer in every frame slot
     const uint64_t GiB = 1ull << 30;
     uint64_t mult = 16;
-    if (64 * c->n * per_entry <= 8 * GiB) mult = 64;
-    else if (32 * c->n * per_entry <= 64 * GiB) mult = 32;
+    if (64 * c->n * per_entry <= 4 * GiB) mult = 64;
+    else if (32 * c->n * per_entry <= 32 * GiB) mult = 32;
     // ... and never more than a quarter of what the device has free right now: a GPU shared with other contexts (eight slab
     // ranks on one device, a host application's own allocations) takes the smaller buffer at once instead of failing the large one
     size_t free_b = 0, total_b = 0;
@@ -526,11 +539,11 @@ uint64_t default_region_multiplier(const splat_ctx* c) {
 bool near_selection(const splat_ctx* c) {
     return c->near_cap != 0u && c->fused_sort_max >= 2048u && c->early_eps > 0.0f && c->sort_in_comp != 0;
 }
-// ... and is only worth its repair launch on frames that have such lists at all (the previous harvested frame's longest
+// ... and is only worth its launch on frames that have such lists at all (the previous harvested frame's longest
 // list; nothing known yet: assume so).  A frame without the selection falls back on the sort launches / the compositor's
 // full sort as before.
 // (... and a list of 8192 keys or a few hundred above 2048: on C2 -- 300 k Gaussians at 720p, a few dozen lists barely above 2048 keys, a 0.12-ms frame -- the
-// selection's launch and the repair launch on the compositor's stream cost 9 us more than the sort launches they replace)
+// selection's launch cost more than the sort launches it replaces)
 bool near_selection_for_frame(const splat_ctx* c) {
     if (!near_selection(c)) return false;
     if (!c->sort_hint || c->hint_maxlen == 0u) return true;
@@ -710,8 +723,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     }
     const bool comp_sorts_frame = compositor_sorts_long_lists(c, m) && s.keys2 != nullptr;
     const unsigned int near_cap = (comp_sorts_frame && near_selection_for_frame(c)) ? c->near_cap : 0u;
+    unsigned int* const off2 = c->fc.bucket_cap ? s.off2 : nullptr;        // (two-pass binning: the second buffer mirrors the first)
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
-                next_layout, next_counts, c->region_spare, near_cap ? s.repair_mask : nullptr);
+                next_layout, next_counts, c->region_spare, false, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull));
     if (c->fc.bucket_cap && moved && c->overflow_redo == 1 && c->redo_armed < 128) {
         // A frame still in flight that outgrew a region (or was binned again): its scan has written that to the host
         // already -- a peek, no wait; the harvest proper comes when the ring wraps, 32 frames on -- and the frames of this
@@ -742,7 +756,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         launch_layout(bs, m, cursors, layout, s.redo_layout, s.redo_cursors, c->fc.bucket_cap, nullptr, nullptr, c->region_spare, d_st);
         launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, s.redo_layout);
         launch_scan(bs, m, s.redo_cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], s.redo_layout,
-                    nullptr, nullptr, c->region_spare, near_cap ? s.repair_mask : nullptr, true);
+                    nullptr, nullptr, c->region_spare, true, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull));
     }
     HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
@@ -764,10 +778,10 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         if (awaited) grid = c->sort_hint ? std::max<unsigned int>(grid, c->hint_ge2048 + c->hint_ge2048 / 8u + 16u) : m;
         launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m,
                       (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows, c->one_pass_select ? c->need_hint + 4u * (size_t)c->m_alloc : nullptr,
-                      std::min(grid, m), c->fc.start_hints == 1);
+                      std::min(grid, m), c->fc.start_hints == 1, off2);
     }
     else if (!comp_sorts)
-        launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max);
+        launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max, off2);
     HIP_TRY(c, mark(4, ss));
     // Which lane composites?  Frames to one image stay on one lane (stream order is their write-after-write / in-out
     // order, as always); a frame to another image takes the other lane when it may.  A frame that must not overlap
@@ -829,7 +843,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
                                              : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
     launch_composite(cs, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
                      pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr, near_cap ? s.near_m : nullptr,
-                     s.repair_mask, s.repair_list, c->need_hint, c->need_hint ? c->need_hint + 5u * (size_t)c->m_alloc : nullptr);
+                     c->need_hint, c->need_hint ? c->need_hint + 5u * (size_t)c->m_alloc : nullptr, off2);
     c->last_near = near_cap != 0u;
     HIP_TRY(c, mark(6, cs));
     // the scan has already delivered this frame's status to h_status[r]; a statistics frame refreshes it with the late
@@ -877,10 +891,10 @@ int finish_frame(splat_ctx* c, bool* last_skipped = nullptr) {
         for (Slot& sl : c->slots) sl.layout_valid = false;
         if (c->layout_want > c->cap) {
             const uint64_t asked = c->layout_want + c->layout_want / 4 + 1024, want = std::min<uint64_t>(asked, KEY_ENTRIES_MAX);
-            const uint64_t bytes = want * 8ull * (c->have_keys2 ? 2u : 1u) * (uint64_t)slots_in_use(c);
+            const uint64_t bytes = (want + c->cap2) * 8ull * (uint64_t)slots_in_use(c);
             if (bytes > c->bucket_bytes || asked > KEY_ENTRIES_MAX) c->bucket_failed = true;    // no room: exactly sized lists instead
             else {
-                rc = ensure_keys(c, want, c->have_keys2);
+                rc = ensure_keys(c, want, c->cap2);
                 if (rc == SPLAT_ERR_CAPACITY) { c->bucket_failed = true; rc = SPLAT_OK; }
                 else if (rc != SPLAT_OK) return rc;
             }
@@ -891,9 +905,18 @@ int finish_frame(splat_ctx* c, bool* last_skipped = nullptr) {
     if (c->overflow_want) {
         uint64_t want = (uint64_t)((double)c->overflow_want * 1.25) + 1024;
         c->overflow_want = 0;
-        rc = ensure_keys(c, want, true);
+        rc = ensure_keys(c, want, want);
         if (rc != SPLAT_OK) return rc;
         msg = "pair buffer overflowed; capacity grown, frame must be re-rendered";
+    }
+    if (c->keys2_want) {
+        // the lists of more than 2048 keys asked for more room in the second key buffer than it has (a camera deep inside a
+        // dense scene): a quarter more than they asked for
+        const uint64_t want2 = std::min<uint64_t>(c->keys2_want + c->keys2_want / 4 + 1024, KEY_ENTRIES_MAX);
+        c->keys2_want = 0;
+        rc = ensure_keys(c, c->cap, want2);
+        if (rc != SPLAT_OK) return rc;
+        msg = "the long tile lists outgrew the second key buffer; buffer grown, frame must be re-rendered";
     }
     return msg ? fail(c, SPLAT_ERR_CAPACITY, msg) : SPLAT_OK;
 }
@@ -942,14 +965,14 @@ int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
         // key buffer: what the two-pass path would start with, unless a layout has asked for more (finish_frame grows it)
         // (always with the second buffer: a region may hold a list of any length, and a list beyond 16384 keys sorts as
         // runs merged through it -- fixed-stride buckets could cap the lists at what the buffers at hand could sort)
-        const bool need2 = true;
         // The buffer that does not fit (the byte budget, or the allocation itself fails: a device with less free memory than
         // the default assumes) is tried again at half the size, down to the 16 entries per Gaussian the two-pass path would
         // start with, before one-pass binning is given up for the scene.
         int rc = SPLAT_ERR_CAPACITY;
         for (uint64_t mult = default_region_multiplier(c); ; mult >>= 1) {
             const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, region_capacity_for(c, mult)), KEY_ENTRIES_MAX);
-            rc = (want * 8ull * (need2 ? 2u : 1u) * (uint64_t)slots_in_use(c) > c->bucket_bytes) ? SPLAT_ERR_CAPACITY : ensure_keys(c, want, need2);
+            const uint64_t want2 = std::min<uint64_t>(std::max<uint64_t>(c->cap2, default_keys2_capacity(c)), KEY_ENTRIES_MAX);
+            rc = ((want + want2) * 8ull * (uint64_t)slots_in_use(c) > c->bucket_bytes) ? SPLAT_ERR_CAPACITY : ensure_keys(c, want, want2);
             if (rc != SPLAT_ERR_CAPACITY || mult <= 16 || want <= c->cap) break;
             (void)hipGetLastError();
         }
@@ -958,7 +981,10 @@ int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
         c->bucket_failed = true;                          // no room: exactly sized lists instead
         return prepare_binning(c, m, fc);
     }
-    return ensure_keys(c, default_pair_capacity(c), true);
+    // two-pass binning: exactly sized lists, and a second buffer that mirrors the first (the merges and global-memory radix
+    // passes of its longest lists address it through the lists' own offsets)
+    const uint64_t want = std::max<uint64_t>(default_pair_capacity(c), c->cap);
+    return ensure_keys(c, want, want);
 }
 
 void fill_stats(splat_ctx* c, splat_stats* st) {
@@ -1080,7 +1106,7 @@ bool store_option(splat_ctx* c, int opt, double v, bool dry = false) {
             if (p != c->pipeline) {
                 // another number of frame slots: the key buffers exist per slot in use and are made again by the next frame
                 for (Slot& sl : c->slots) { dfree(sl.keys); dfree(sl.keys2); sl.layout_valid = false; sl.flip = 0; sl.used = false; sl.free_ring = -1; }
-                c->cap = 0; c->have_keys2 = false; c->frame_idx = 0;
+                c->cap = 0; c->cap2 = 0; c->frame_idx = 0;
                 c->pipeline = p;
                 // One stream for everything has no compositor lanes: the lane state goes as splat_set_frame_overlap(1) leaves it
                 // (unless the operator pinned the overlap from the environment: then only the second lane's stream is dropped, and
@@ -1232,7 +1258,6 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* k8 = std::getenv("SPLAT_DBG_SELECT_STRIDE")) c->knobs.dbg_select_stride = (unsigned int)std::max(0, std::atoi(k8));
     if (const char* k10 = std::getenv("SPLAT_START_HINTS")) { c->start_hints = std::min(2, std::max(0, std::atoi(k10))); c->env_pinned |= 1u << SPLAT_OPT_START_HINTS; }
     if (const char* k7 = std::getenv("SPLAT_DBG_ONE_PASS_SELECT")) c->one_pass_select = std::atoi(k7) != 0;
-    if (const char* k6 = std::getenv("SPLAT_DBG_REPAIR_GRID")) c->knobs.dbg_repair_grid = (unsigned int)std::max(0, std::atoi(k6));
     if (const char* k5 = std::getenv("SPLAT_DBG_STARTS")) c->knobs.dbg_starts = std::atoi(k5) != 0 ? 1u : 0u;
     if (const char* k4 = std::getenv("SPLAT_COMP_LDS_PAD")) c->knobs.comp_lds_pad = (unsigned int)std::max(0, std::atoi(k4));
     auto bail = [&](const char* what, hipError_t err) {
@@ -1286,7 +1311,7 @@ void splat_destroy(splat_ctx* c) {
     dfree(c->zero_layout); dfree(c->need_hint);
     for (Slot& s : c->slots) {
         dfree(s.counts); dfree(s.offsets); dfree(s.cursor); dfree(s.order); dfree(s.lens); dfree(s.counts_b); dfree(s.lay_a); dfree(s.lay_b);
-        dfree(s.repair_mask); dfree(s.repair_list); dfree(s.near_m); dfree(s.redo_layout); dfree(s.redo_cursors);
+        dfree(s.near_m); dfree(s.redo_layout); dfree(s.redo_cursors); dfree(s.off2);
         dfree(s.keys); dfree(s.keys2); dfree(s.d_status);
         if (s.ev_ready) (void)hipEventDestroy(s.ev_ready);
         if (s.ev_binned) (void)hipEventDestroy(s.ev_binned);
@@ -1350,7 +1375,7 @@ int splat_set_option(splat_ctx* c, int32_t option, double value) {
     if (option == SPLAT_OPT_KEYS_PER_GAUSSIAN) {
         // another key buffer size: the buffers are made again by the next frame (prepare_binning), the regions with them
         for (Slot& sl : c->slots) { dfree(sl.keys); dfree(sl.keys2); sl.layout_valid = false; sl.flip = 0; }
-        c->cap = 0; c->have_keys2 = false; c->bucket_failed = false;
+        c->cap = 0; c->cap2 = 0; c->bucket_failed = false;
     }
     if (!store_option(c, option, value)) return fail(c, SPLAT_ERR_INVALID, "option value out of range");
     // (another selection size: what the tiles' walks needed under the old one is forgotten)
@@ -1861,15 +1886,13 @@ int splat_debug_k1_hwid(splat_ctx* c, unsigned long long* out, unsigned long lon
 }
 #endif
 
-// (debug, not part of the ABI: tools/near_debug.py)  The near selection's per-tile state of the most recent frame: lens[m],
-// near_m[m], repair_mask[m], need_hint[4 m].
-int splat_debug_near_state(splat_ctx* c, unsigned int* lens, unsigned int* near_m, unsigned int* repair_mask, unsigned int* need_hint, unsigned int m) {
+// (debug, not part of the ABI)  The near selection's per-tile state of the most recent frame: lens[m], near_m[m], need_hint[4 m].
+int splat_debug_near_state(splat_ctx* c, unsigned int* lens, unsigned int* near_m, unsigned int* need_hint, unsigned int m) {
     if (!c || c->last_slot < 0 || m != c->n_tiles) return SPLAT_ERR_INVALID;
     (void)sync_all(c);
     const Slot& s = c->slots[c->last_slot];
     bool ok = hipMemcpy(lens, s.lens, sizeof(unsigned int) * m, hipMemcpyDeviceToHost) == hipSuccess;
     ok = ok && hipMemcpy(near_m, s.near_m, sizeof(unsigned int) * m, hipMemcpyDeviceToHost) == hipSuccess;
-    ok = ok && hipMemcpy(repair_mask, s.repair_mask, sizeof(unsigned int) * m, hipMemcpyDeviceToHost) == hipSuccess;
     ok = ok && hipMemcpy(need_hint, c->need_hint, sizeof(unsigned int) * 4u * m, hipMemcpyDeviceToHost) == hipSuccess;
     return ok ? SPLAT_OK : SPLAT_ERR_HIP;
 }
@@ -1893,7 +1916,8 @@ int splat_get_tile_lists(splat_ctx* c, uint32_t* tile_offsets, uint64_t n_offset
         // the frame's compositor selected the nearest keys of every list of more than 2048 keys and left the list itself
         // as K1 had written it: put those lists in order now (the sort launches, every tile in their grids)
         use_launch_knobs(&c->knobs);
-        launch_sort(c->stream, c->n_tiles, c->n_tiles, c->n_tiles, c->n_tiles, s.offsets, s.order, s.lens, s.keys, s.keys2, c->slots[c->last_slot].d_status, c->orig, 2048u);
+        launch_sort(c->stream, c->n_tiles, c->n_tiles, c->n_tiles, c->n_tiles, s.offsets, s.order, s.lens, s.keys, s.keys2, c->slots[c->last_slot].d_status, c->orig, 2048u,
+                    c->fc.bucket_cap ? s.off2 : nullptr);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->last_near = false;

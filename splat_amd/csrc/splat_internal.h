@@ -58,7 +58,7 @@ struct FrameStatus {
     unsigned long long n_pairs;
     unsigned int max_tile_len;
     unsigned int overflow;   // 1: n_pairs > capacity; 2: a tile outgrew its bucket; 3: more long lists than the
-                             // sort grids were sized for.  Emit/sort/composite skipped
+                             // sort grids were sized for; 4: the long lists outgrew the second key buffer.  Emit/sort/composite skipped
     unsigned long long n_fallback;   // waves whose early-out bracket did not close (redone in full)
     unsigned long long n_sort_fallback; // tiles whose radix-by-depth order failed the 64-bit check (depth ties): bitonic redo
     unsigned int n_near_tiles;       // tiles whose long list (> 2048 keys) was served by its selected nearest keys (select_near) ...
@@ -67,6 +67,7 @@ struct FrameStatus {
     unsigned int n_ge8192, n_ge2048;    // tiles whose list has >= 8192 / >= 2048 keys: in `order` they are a prefix
     unsigned int n_ge16384;             // likewise >= 16384 (the lists sorted as several runs and merged)
     unsigned int redone;                // 1: the frame outgrew its regions and was binned again on the device (overflow redo); written by every scan
+    unsigned int n_long_keys, pad2_;    // one-pass binning: entries of the second key buffer the frame's lists of more than 2048 keys ask for
     unsigned long long n_blocks_culled; // K1 blocks skipped by the bounds test (filled on the host from the block flags)
     unsigned long long layout_total;    // one-pass binning: key-buffer entries the regions built from this frame ask for (layout_kernel)
 };
@@ -87,7 +88,6 @@ struct LaunchKnobs {
     unsigned int dbg_ntiles = 0;           // != 0: composite only the N longest tiles
     unsigned int comp_lds_pad = 0;         // extra dynamic LDS per compositor workgroup (an occupancy cap)
     unsigned int dbg_select_stride = 0;    // SPLAT_DBG_SELECT_STRIDE: slots of the tile order per workgroup of the near selection's launch (default 8)
-    unsigned int dbg_repair_grid = 0;      // SPLAT_DBG_REPAIR_GRID: workgroups of the near selection's repair launch (default 64)
     unsigned int dbg_starts = 0;           // SPLAT_DBG_STARTS: statistics frames record (list length, nearest keys the walk needed) per wave
 };
 void use_launch_knobs(const LaunchKnobs* k);
@@ -110,8 +110,10 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  unsigned int* next_layout = nullptr, unsigned int* next_counts = nullptr /* both given: a second workgroup of
                      the launch builds the regions + cursors of the next frame on this stream (see launch_layout) */,
                  float spare_max = 4.0f /* how far a region may grow into the buffer's spare room */,
-                 unsigned int* repair_mask = nullptr /* near selection: per-tile words the scan zeroes for the compositor */,
-                 bool redo_only = false /* the second scan of a frame binned again on the device: nothing unless status->overflow == 2 */);
+                 bool redo_only = false /* the second scan of a frame binned again on the device: nothing unless status->overflow == 2 */,
+                 unsigned int* off2 = nullptr /* one-pass binning: per tile, where its room in the SECOND key buffer starts -- handed out
+                                                 by this scan to the lists of more than 2048 keys */,
+                 unsigned int cap2 = 0 /* entries of the second key buffer: beyond it the frame is flagged (overflow 4) */);
 // the regions (and cursors) of the slot's next one-pass frame from this frame's lists; an all-zero `layout` with cursors
 // counted from zero is the bootstrap
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
@@ -124,7 +126,8 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
 void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
                  FrameStatus* status, const unsigned int* orig /* slot -> original index: the order among equal depths */,
-                 unsigned int fused_sort_max = 0);
+                 unsigned int fused_sort_max = 0,
+                 const unsigned int* off2 = nullptr /* where a tile's room in keys2 starts; nullptr: at offsets[tile], like its list in keys */);
 // fused_sort_max: lists of up to this many keys (<= 2048) are sorted by the compositor's workgroups
 // themselves (launch_sort must be given the same value and then leaves them alone); 0 = off.
 // near selection instead of the sort launches: the nearest keys of every list of more than 2048 keys, by last frame's need
@@ -134,7 +137,8 @@ void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offs
                    unsigned int tiles_x, unsigned int tile_rows /* the tile grid: a tile's selection also looks at its neighbours' hints */,
                    unsigned int* near_thr = nullptr /* one word per tile, kept from frame to frame: the depth its last selection began at */,
                    unsigned int grid = 0 /* workgroups (each strides over the tile order); 0 = an eighth of the tiles */,
-                   bool at_rest = false /* the camera of the last frames: selections sized tightly */);
+                   bool at_rest = false /* the camera of the last frames: selections sized tightly */,
+                   const unsigned int* off2 = nullptr /* see launch_sort */);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max = 0,
@@ -149,12 +153,11 @@ void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const 
                                                              are sorted by their tile's workgroup through this buffer */,
                       const unsigned int* near_m = nullptr /* != nullptr (with keys2): near selection -- launch_select ran in front: of a
                                                    list of more than 2048 keys only the nearest near_m[tile] are in order (composite_tile) */,
-                      unsigned int* repair_mask = nullptr /* per tile: waves whose walk needed more than the selection (zeroed by the scan) */,
-                      unsigned int* repair_list = nullptr /* n_tiles entries: the tiles the repair launch takes again */,
                       unsigned int* need_hint = nullptr /* 4 words per tile, kept from frame to frame: how many of its list's nearest
                                                            keys each wave's walk needed (sizes the next frame's selection) */,
                       unsigned int* start_hint = nullptr /* 4 words per tile, kept from frame to frame: where each wave's exact walk
-                                                            started, in keys from the list's near end (fc.start_hints) */);
+                                                            started, in keys from the list's near end (fc.start_hints) */,
+                      const unsigned int* off2 = nullptr /* see launch_sort */);
 hipError_t init_device_kernels();   // per-device kernel attributes; call with the device current
 
 // ---- splat_multi.hip: the multi-GPU layer's hooks into a context (splat_ctx itself stays private to splat_api.hip)

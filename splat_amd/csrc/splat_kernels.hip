@@ -677,8 +677,11 @@ __device__ __forceinline__ bool block_may_reach_slab(const BlockBounds& bb, cons
 // CORRECTED = SPLAT_MODE_CORRECTED_PROJECTION, a compile-time flavour: in the reference's projection the clamped tx/ty
 // and the Jacobian's shear entries only reach the discarded third column of cov (src/gaussians.rs:133-151), so the
 // compiler drops them -- two divisions, the clamps and a third of the products -- when it can see that.
+#ifndef SPLAT_K1_WAVES
+#define SPLAT_K1_WAVES 1         // (A/B: 8 = at most 64 VGPRs, eight blocks per CU instead of seven)
+#endif
 template <bool BUCKET, bool CORRECTED = false>
-__global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes,
+__global__ __launch_bounds__(256, SPLAT_K1_WAVES) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes,
                                                          const unsigned int* __restrict__ orig, FrameConst fc,
                                                          Rec* __restrict__ recs, float* __restrict__ depth,
                                                          ushort4* __restrict__ rect, unsigned int* __restrict__ counts,
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
                                                     FrameStatus* __restrict__ status,
                                                     unsigned long long capacity, unsigned int bucket_cap,
                                                     unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
-                                                    FrameStatus* __restrict__ host_status, unsigned int* __restrict__ repair_mask) {
+                                                    FrameStatus* __restrict__ host_status) {
     constexpr int NCLS = 64;
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int hist[NCLS];
@@ -987,7 +990,6 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
             cursor[k] = excl;
             const unsigned int len = bucket_cap ? min(c, bucket_cap) : c;
             lens[k] = len;
-            if (repair_mask) repair_mask[k] = 0u;
             atomicAdd(&hist[cls_of(len)], 1u);
         }
         carry += total;
@@ -1146,8 +1148,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
                                                            unsigned int cls_in_lds, FrameStatus* __restrict__ host_status,
                                                            unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
-                                                           unsigned int key_entries, float spare_max, unsigned int* __restrict__ repair_mask,
-                                                           unsigned int redo_only) {
+                                                           unsigned int key_entries, float spare_max, unsigned int redo_only,
+                                                           unsigned int* __restrict__ off2, unsigned int cap2) {
     constexpr int NCLS = 64;
     if (redo_only && status->overflow != 2u) return;       // (the second scan of a frame that was binned again: see enqueue_frame)
     // Workgroup 1 of the launch (when there is one) builds the regions of the next frame on this binning stream from
@@ -1161,6 +1163,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
     __shared__ unsigned int start[NCLS];
     __shared__ unsigned long long wsum[SCAN_NT / 64];
     __shared__ unsigned int wmax[SCAN_NT / 64];
+    // The SECOND key buffer holds room only for the lists that use it -- the lists of more than 2048 keys: their sorted near
+    // selection, or the scatter space of a full sort -- handed out here, list by list, from a counter (any order will do).
+    // (A mirror of the first buffer, regions and all, used to stand behind every frame slot: 768 MB each on C3 for the 43 MB
+    // its long lists hold.)  pool2 beyond cap2: the frame is skipped like any other that outgrows its storage, the host
+    // grows the buffer (overflow = 4).
+    __shared__ unsigned int pool2;
     const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     auto cls_of = [](unsigned int c) -> unsigned int {
         if (c == 0) return 0u;
@@ -1169,6 +1177,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         return min(1u + 2u * msb + half, (unsigned int)NCLS - 1u);
     };
     row[wave][lane] = 0;
+    if (tid == 0u) pool2 = 0u;
     __syncthreads();
     unsigned long long sum = 0;
     unsigned int mx = 0, over = 0;
@@ -1197,7 +1206,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                 c[u] = raw;
                 lens[k] = len;
                 offsets[k] = l0[u];
-                if (repair_mask) repair_mask[k] = 0u;          // near selection: no wave of this tile has asked for the whole list yet
+                if (off2 != nullptr) off2[k] = len > 2048u ? atomicAdd(&pool2, (len + 63u) & ~63u) : 0u;
                 sum += c[u]; mx = max(mx, c[u]);
                 const unsigned int cls = cls_of(len);
                 if (cls_in_lds) cls_lds[k] = (unsigned char)cls;
@@ -1237,6 +1246,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         status->max_tile_len = mx & 0x7fffffffu;
         status->n_ge16384 = ge[0]; status->n_ge8192 = ge[1]; status->n_ge2048 = ge[2];
         status->overflow = (mx & 0x80000000u) ? 2u : ((ge[1] > grid_big || ge[2] > grid_mid || ge[0] > grid_long) ? 3u : 0u);
+        status->n_long_keys = pool2;            // (complete: the barriers above)
+        if (off2 != nullptr && pool2 > cap2 && status->overflow == 0u) status->overflow = 4u;
         // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
         status->n_visible = 0; status->n_singular = 0;
         status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
@@ -2035,7 +2046,8 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
                                                          unsigned long long* __restrict__ keys2,
                                                          FrameStatus* __restrict__ status, unsigned int lo,
                                                          unsigned int radix_min, int chunks, unsigned int grid0,
-                                                         unsigned int grid_long, const unsigned int* __restrict__ orig) {
+                                                         unsigned int grid_long, const unsigned int* __restrict__ orig,
+                                                         const unsigned int* __restrict__ off2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (status->overflow) return;
     // workgroups [0, grid0) take run 0 of the first grid0 lists; the next 3 * grid_long ones take runs
@@ -2059,7 +2071,7 @@ __global__ __launch_bounds__(NT) void sort_tiles_kernel(const unsigned int* __re
         sort_list_in_lds<NT, CAP>(smem, keys + b, keys + b, n, radix_min, status, orig);
     } else if (chunks) {
         // longer than chunks * CAP: radix passes over the L2-resident bucket, then the same tie fix-up
-        sort_list_global<NT>(smem + (size_t)CAP * 8, keys + b, keys2 + b, n, status, orig);
+        sort_list_global<NT>(smem + (size_t)CAP * 8, keys + b, keys2 + off2[tile], n, status, orig);
     }
 }
 
@@ -2090,7 +2102,7 @@ __global__ __launch_bounds__(NT) void merge_runs_kernel(const unsigned int* __re
                                                          unsigned long long* __restrict__ keys,
                                                          unsigned long long* __restrict__ keys2,
                                                          const FrameStatus* __restrict__ status,
-                                                         const unsigned int* __restrict__ orig) {
+                                                         const unsigned int* __restrict__ orig, const unsigned int* __restrict__ off2) {
     __shared__ unsigned long long sm[MERGE_T];
     __shared__ unsigned int split[4 * CAP / MERGE_T + 2];
     if (status->overflow) return;
@@ -2130,7 +2142,7 @@ __global__ __launch_bounds__(NT) void merge_runs_kernel(const unsigned int* __re
     };
     const unsigned int r1 = min(n, (unsigned int)CAP), r2 = min(n, 2u * CAP), r3 = min(n, 3u * CAP);
     unsigned long long* g = keys + base;
-    unsigned long long* h = keys2 + base;
+    unsigned long long* h = keys2 + off2[tile];
     merge(g, r1, g + r1, r2 - r1, h);                 // runs 0, 1 -> h[0 .. r2)
     merge(g + r2, r3 - r2, g + r3, n - r3, h + r2);   // runs 2, 3 -> h[r2 .. n)
     __syncthreads();                                  // (orders this workgroup's global writes and reads)
@@ -2268,6 +2280,23 @@ __device__ __forceinline__ f2 blend_channel2(f2 k, float ia, f2 ac) {
 #ifndef SPLAT_COMP_WAVES
 #define SPLAT_COMP_WAVES 1
 #endif
+// The compositor kernel's arguments, as ONE struct: the kernarg segment then is this struct, and the rarely taken repair path
+// (repair_tile, a real function call) re-reads them from there instead of having them handed over in registers.
+struct CompArgs {
+    FrameConst fc;
+    const unsigned int* offsets; const unsigned int* order; const unsigned int* lens;
+    unsigned long long* keys; const Rec* recs; uint32_t* argb; FrameStatus* status;
+    unsigned int fused_sort_max, radix_min;
+    uint2* iters;
+    unsigned int keep_keys, clear_first;
+    const unsigned int* orig;
+    unsigned long long* keys2; const unsigned int* near_m;
+    unsigned int* need_hint; unsigned int* start_hint; const unsigned int* off2;
+};
+typedef const __attribute__((address_space(4))) CompArgs* KernArgs;       // (constant address space: uniform scalar loads)
+template <bool PAIR, bool LIBM>
+static __device__ void repair_tile(KernArgs ka, unsigned int smem_lds, unsigned int exptab_lds, unsigned int item, bool again);
+
 // One tile (slot `item` of the longest-first tile order) by one workgroup; `smem` = sort_lds_bytes<256, 2048>() bytes.
 // PAIR: the exact walk takes two records per step with packed math (see the note above WaveLds).
 // LONG: lists of more than 2048 keys are sorted by this workgroup as well (sort_long_list), no sort launch needed.
@@ -2275,8 +2304,7 @@ __device__ __forceinline__ f2 blend_channel2(f2 k, float ia, f2 ac) {
 //   0  nobody here (the sort launches ran)
 //   1  this workgroup, in full (sort_long_list)
 //   2  NEAR SELECTION: this workgroup selects and sorts the nearest <= near_cap keys only; a wave whose walk needs more
-//      reports its tile for the repair launch (composite_repair_kernel: flavour 1 over the reported tiles, their
-//      reported waves only)
+//      makes its tile repair itself: the workgroup sorts the whole list (flavour 1's code) and the waves that asked walk again
 template <bool PAIR, bool LIBM, int LONGM>
 __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsigned long long* exptab, const unsigned int item, const FrameConst& fc,
                                                const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
@@ -2286,9 +2314,9 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                                                unsigned int radix_min, uint2* __restrict__ iters, unsigned int keep_keys,
                                                const unsigned int* __restrict__ orig, const unsigned int clear_first,
                                                unsigned long long* __restrict__ keys2, const unsigned int* __restrict__ near_m,
-                                               unsigned int* __restrict__ repair_mask, unsigned int* __restrict__ repair_list,
-                                               const unsigned int wave_mask, unsigned int* __restrict__ need_hint,
-                                               unsigned int* __restrict__ start_hint) {
+                                               unsigned int* __restrict__ need_hint, unsigned int* __restrict__ start_hint,
+                                               const unsigned int* __restrict__ off2, KernArgs ka = nullptr /* flavour 2: the kernel's arguments, for repair_tile */,
+                                               const bool walk_this_wave = true, const bool second_walk = false /* flavour 1 inside repair_tile */) {
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -2327,8 +2355,8 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // only the NEAREST keys of the list in order; the walks then see the list [lb, end) with `has_far` set -- farther keys
     // exist in front of `lb`, NOT in order.  The early-out makes that enough: a walk that starts inside the selection
     // and closes its bracket there is exact as always.  A wave whose walk would have to start at or before `lb` (its
-    // pixels did not saturate within the selection, the bracket did not close, a pixel met no record) writes no pixel and
-    // reports the tile instead: the repair launch behind this one sorts that list in full and walks those waves again.
+    // pixels did not saturate within the selection, the bracket did not close, a pixel met no record) writes no pixel: the
+    // workgroup then sorts the list in full and that wave walks again (the end of this function).
     // On C3 / C5 the selection serves every tile of the bench pose (tools/near_probe.py): 93-98 % of the long lists' keys
     // are never sorted.
     unsigned int lb = beg;
@@ -2339,7 +2367,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         unsigned int n_sort = end - beg;
         if constexpr (LONGM == 1) {
             if (end - beg > 2048u) {
-                (void)sort_long_list(smem, keys + beg, keys2 + beg, end - beg, end - beg, radix_min, status, orig);
+                (void)sort_long_list(smem, keys + beg, keys2 + off2[tile], end - beg, end - beg, radix_min, status, orig);
                 __syncthreads();
             }
         }
@@ -2350,7 +2378,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                 const unsigned int m = (unsigned int)__builtin_amdgcn_readfirstlane((int)near_m[tile]);
                 if (m < end - beg) {
                     has_far = true; lb = end - m;
-                    wk = keys2 + beg - lb;
+                    wk = keys2 + off2[tile] - lb;      // (the selection, in order, at the start of the tile's room in the second key buffer)
                 }
             }
         }
@@ -2368,6 +2396,12 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         else if (len >= (unsigned int)fc.prio_len * 2u) __builtin_amdgcn_s_setprio(2);
         else if (len >= (unsigned int)fc.prio_len) __builtin_amdgcn_s_setprio(1);
     }
+    // Everything this wave does with the list as it stands -- alpha pass, scan, exact walk, its pixels, its hints.  Returns
+    // true when the walk needs keys in FRONT of a near selection (has_far): nothing has been written then.  (The wave's
+    // own constants are derived inside: a tile that repairs itself sorts its list between two calls, and nothing of the
+    // walk should have to live in registers across that sort.)
+    if (!walk_this_wave) return;                 // (repair_tile: this wave's pixels are final; it was here for the sort)
+    auto walk_list = [&]() -> bool {
     WaveLds& L = slds[wave];
     const int txx = (int)(tile % (unsigned int)fc.tiles_x), tyy = (int)(tile / (unsigned int)fc.tiles_x) + fc.tile_row0;
     // wave w owns the 8x8 pixel block (w&1, w>>1) of the tile: a square block meets fewer of the
@@ -2379,8 +2413,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // sample extents of this wave's strip, clipped to the target / slab
     const int x1w = min(bx0 + 7, fc.W - 1);
     const int y0w = by0, y1w = min(y0w + 7, min(fc.H, fc.row_px1) - 1);
-    if (bx0 > x1w || y0w > y1w) return;           // block entirely off the target: nothing to do (no barriers below)
-    if (((wave_mask >> wave) & 1u) == 0u) return; // (repair launch: this wave's pixels are final already)
+    if (bx0 > x1w || y0w > y1w) return false;     // block entirely off the target: nothing to do
     const float xlo = (float)bx0 + off, xhi = (float)x1w + off;
     const float ylo = (float)y0w + off, yhi = (float)y1w + off;
     const float sx = (float)px + off, sy = (float)py + off;
@@ -2720,10 +2753,10 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // statistics frames only (iters != nullptr): this wave's (scan, blend) iteration counts as one plain store
     // (atomics on two frame-wide counters cost ~0.2 ms per frame)
     // (keep_keys bit 1, SPLAT_DBG_STARTS: the list's length and how many of its nearest keys this wave's walk needed instead)
-    // (the repair launch ADDS: its wave walked this tile once already, with the selection, and left its counts here)
+    // (a second walk ADDS: the wave walked this tile once already, with the selection, and left its counts here)
     if (iters != nullptr && lane == 0) {
         uint2 v = (keep_keys & 2u) ? make_uint2(end - beg, end - max(start, beg)) : make_uint2(itA, itB);
-        if ((keep_keys & 4u) && !(keep_keys & 2u)) { const uint2 o = iters[item * 4u + wave]; v.x += o.x; v.y += o.y; }
+        if (second_walk && !(keep_keys & 2u)) { const uint2 o = iters[item * 4u + wave]; v.x += o.x; v.y += o.y; }
         iters[item * 4u + wave] = v;
     }
     if constexpr (LONGM != 0) {
@@ -2737,15 +2770,58 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         if (!has_far && used > (end - beg) - ((end - beg) >> 2)) used = end - beg;     // (most of the list anyway: all of it, without a bracket)
         start_hint[tile * 4u + wave] = used;
     }
-    if constexpr (LONGM == 2) {
-        if (need_far) {
-            // the first wave of a tile to ask puts the tile on the repair list; the mask says which waves to walk again
-            if (lane == 0u && atomicOr(&repair_mask[tile], 1u << wave) == 0u) repair_list[atomicAdd(&status->n_near_fallback, 1u)] = item;
-            return;
-        }
-    }
+    if (need_far) return true;
     if (inside)
         argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
+    return false;
+    };      // walk_list
+    if constexpr (LONGM != 2) {
+        (void)walk_list();
+    } else {
+        // NEAR SELECTION, when the selection did not do for every wave (its pixels did not saturate within the selected keys, the
+        // bracket did not close there, a pixel met no record): the TILE REPAIRS ITSELF.  The workgroup is resident and holds the
+        // workspace -- its four waves meet, sort the whole list (what the sort launches would have left: flavour 1's code), and
+        // the waves that asked walk again, now over a list that is in order from its first key.  (Round 5 put such tiles on a
+        // list for a repair LAUNCH behind the frame: a serial launch of a few workgroups on a chip the next frames' binning
+        // keeps busy -- 0.1 ms behind every frame of a camera in motion on the surface scene, profiles/r05_motion_probe.txt.)
+        // The repair is a FUNCTION CALL, not inlined code: with the long-list sort and a second copy of the walks inlined the
+        // kernel needed scratch and half its uniform values spilled -- the hot path paid 4.4 % for a path a frame at rest never
+        // takes (profiles/r06_repair_ab.txt).
+        const bool again = walk_list();
+#if SPLAT_AB == 3
+        if (false) {
+#else
+        if (has_far && __syncthreads_or(again ? 1 : 0) != 0) {                // (has_far is uniform in the workgroup: the tile's near_m)
+#endif
+            if (tid == 0u) atomicAdd(&status->n_near_fallback, 1u);
+            repair_tile<PAIR, LIBM>(ka, (unsigned int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem,
+                                    (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned long long*)exptab, item, again);
+        }
+    }
+}
+
+// The rarely taken path of a near-selection frame: the tile's whole list sorted by its workgroup, the waves in `again` walked
+// over it (flavour 1 of composite_tile: sort_long_list, then the walks).  Not inlined: see composite_tile's last lines.
+// Everything but the workgroup's own state comes from the kernarg segment again; LDS addresses travel as offsets.
+// (static: with every caller in sight the compiler hands the kernel's seven-waves-per-SIMD register budget down to this
+// function -- 72 VGPRs, the rest on the stack -- instead of raising the kernel's to the 150 it would like.)
+template <bool PAIR, bool LIBM>
+static __device__ __attribute__((noinline)) void repair_tile(KernArgs ka, unsigned int smem_lds, unsigned int exptab_lds, unsigned int item, bool again) {
+    // (function arguments arrive in vector registers: make the uniform ones uniform again)
+    const unsigned long long kp = uniform_u64((unsigned long long)(size_t)ka);
+    const KernArgs k = (KernArgs)(size_t)kp;
+    unsigned char* const smem = (unsigned char*)(__attribute__((address_space(3))) unsigned char*)(size_t)__builtin_amdgcn_readfirstlane((int)smem_lds);
+    const unsigned long long* const exptab = (const unsigned long long*)(__attribute__((address_space(3))) const unsigned long long*)(size_t)__builtin_amdgcn_readfirstlane((int)exptab_lds);
+    const unsigned int it = (unsigned int)__builtin_amdgcn_readfirstlane((int)item);
+    FrameConst fc;                                  // (word by word out of the constant address space: scalar loads)
+    {
+        const __attribute__((address_space(4))) unsigned int* src = (const __attribute__((address_space(4))) unsigned int*)&k->fc;
+        unsigned int* dst = reinterpret_cast<unsigned int*>(&fc);
+#pragma unroll
+        for (unsigned int q = 0; q < sizeof(FrameConst) / 4u; ++q) dst[q] = src[q];
+    }
+    composite_tile<PAIR, LIBM, 1>(smem, exptab, it, fc, k->offsets, k->order, k->lens, k->keys, k->recs, k->argb, k->status, k->fused_sort_max, k->radix_min,
+                                  k->iters, k->keep_keys, k->orig, k->clear_first, k->keys2, nullptr, k->need_hint, k->start_hint, k->off2, nullptr, again, true);
 }
 
 // NEAR SELECTION, the kernel (one workgroup per slot of the longest-first tile order; 256 threads and the compositor's
@@ -2759,7 +2835,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
 //   as sorted parts (sort_long_list with a cap) beyond that; and a tile that ran out of its selection last time, or whose
 //   selection would be most of the list anyway, is sorted in full, in its region, as a sort launch would leave it.
 // near_m[tile] = how many of the nearest keys are in order (== the list's length: all of them).  A wrong guess costs time
-// only -- a larger sort than necessary, or the compositor's repair launch -- never a pixel.
+// only -- a larger sort than necessary, or a tile that sorts its whole list inside the compositor after all -- never a pixel.
 #ifndef SPLAT_HINT_RADIUS
 #define SPLAT_HINT_RADIUS 2
 #endif
@@ -2769,7 +2845,7 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
                                                           const unsigned int* __restrict__ orig, unsigned int radix_min, unsigned int near_cap,
                                                           const unsigned int* __restrict__ need_hint, unsigned int* __restrict__ near_m,
                                                           unsigned int tiles_x, unsigned int tile_rows, unsigned int* __restrict__ near_thr,
-                                                          unsigned int n_slots, unsigned int at_rest) {
+                                                          unsigned int n_slots, unsigned int at_rest, const unsigned int* __restrict__ off2) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
     // (an eighth as many workgroups as tiles, each taking the slots blockIdx.x, + gridDim.x, ... of the longest-first order until it
@@ -2783,6 +2859,7 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
     if (n < 2048u) return;
     if (n == 2048u) continue;
     const unsigned int beg = (unsigned int)__builtin_amdgcn_readfirstlane((int)offsets[tile]);
+    unsigned long long* const k2 = keys2 + (unsigned int)__builtin_amdgcn_readfirstlane((int)off2[tile]);     // the tile's room in the second key buffer
     unsigned int want = near_cap, deepest, thr = 0u;
     {
         // ONE wave reads the hints and the workgroup takes its word for them: the previous frames' compositors are storing
@@ -2849,14 +2926,14 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
         // (the bins are coarse where many keys share a depth: a selection that came out shorter than the tile needed last
         // time is not worth walking)
         if (m != 0u && (deepest == 0u || m >= deepest + (deepest >> 3))) {
-            sort_list_in_lds<256, 2048>(smem, nullptr, keys2 + beg, m, radix_min, status, orig, nullptr, true, 0u, smn, smx);
+            sort_list_in_lds<256, 2048>(smem, nullptr, k2, m, radix_min, status, orig, nullptr, true, 0u, smn, smx);
         } else {
             m = 0u; want = min(n, 2u * near_cap);
             __syncthreads();
         }
     }
     if (m == 0u)
-        m = sort_long_list(smem, keys + beg, keys2 + beg, n, want, radix_min, status, orig,
+        m = sort_long_list(smem, keys + beg, k2, n, want, radix_min, status, orig,
                            (deepest != 0u && deepest != 0xffffffffu) ? min(n, deepest + (deepest >> 3)) : 0u);
     if (threadIdx.x == 0u) {
         near_m[tile] = m;
@@ -2869,72 +2946,28 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
 // The launch: one workgroup per tile, slot blockIdx.x of the longest-first order.  (A persistent grid pulling
 // slots from a ticket counter, and the order composited as consecutive chunk launches, were both measured as
 // ways to cap the compositor's residency beside the next frame's K1: both slower -- DESIGN.md section 3.)
-// LONGM == 1: seven waves per SIMD = seven workgroups per CU, which is also what the 21.5 KB of LDS allow: at most 72
-// VGPRs.  The walks need 64; the long-list sort in front of them would take 88, and under this bound spills nine
-// registers around its loop over the parts instead -- outside every hot loop (checked in the ISA).
+// Flavours that carry the long-list sort (1: always; 2: a tile of a near-selection frame that repairs itself): seven
+// waves per SIMD = seven workgroups per CU, which is also what the 21.5 KB of LDS allow: at most 72 VGPRs.  The walks
+// need 64-69; the long-list sort would take 88, and under this bound spills nine registers around its loop over the
+// parts instead -- outside every hot loop (checked in the ISA).
 // (At most 96 SGPRs: with 97-112 a CU admits six 256-thread workgroups instead of seven -- MI355X_MICROARCH.md,
 // "Residency" -- and the compositor hides its LDS and dependency latency with residency.  The near-selection flavour
 // carries a few more uniform values than the others and would take 106.)
+#ifndef SPLAT_AB
+#define SPLAT_AB 0
+#endif
 template <bool PAIR, bool LIBM, int LONGM>
-__global__ __launch_bounds__(256, LONGM == 1 ? 7 : SPLAT_COMP_WAVES) __attribute__((amdgpu_num_sgpr(96))) void composite_exact_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
-                                                              const unsigned int* __restrict__ order,
-                                                              const unsigned int* __restrict__ lens,
-                                                              unsigned long long* __restrict__ keys,
-                                                              const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
-                                                              FrameStatus* __restrict__ status, unsigned int fused_sort_max,
-                                                              unsigned int radix_min, uint2* __restrict__ iters,
-                                                              unsigned int keep_keys, const unsigned int* __restrict__ orig,
-                                                              unsigned int clear_first, unsigned long long* __restrict__ keys2,
-                                                              const unsigned int* __restrict__ near_m, unsigned int* __restrict__ repair_mask,
-                                                              unsigned int* __restrict__ repair_list, unsigned int* __restrict__ need_hint,
-                                                              unsigned int* __restrict__ start_hint) {
+__global__ __launch_bounds__(256, (LONGM != 0 && !PAIR) ? 7 : SPLAT_COMP_WAVES) __attribute__((amdgpu_num_sgpr(96))) void composite_exact_kernel(CompArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     __shared__ unsigned long long exptab[LIBM ? 32 : 1];
-    if (status->overflow) return;
+    if (a.status->overflow) return;
     if constexpr (LIBM) {
         static_assert(!PAIR, "the libm exponential is built for the one-record walk only");
         if (threadIdx.x < 32) exptab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
         __syncthreads();
     }
-    composite_tile<PAIR, LIBM, LONGM>(smem, exptab, blockIdx.x, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, keep_keys, orig, clear_first, keys2,
-                                      near_m, repair_mask, repair_list, 0xfu, need_hint, start_hint);
-}
-
-// The repair launch behind a near-selection frame: the tiles whose selected nearest keys did not do for every wave
-// (status->n_near_fallback entries of repair_list; normally none) are taken again by a few workgroups -- the whole list
-// sorted (flavour 1), the reported waves walked from memory.  The other waves' pixels are final and stay untouched.
-template <bool PAIR, bool LIBM>
-__global__ __launch_bounds__(256) void composite_repair_kernel(FrameConst fc, const unsigned int* __restrict__ offsets,
-                                                               const unsigned int* __restrict__ order,
-                                                               const unsigned int* __restrict__ lens,
-                                                               unsigned long long* __restrict__ keys,
-                                                               const Rec* __restrict__ recs, uint32_t* __restrict__ argb,
-                                                               FrameStatus* __restrict__ status, unsigned int fused_sort_max,
-                                                               unsigned int radix_min, const unsigned int* __restrict__ orig,
-                                                               unsigned int clear_first, unsigned long long* __restrict__ keys2,
-                                                               const unsigned int* __restrict__ repair_mask,
-                                                               const unsigned int* __restrict__ repair_list,
-                                                               unsigned int* __restrict__ need_hint, unsigned int* __restrict__ start_hint,
-                                                               uint2* __restrict__ iters, unsigned int flags) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
-    __shared__ unsigned long long exptab[LIBM ? 32 : 1];
-    if (status->overflow) return;
-    const unsigned int count = status->n_near_fallback;
-    if (blockIdx.x >= count) return;
-    // (a repair is pure latency on the frame -- a handful of workgroups, the next frame's compositor waits behind them, the chip
-    // is busy with the next frames' binning: their waves go first)
-    __builtin_amdgcn_s_setprio(3);
-    if constexpr (LIBM) {
-        if (threadIdx.x < 32) exptab[threadIdx.x] = EXP2F_TAB[threadIdx.x];
-        __syncthreads();
-    }
-    for (unsigned int i = blockIdx.x; i < count; i += gridDim.x) {
-        const unsigned int item = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_list[i]);
-        const unsigned int mask = (unsigned int)__builtin_amdgcn_readfirstlane((int)repair_mask[order[item]]);
-        composite_tile<PAIR, LIBM, 1>(smem, exptab, item, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max, radix_min, iters, (flags & 2u) | 4u, orig, clear_first, keys2,
-                                      nullptr, nullptr, nullptr, mask, need_hint, start_hint);
-        __syncthreads();          // the workspace is the next tile's: every wave has finished its walk
-    }
+    composite_tile<PAIR, LIBM, LONGM>(smem, exptab, blockIdx.x, a.fc, a.offsets, a.order, a.lens, a.keys, a.recs, a.argb, a.status, a.fused_sort_max, a.radix_min, a.iters, a.keep_keys, a.orig,
+                                      a.clear_first, a.keys2, a.near_m, a.need_hint, a.start_hint, a.off2, (KernArgs)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 // ---------------------------------------------------------------------------
@@ -2987,7 +3020,7 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
                  FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts, float spare_max,
-                 unsigned int* repair_mask, bool redo_only) {
+                 bool redo_only, unsigned int* off2, unsigned int cap2) {
     if (bucket_cap && layout)
     {
         const unsigned int nwg = (next_layout && next_counts) ? 2u : 1u;
@@ -2998,17 +3031,17 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         const unsigned int dyn = in_lds ? cls_bytes : 0u;
         if (nt == 256)
             hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(nwg), dim3(256), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask, redo_only ? 1u : 0u);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2);
         else if (nt == 512)
             hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(nwg), dim3(512), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask, redo_only ? 1u : 0u);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2);
         else
             hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(nwg), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, repair_mask, redo_only ? 1u : 0u);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
-                           bucket_cap, grid_big, grid_mid, grid_long, host_status, repair_mask);
+                           bucket_cap, grid_big, grid_mid, grid_long, host_status);
 }
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
                    unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max,
@@ -3022,8 +3055,9 @@ void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, c
 }
 void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long, const unsigned int* offsets,
                  const unsigned int* order, const unsigned int* lens, unsigned long long* keys, unsigned long long* keys2,
-                 FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max) {
+                 FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, const unsigned int* off2) {
     if (!n_tiles) return;
+    if (!off2) off2 = offsets;          // (two-pass binning: the second buffer mirrors the first, list for list)
     const unsigned int radix_min = sort_radix_min();
     // longest class first (the tiles are ordered longest-first too)
     grid_big = std::min(grid_big, n_tiles); grid_mid = std::min(grid_mid, n_tiles);
@@ -3032,55 +3066,51 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
         // (two-pass binning only: one-pass buckets hold at most 16384 keys and there is no keys2)
         grid_long = keys2 ? std::min(grid_long, grid_big) : 0u;
         hipLaunchKernelGGL((sort_tiles_kernel<1024, 16384>), dim3(grid_big + 3u * grid_long), dim3(1024), (sort_lds_bytes<1024, 16384>()), s,
-                           offsets, order, lens, keys, keys2, status, 8192u, radix_min, keys2 ? 4 : 1, grid_big, std::max(grid_long, 1u), orig);
+                           offsets, order, lens, keys, keys2, status, 8192u, radix_min, keys2 ? 4 : 1, grid_big, std::max(grid_long, 1u), orig, off2);
         if (grid_long)
             hipLaunchKernelGGL((merge_runs_kernel<1024, 16384>), dim3(grid_long), dim3(1024), 0, s, offsets, order, lens, keys, keys2,
-                               status, orig);
+                               status, orig, off2);
     }
     if (grid_mid)
     hipLaunchKernelGGL((sort_tiles_kernel<512, 8192>), dim3(grid_mid), dim3(512), (sort_lds_bytes<512, 8192>()), s, offsets, order,
-                       lens, keys, keys2, status, 2048u, radix_min, 0, 0u, 1u, orig);
+                       lens, keys, keys2, status, 2048u, radix_min, 0, 0u, 1u, orig, off2);
     if (fused_sort_max < 2048u)      // (lists up to fused_sort_max are sorted by the compositor's own workgroups)
         hipLaunchKernelGGL((sort_tiles_kernel<256, 2048>), dim3(n_tiles), dim3(256), (sort_lds_bytes<256, 2048>()), s, offsets, order,
-                           lens, keys, keys2, status, fused_sort_max, radix_min, 0, 0u, 1u, orig);
+                           lens, keys, keys2, status, fused_sort_max, radix_min, 0, 0u, 1u, orig, off2);
 }
 void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
                    unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
-                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows, unsigned int* near_thr, unsigned int grid, bool at_rest) {
+                   const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows, unsigned int* near_thr, unsigned int grid, bool at_rest,
+                   const unsigned int* off2) {
     if (!n_tiles) return;
+    if (!off2) off2 = offsets;
     if (g_knobs->dbg_select_stride) grid = (n_tiles + g_knobs->dbg_select_stride - 1u) / g_knobs->dbg_select_stride;
     if (!grid) grid = (n_tiles + 7u) / 8u;
     hipLaunchKernelGGL(select_near_kernel, dim3(std::min(grid, n_tiles)), dim3(256), 0, s, offsets, order, lens, keys, keys2, status, orig, sort_radix_min(),
-                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr, n_tiles, at_rest ? 1u : 0u);
+                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr, n_tiles, at_rest ? 1u : 0u, off2);
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max, uint2* iters,
                       bool keep_keys, bool pair_walk, bool libm_exp, bool clear_first, unsigned long long* keys2, const unsigned int* near_m,
-                      unsigned int* repair_mask, unsigned int* repair_list, unsigned int* need_hint, unsigned int* start_hint) {
+                      unsigned int* need_hint, unsigned int* start_hint, const unsigned int* off2) {
     if (!n_tiles) return;
+    if (!off2) off2 = offsets;
     if (g_knobs->dbg_ntiles) n_tiles = std::min(n_tiles, g_knobs->dbg_ntiles);   // debug: composite only the N longest tiles
     // SPLAT_COMP_LDS_PAD: extra dynamic LDS per workgroup, i.e. an occupancy cap (12 KB are in use:
     // 13 workgroups fit a CU's LDS, 8 its wave slots) -- for overlapping the next frame's K1
     const unsigned int pad = g_knobs->comp_lds_pad;
-    const bool near = near_m != nullptr && keys2 != nullptr && repair_mask != nullptr && repair_list != nullptr && need_hint != nullptr;
+    const bool near = near_m != nullptr && keys2 != nullptr && need_hint != nullptr;
     const unsigned int flags = (keep_keys ? 1u : 0u) | (g_knobs->dbg_starts ? 2u : 0u);
-    auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), pad, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                           sort_radix_min(), iters, flags, orig, clear_first ? 1u : 0u, keys2, near_m, repair_mask, repair_list, near ? need_hint : nullptr, start_hint);
-    };
-    if (near) {
+    CompArgs a;
+    a.fc = fc; a.offsets = offsets; a.order = order; a.lens = lens; a.keys = keys; a.recs = recs; a.argb = argb; a.status = status;
+    a.fused_sort_max = fused_sort_max; a.radix_min = sort_radix_min(); a.iters = iters; a.keep_keys = flags; a.clear_first = clear_first ? 1u : 0u;
+    a.orig = orig; a.keys2 = keys2; a.near_m = near_m; a.need_hint = near ? need_hint : nullptr; a.start_hint = start_hint; a.off2 = off2;
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), pad, s, a); };
+    if (near) {         // (a tile the selection does not serve repairs itself: no launch behind this one)
         if (libm_exp) go(composite_exact_kernel<false, true, 2>);
         else if (pair_walk) go(composite_exact_kernel<true, false, 2>);
         else go(composite_exact_kernel<false, false, 2>);
-        // the repair launch: tiles the selection did not serve (normally none: its workgroups read one word and leave)
-        auto fix = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(std::min(n_tiles, g_knobs->dbg_repair_grid ? g_knobs->dbg_repair_grid : 64u)), dim3(256), 0, s, fc, offsets, order, lens, keys, recs, argb, status, fused_sort_max,
-                               sort_radix_min(), orig, clear_first ? 1u : 0u, keys2, repair_mask, repair_list, need_hint, start_hint, iters, flags);
-        };
-        if (libm_exp) fix(composite_repair_kernel<false, true>);
-        else if (pair_walk) fix(composite_repair_kernel<true, false>);
-        else fix(composite_repair_kernel<false, false>);
     } else if (keys2 != nullptr) {
         if (libm_exp) go(composite_exact_kernel<false, true, 1>);
         else if (pair_walk) go(composite_exact_kernel<true, false, 1>);

@@ -252,6 +252,19 @@ def test_fuzzed_pose_sequences_through_the_frame_pipeline():
     assert "15 cases, 0 failures" in r.stdout
 
 
+def test_frames_do_not_depend_on_the_schedule():
+    """tools/fuzz_async.py --determinism: every fuzzed pose sequence is rendered by three processes -- the default frame
+    pipeline (two binning chains + a compositor in flight), SPLAT_PIPELINE=1 (one stream) and AMD_SERIALIZE_KERNEL=3 (the
+    runtime waits around every launch) -- and the frames' digests must agree: bytes that depend on how launches interleave
+    are a race (the allocation-time fill race of round 5 would have been caught by this two rounds earlier)."""
+    import subprocess, sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_async.py"), "--determinism", "5", "900"], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "5 cases x 3 schedules, 0 failures" in r.stdout
+
+
 def test_first_call_after_allocation_counts_into_zeroed_counters_under_contention():
     """tools/row_loads_stress.py: six processes share the GPU and each asks for the C3 frame's per-tile-row pair counts right
     after its upload, then again between frames.  The context's fills at allocation time are hipMemset calls, which are

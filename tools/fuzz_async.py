@@ -3,7 +3,13 @@
 frames in flight with storage and launch sizes derived from EARLIER frames of the sequence, each into its own
 device image; then every image is compared with the same pose rendered synchronously.  A frame may only differ if it
 was skipped on the device (then its image is untouched and splat_frames_dropped() accounts for it); also slabs
-(2..4 tile-row slabs == the full frame) and the streamed path.   usage: python tools/fuzz_async.py [n_cases] [seed]"""
+(2..4 tile-row slabs == the full frame) and the streamed path.   usage: python tools/fuzz_async.py [n_cases] [seed]
+  --determinism [n_cases] [seed]: every case's sequence (asynchronous frames + their synchronous references) is rendered by
+  THREE processes -- the default pipeline, SPLAT_PIPELINE=1 (one stream, nothing overlaps) and AMD_SERIALIZE_KERNEL=3 (the
+  runtime waits before and after every launch) -- and the frames' digests are compared: a race between streams, or a fill the
+  launches do not wait for (the allocation-time race of round 5 lived through two rounds), shows up as bytes that depend on
+  the schedule."""
+import hashlib, json, os, subprocess
 import sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -12,6 +18,86 @@ from splat_amd import _lib
 from splat_amd.renderer import SplatError
 from helpers import make_camera
 
+def sequence(rng, H, W):
+    """jumps, and between them stretches of a camera at rest and of one that creeps (0.03-0.35 degrees a frame)"""
+    poses = []
+    pos, yaw, pitch, lp = (0, 0, 5.0), 0.0, 0.0, 0.01
+    for k in range(18):
+        r = rng.uniform()
+        if k == 0 or r >= 0.55:
+            pos = [(0, 0, 5.0), (0, 0, 1.5), (0.3, 0.2, 0.4), (0, 0, 25.0), (2.0, -1.0, 3.0), (0, 0, 9.0)][int(rng.integers(0, 6))]
+            yaw, pitch, lp = float(rng.uniform(0, 6.28)), float(rng.uniform(-0.5, 0.5)), float(rng.choice([0.01, 0.3]))
+        elif r >= 0.3:
+            yaw += float(rng.uniform(0.0005, 0.006))
+        poses.append(make_camera(H, W, pos, yaw=yaw, pitch=pitch).to_c(lp, 15))
+    return poses
+
+
+def emit(seed):
+    """child of --determinism: one case under this process's environment; prints the frames' digests"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([3000, 20000, 80000, 200000]))
+    g = splat_amd.synthetic_scene(n, seed)
+    if rng.integers(0, 3) == 0: g.positions[:, :3] *= rng.choice([0.1, 0.3])
+    H, W = int(rng.choice([96, 160, 240])), int(rng.choice([128, 200, 320]))
+    R = splat_amd.Renderer()
+    g.compute_cov3d(R); R.upload(g)
+    poses = sequence(rng, H, W)
+    garbage = rng.integers(1, 2**32, (H, W), dtype=np.uint64).astype(np.uint32)
+    imgs = [R.device_image(garbage) for _ in poses]
+    R.render_device(poses[0], imgs[0], sync=True)
+    R.device_free(imgs[0]); imgs[0] = R.device_image(garbage)
+    for p_, im in zip(poses, imgs):
+        R.render_frame_device(p_, im)
+    try:
+        R.sync()
+    except SplatError:
+        pass
+    out = {"async": [], "sync": []}
+    for im in imgs:
+        a = R.device_download(im, H, W)
+        out["async"].append("skipped" if np.array_equal(a, garbage) else hashlib.sha256(a.tobytes()).hexdigest())
+    for p_ in poses:
+        ref = np.zeros((H, W), np.uint32)
+        R.render(p_, ref)
+        out["sync"].append(hashlib.sha256(ref.tobytes()).hexdigest())
+    R.close()
+    print("DIGEST " + json.dumps(out))
+
+
+def determinism(ncases, seed0):
+    envs = [("default", {}), ("SPLAT_PIPELINE=1", {"SPLAT_PIPELINE": "1"}), ("AMD_SERIALIZE_KERNEL=3", {"AMD_SERIALIZE_KERNEL": "3"})]
+    bad = 0
+    t0 = time.time()
+    for case in range(ncases):
+        got = []
+        for name, extra in envs:
+            env = dict(os.environ); env.update(extra)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--emit", str(seed0 + case)], capture_output=True, text=True, env=env, timeout=600)
+            line = next((l for l in r.stdout.splitlines() if l.startswith("DIGEST ")), None)
+            if r.returncode != 0 or line is None:
+                bad += 1; print("CASE seed %d under %s: child failed (rc %d)\n%s" % (seed0 + case, name, r.returncode, r.stderr[-400:])); got.append(None); continue
+            got.append(json.loads(line[7:]))
+        base = got[0]
+        for (name, _), d in zip(envs[1:], got[1:]):
+            if base is None or d is None: continue
+            if d["sync"] != base["sync"]:
+                bad += 1; print("CASE seed %d: synchronous frames differ between the default schedule and %s: frames %s" % (seed0 + case, name, [k for k, (a, b) in enumerate(zip(base["sync"], d["sync"])) if a != b]))
+            diff = [k for k, (a, b) in enumerate(zip(base["async"], d["async"])) if a != b and "skipped" not in (a, b)]
+            if diff:
+                bad += 1; print("CASE seed %d: asynchronous frames %s differ between the default schedule and %s" % (seed0 + case, diff, name))
+        if base is not None:
+            wrong = [k for k, (a, b) in enumerate(zip(base["async"], base["sync"])) if a != b and a != "skipped"]
+            if wrong:
+                bad += 1; print("CASE seed %d: asynchronous frames %s are not their synchronous renders" % (seed0 + case, wrong))
+    print("fuzz_async --determinism: %d cases x %d schedules, %d failures, %.0f s" % (ncases, len(envs), bad, time.time() - t0))
+    return bad
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--emit":
+    emit(int(sys.argv[2])); sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "--determinism":
+    sys.exit(1 if determinism(int(sys.argv[2]) if len(sys.argv) > 2 else 12, int(sys.argv[3]) if len(sys.argv) > 3 else 500) else 0)
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = 0
@@ -25,18 +111,8 @@ for case in range(ncases):
     H, W = int(rng.choice([96, 160, 240])), int(rng.choice([128, 200, 320]))
     R = splat_amd.Renderer()
     g.compute_cov3d(R); R.upload(g)
-    # jumps, and between them stretches of a camera at rest and of one that creeps (0.03-0.35 degrees a frame): the frames
-    # whose exact walks start from the previous frames' hints (SPLAT_OPT_START_HINTS) and whose selections are sized tightly
-    poses = []
-    pos, yaw, pitch, lp = (0, 0, 5.0), 0.0, 0.0, 0.01
-    for k in range(18):
-        r = rng.uniform()
-        if k == 0 or r >= 0.55:
-            pos = [(0, 0, 5.0), (0, 0, 1.5), (0.3, 0.2, 0.4), (0, 0, 25.0), (2.0, -1.0, 3.0), (0, 0, 9.0)][int(rng.integers(0, 6))]
-            yaw, pitch, lp = float(rng.uniform(0, 6.28)), float(rng.uniform(-0.5, 0.5)), float(rng.choice([0.01, 0.3]))
-        elif r >= 0.3:
-            yaw += float(rng.uniform(0.0005, 0.006))
-        poses.append(make_camera(H, W, pos, yaw=yaw, pitch=pitch).to_c(lp, 15))
+    # the frames whose exact walks start from the previous frames' hints (SPLAT_OPT_START_HINTS) and whose selections are sized tightly
+    poses = sequence(rng, H, W)
     garbage = rng.integers(1, 2**32, (H, W), dtype=np.uint64).astype(np.uint32)
     imgs = [R.device_image(garbage) for _ in poses]
     d0 = R.frames_dropped()
