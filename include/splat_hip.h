@@ -277,6 +277,12 @@ int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
 #define SPLAT_OPT_KEYS_PER_GAUSSIAN 20   /* one-pass binning: entries of a frame slot's key buffer per Gaussian of the scene, 4..256,
                                             0 = by the scene's size (default; SPLAT_KEYS_PER_GAUSSIAN).  What the tiles' regions do
                                             not ask for is their room to grow under a moving camera (SPLAT_OPT_REGION_SPARE)       */
+#define SPLAT_OPT_COUNT_FIRST 21         /* one-pass binning: which frames count their pairs per tile first (K1's count flavour: geometry
+                                            only, a third of a K1) and bin into regions that fit exactly their own camera, instead of
+                                            into regions sized from the frame two back: 0 = only a frame slot without regions (first
+                                            frames, a new scene / target / slab); 1 = also the frames behind one that outgrew its
+                                            regions and was binned twice, and behind a camera jump; 2 = also every frame whose camera
+                                            moved by more than half a degree (default: see DESIGN.md section 3; SPLAT_COUNT_FIRST)    */
 int splat_set_option(splat_ctx* ctx, int32_t option, double value);
 int splat_get_option(const splat_ctx* ctx, int32_t option, double* value);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */

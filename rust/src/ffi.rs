@@ -34,6 +34,7 @@ pub const SPLAT_OPT_OVERFLOW_REDO: i32 = 17;
 pub const SPLAT_OPT_START_HINTS: i32 = 18;
 pub const SPLAT_OPT_HOST_ZERO_COPY: i32 = 19;
 pub const SPLAT_OPT_KEYS_PER_GAUSSIAN: i32 = 20;
+pub const SPLAT_OPT_COUNT_FIRST: i32 = 21;
 /// SPLAT_ABI_VERSION of the header this file mirrors; compared with splat_abi_version() before the first call
 pub const SPLAT_ABI_VERSION: u32 = 6;
 

@@ -125,6 +125,7 @@ OPT_OVERFLOW_REDO = 17
 OPT_START_HINTS = 18
 OPT_HOST_ZERO_COPY = 19
 OPT_KEYS_PER_GAUSSIAN = 20
+OPT_COUNT_FIRST = 21
 ABI_VERSION = 6          # SPLAT_ABI_VERSION of the header these structures were written against
 
 _LIB = None

@@ -192,6 +192,11 @@ struct splat_ctx {
     // skipped and reported as before, and arms the redo); 2 = on every moving frame.
     int overflow_redo = 1;
     int redo_armed = 0;                    // moving frames left that still carry the redo launches (adaptive)
+    int count_first = 1;                   // SPLAT_OPT_COUNT_FIRST: 0 only slots without a layout; 1 + the frames behind one that was binned twice, and behind
+                                           // a camera jump; 2 + every frame whose camera moved by more than half a degree
+    float cam_delta = 0.0f;                // how far the camera moved since the last frame (largest relative change of a view / projection entry)
+    int count_first_left = 0;              // moving frames left that count their pairs first (enqueue_frame): set when a frame was binned twice
+    int hint_radius = 2;                   // tiles around a tile whose walks' needs size its near selection (by the camera's motion: enqueue_frame)
     int start_hints = 2;                   // SPLAT_OPT_START_HINTS / SPLAT_START_HINTS: 0 the compositor scans for its walks' starts on every frame; 1 not with
                                            // a camera at rest; 2 nor, three frames of four, with one in slow motion (see enqueue_frame)
     bool cam_jumped = false;               // this frame's camera is a jump away from the last frame's: its lists may outgrow any region sized before
@@ -372,7 +377,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow) c->frames_dropped++;
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) c->bucket_overflow = true;           // a tile's list outgrew its region: the layouts are stale
-    if (st.overflow == 2 || st.redone == 1u) c->redo_armed = 256;  // ... or did and was binned again on the device: keep the redo launches on
+    if (st.overflow == 2 || st.redone == 1u) { c->redo_armed = 256; c->count_first_left = 64; }  // ... or did and was binned again on the device: keep the redo launches on
     if (st.layout_total > c->cap) c->layout_want = std::max<uint64_t>(c->layout_want, st.layout_total);   // the regions were cut off
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 4) c->keys2_want = std::max<uint64_t>(c->keys2_want, st.n_long_keys);
@@ -474,6 +479,18 @@ int ensure_bins(splat_ctx* c, unsigned int m) {
 
 int slots_in_use(const splat_ctx* c);
 
+// depth / pixel rectangle / visible list per Gaussian and frame slot (16 bytes x N x slots): what the COUNTING flavour of K1
+// hands to K2 -- two-pass binning, splat_tile_row_loads, splat_get_records.  A one-pass frame keeps all three in registers,
+// so they exist from the first call that needs them (the slots the caller names), not from the upload.
+int ensure_two_pass_buffers(splat_ctx* c, Slot& s) {
+    if (s.depth || c->n == 0) return SPLAT_OK;
+    hipError_t e = dmalloc(c, &s.depth, sizeof(float) * c->n);
+    if (e == hipSuccess) e = dmalloc(c, &s.rect, sizeof(ushort4) * c->n);
+    if (e == hipSuccess) e = dmalloc(c, &s.vislist, sizeof(unsigned int) * c->n);
+    if (e != hipSuccess) { dfree(s.depth); dfree(s.rect); dfree(s.vislist); return fail(c, SPLAT_ERR_HIP, std::string("hipMalloc(two-pass buffers): ") + hipGetErrorString(e)); }
+    return SPLAT_OK;
+}
+
 // keys of at least `want` entries, and a second key buffer of at least `want2`, in every slot that frames rotate through
 // (a buffer that is large enough is kept)
 int ensure_keys(splat_ctx* c, uint64_t want, uint64_t want2) {
@@ -513,16 +530,23 @@ uint64_t default_pair_capacity(const splat_ctx* c) {
 // memory on C3, 14.8 -> 15.4 GB on C5 (32 N), of 288.
 int slots_in_use(const splat_ctx* c);
 uint64_t region_capacity_for(const splat_ctx* c, uint64_t mult) { return std::max<uint64_t>(1ull << 22, mult * c->n); }
-// The second key buffer of a one-pass frame slot: room for the lists of more than 2048 keys (the scan hands it out).  16
-// entries per Gaussian hold every frame measured (C3's bench pose asks for 5.3 M of 24 M, the surface scene from inside
+// The second key buffer of a one-pass frame slot: room for the lists of more than 2048 keys (the scan hands it out).  12
+// entries per Gaussian hold every frame measured (C3's bench pose asks for 5.3 M of 18 M, the surface scene from inside
 // for 15 M); a frame that asks for more is skipped once and the buffer grown (finish_frame).
-uint64_t default_keys2_capacity(const splat_ctx* c) { return std::max<uint64_t>(1ull << 22, 16 * c->n); }
+uint64_t default_keys2_capacity(const splat_ctx* c) {
+    if (c->knobs.dbg_keys2_entries) return c->knobs.dbg_keys2_entries;      // (tests force the growth path)
+    return std::max<uint64_t>(1ull << 22, 12 * c->n);
+}
 uint64_t default_region_multiplier(const splat_ctx* c) {
     if (c->keys_per_gaussian) return c->keys_per_gaussian;
     const uint64_t per_entry = 8ull * (uint64_t)slots_in_use(c);               // a key buffer in every frame slot
     const uint64_t GiB = 1ull << 30;
+    // 32 entries per Gaussian (64 for scenes of up to half a million Gaussians, where it is a gigabyte: their frames are
+    // short, and a frame binned twice shows), 16 beyond 32 GiB.  What the 64 of round 5 bought a camera in motion -- fewer
+    // frames binned twice -- the count-first frames of round 6 give it without the room (profiles/r06_motion_probe.txt),
+    // for 1.5 GB less on C3.
     uint64_t mult = 16;
-    if (64 * c->n * per_entry <= 4 * GiB) mult = 64;
+    if (64 * c->n * per_entry <= 1 * GiB) mult = 64;
     else if (32 * c->n * per_entry <= 32 * GiB) mult = 32;
     // ... and never more than a quarter of what the device has free right now: a GPU shared with other contexts (eight slab
     // ranks on one device, a host application's own allocations) takes the smaller buffer at once instead of failing the large one
@@ -637,8 +661,14 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         // for a caller that interleaves uploads), and after the compositor that last used the slot
         if (s.used && s.free_ring >= 0) HIP_TRY(c, hipStreamWaitEvent(bs, c->ring[s.free_ring].e[7], 0));
     }
-    if (!c->fc.bucket_cap)                                 // two-pass binning: K1 counts visible Gaussians into the status before the scan
+#if SPLAT_K1X == 30 || SPLAT_K1X == 31
+    { int rck = ensure_two_pass_buffers(c, s); if (rck != SPLAT_OK) return rck; }      // (the timeline builds stamp into depth / rect)
+#endif
+    if (!c->fc.bucket_cap) {                               // two-pass binning: K1 counts visible Gaussians into the status before the scan
+        int rc2 = ensure_two_pass_buffers(c, s);
+        if (rc2 != SPLAT_OK) return rc2;
         HIP_TRY(c, hipMemsetAsync(d_st, 0, sizeof(FrameStatus), bs));
+    }
     // One-pass binning: the tiles' regions of the key buffer and their cursors.  Normally the layout_kernel of the frame
     // before this one ON THIS STREAM has left them in the slot's other copy (below); a slot without a layout (first
     // frames, a new scene / target / slab, after a frame outgrew a region) counts its pairs first -- K1 against the
@@ -677,18 +707,39 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         c->fc.start_hints = mode;
         c->fc.start_light = delta < 0.003f ? 1 : 0;
         c->cam_jumped = delta >= 0.2f;          // (a cut, not a pan: ~12 degrees or more since the last frame)
+        c->cam_delta = delta;
+        // how far the image moved since the last frame, in tiles: a rotation by delta radians shifts the centre by focal * delta
+        // pixels (the matrices' entries change by about the angle).  The near selection looks that far around a tile for what
+        // its walks may need (launch_select): 2 tiles for a camera at rest, 7 for a 10-degree step.
+        c->hint_radius = std::min(7, std::max(2, (int)std::ceil(delta * c->fc.focal / (float)TILE) + 1));
         // (at rest the scan is paid once, in the first frames after the camera stopped: lists from half the usual length take the
         // early-out then -- 384 instead of 768 keys: C3 3060 -> 3120 frames/s, below that nothing more)
         if (c->start_hints >= 1 && c->still_frames >= 1u) c->fc.early_min = std::min(c->fc.early_min, std::max(c->early_min / 2, 1));
     }
     bool moved = false;
     if (c->fc.bucket_cap) {
-        if (!s.layout_valid) {
-            HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));
-            launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.counts, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout);
-            launch_layout(bs, m, s.counts, c->zero_layout, s.lay_b, s.counts_b, c->fc.bucket_cap, nullptr, nullptr, c->region_spare);
-            s.flip = 1; s.layout_valid = true;
-            s.layout_cam[1] = cam_hash;
+        // COUNT FIRST: the frame counts its pairs per tile (K1's count flavour: geometry planes only, no SH, no record, no key --
+        // a third of a K1) and bins into regions that fit exactly ITS camera.  A slot without a layout does (first frames, a
+        // new scene / target / slab, after a frame outgrew the key buffer); so do the frames behind a camera JUMP (the jump's
+        // own and the eight behind it: the slots' regions are sized two frames ahead, from lists of before the jump); and,
+        // by SPLAT_OPT_COUNT_FIRST, either every frame whose camera moved by more than half a degree (2), or (1) the 64
+        // moving frames behind one that outgrew regions sized two frames back and was binned twice (the overflow redo: a K1,
+        // then another K1 -- 0.15 + 0.15 ms of binning where the frame that counts first pays 0.06 + 0.15), after which one
+        // tries its luck again.  (A host that runs 30 frames ahead of the device learns of a frame binned twice 30 frames
+        // late: hence 64, not 8.)
+        if (c->cam_jumped && c->count_first != 0) c->count_first_left = std::max(c->count_first_left, 9);
+        bool count_first = !s.layout_valid;
+        if (!count_first && s.layout_cam[s.flip] != cam_hash && c->count_first != 0) {
+            if (c->count_first >= 2 && c->cam_delta >= 0.009f) count_first = true;
+            else if (c->count_first_left > 0) { count_first = true; --c->count_first_left; }
+        }
+        if (count_first) {
+            const int into = s.layout_valid ? s.flip : 1;
+            HIP_TRY(c, hipMemsetAsync(s.redo_cursors, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));     // (the redo's buffer: a count-first frame has no redo)
+            launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout, true);
+            launch_layout(bs, m, s.redo_cursors, c->zero_layout, into ? s.lay_b : s.lay_a, into ? s.counts_b : s.counts, c->fc.bucket_cap, nullptr, nullptr, c->region_spare);
+            s.flip = into; s.layout_valid = true;
+            s.layout_cam[into] = cam_hash;
         }
         cursors = s.flip ? s.counts_b : s.counts;
         layout = s.flip ? s.lay_b : s.lay_a;
@@ -726,14 +777,14 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     unsigned int* const off2 = c->fc.bucket_cap ? s.off2 : nullptr;        // (two-pass binning: the second buffer mirrors the first)
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
                 next_layout, next_counts, c->region_spare, false, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull));
-    if (c->fc.bucket_cap && moved && c->overflow_redo == 1 && c->redo_armed < 128) {
+    if (c->fc.bucket_cap && moved && c->overflow_redo == 1 && (c->redo_armed < 128 || c->count_first_left == 0)) {
         // A frame still in flight that outgrew a region (or was binned again): its scan has written that to the host
         // already -- a peek, no wait; the harvest proper comes when the ring wraps, 32 frames on -- and the frames of this
         // path carry the redo launches from here on, not from 32 lost frames later.
         for (int q = 0; q < EV_RING; ++q) {
             if (!c->ring[q].used || q == r) continue;
             const volatile FrameStatus* hs = &c->h_status[q];
-            if (hs->overflow == 2u || hs->redone == 1u) { c->redo_armed = 256; break; }
+            if (hs->overflow == 2u || hs->redone == 1u) { c->redo_armed = 256; c->count_first_left = 64; break; }
         }
     }
     // (adaptive: while a list has outgrown its region lately -- or on the frame of a camera JUMP, whose lists have nothing to do with
@@ -778,7 +829,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         if (awaited) grid = c->sort_hint ? std::max<unsigned int>(grid, c->hint_ge2048 + c->hint_ge2048 / 8u + 16u) : m;
         launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m,
                       (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows, c->one_pass_select ? c->need_hint + 4u * (size_t)c->m_alloc : nullptr,
-                      std::min(grid, m), c->fc.start_hints == 1, off2);
+                      std::min(grid, m), c->fc.start_hints == 1, off2, c->hint_radius);
     }
     else if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max, off2);
@@ -1140,6 +1191,7 @@ bool store_option(splat_ctx* c, int opt, double v, bool dry = false) {
         case SPLAT_OPT_OVERFLOW_REDO: if (v != 0.0 && v != 1.0 && v != 2.0) return false; SPLAT_DRY_; c->overflow_redo = (int)v; return true;
         case SPLAT_OPT_START_HINTS: if (v != 0.0 && v != 1.0 && v != 2.0) return false; SPLAT_DRY_; c->start_hints = (int)v; return true;
         case SPLAT_OPT_HOST_ZERO_COPY: if (v != 0.0 && v != 1.0) return false; SPLAT_DRY_; c->host_zero_copy = (int)v; return true;
+        case SPLAT_OPT_COUNT_FIRST: if (v != 0.0 && v != 1.0 && v != 2.0) return false; SPLAT_DRY_; c->count_first = (int)v; return true;
         case SPLAT_OPT_KEYS_PER_GAUSSIAN: if (v != 0.0 && (v < 4.0 || v > 256.0)) return false; SPLAT_DRY_; c->keys_per_gaussian = (unsigned int)v; return true;
         default: return false;
     }
@@ -1167,6 +1219,7 @@ bool load_option(const splat_ctx* c, int opt, double* v) {
         case SPLAT_OPT_START_HINTS: *v = c->start_hints; return true;
         case SPLAT_OPT_HOST_ZERO_COPY: *v = c->host_zero_copy; return true;
         case SPLAT_OPT_KEYS_PER_GAUSSIAN: *v = c->keys_per_gaussian; return true;
+        case SPLAT_OPT_COUNT_FIRST: *v = c->count_first; return true;
         default: return false;
     }
 }
@@ -1247,6 +1300,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         c->env_pinned |= 1u << SPLAT_OPT_NEAR_SELECT_KEYS;
     }
     option_from_env(c, SPLAT_OPT_HOST_ZERO_COPY, "SPLAT_HOST_ZERO_COPY", 0, 1);
+    option_from_env(c, SPLAT_OPT_COUNT_FIRST, "SPLAT_COUNT_FIRST", 0, 2);
     if (const char* kg = std::getenv("SPLAT_KEYS_PER_GAUSSIAN")) {
         const int v = std::atoi(kg);
         c->keys_per_gaussian = v <= 0 ? 0u : (unsigned int)std::min(256, std::max(4, v));
@@ -1258,6 +1312,8 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* k8 = std::getenv("SPLAT_DBG_SELECT_STRIDE")) c->knobs.dbg_select_stride = (unsigned int)std::max(0, std::atoi(k8));
     if (const char* k10 = std::getenv("SPLAT_START_HINTS")) { c->start_hints = std::min(2, std::max(0, std::atoi(k10))); c->env_pinned |= 1u << SPLAT_OPT_START_HINTS; }
     if (const char* k7 = std::getenv("SPLAT_DBG_ONE_PASS_SELECT")) c->one_pass_select = std::atoi(k7) != 0;
+    if (const char* k11 = std::getenv("SPLAT_DBG_KEYS2_ENTRIES")) c->knobs.dbg_keys2_entries = std::strtoull(k11, nullptr, 10);
+    if (const char* k9 = std::getenv("SPLAT_DBG_HINT_RADIUS")) c->knobs.dbg_hint_radius = std::atoi(k9);
     if (const char* k5 = std::getenv("SPLAT_DBG_STARTS")) c->knobs.dbg_starts = std::atoi(k5) != 0 ? 1u : 0u;
     if (const char* k4 = std::getenv("SPLAT_COMP_LDS_PAD")) c->knobs.comp_lds_pad = (unsigned int)std::max(0, std::atoi(k4));
     auto bail = [&](const char* what, hipError_t err) {
@@ -1423,9 +1479,6 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     UP_TRY(dmalloc(c, &c->orig, sizeof(unsigned int) * n));
     for (Slot& s : c->slots) {
         UP_TRY(dmalloc(c, &s.recs, sizeof(Rec) * n));
-        UP_TRY(dmalloc(c, &s.depth, sizeof(float) * n));
-        UP_TRY(dmalloc(c, &s.rect, sizeof(ushort4) * n));
-        UP_TRY(dmalloc(c, &s.vislist, sizeof(unsigned int) * n));
         UP_TRY(dmalloc(c, &s.blockinfo, sizeof(unsigned int) * ((n + 255) / 256)));
         UP_TRY(hipMemsetAsync(s.blockinfo, 0, sizeof(unsigned int) * ((n + 255) / 256), c->stream));
     }
@@ -1519,6 +1572,8 @@ int splat_tile_row_loads(splat_ctx* c, const splat_camera* cam, uint64_t* row_pa
     rc = ensure_bins(c, nt);
     if (rc != SPLAT_OK) return rc;
     Slot& s = c->slots[0];
+    rc = ensure_two_pass_buffers(c, s);
+    if (rc != SPLAT_OK) return rc;
     fc.bucket_cap = 0;          // count only
     HIP_TRY(c, hipMemsetAsync(s.counts, 0, sizeof(unsigned int) * ((size_t)nt + 1), c->stream));   // (one-pass frames leave cursors there)
     s.layout_valid = false; s.flip = 0;                                                          // ... and will find them gone
@@ -1840,6 +1895,8 @@ int splat_get_records(splat_ctx* c, splat_record* out, uint64_t n) {
     int rc = splat_sync(c);
     if (rc != SPLAT_OK) return rc;
     if (c->last_slot < 0) return fail(c, SPLAT_ERR_INVALID, "no frame rendered yet");
+    rc = ensure_two_pass_buffers(c, c->slots[c->last_slot]);
+    if (rc != SPLAT_OK) return rc;
     const Slot& s = c->slots[c->last_slot];
     // The 48-byte records are the ones the frame itself was composited from (written by whichever flavour of K1
     // rendered it -- preprocess_kernel<true> on the default one-pass path); they are read FIRST.

@@ -88,6 +88,8 @@ struct LaunchKnobs {
     unsigned int dbg_ntiles = 0;           // != 0: composite only the N longest tiles
     unsigned int comp_lds_pad = 0;         // extra dynamic LDS per compositor workgroup (an occupancy cap)
     unsigned int dbg_select_stride = 0;    // SPLAT_DBG_SELECT_STRIDE: slots of the tile order per workgroup of the near selection's launch (default 8)
+    unsigned long long dbg_keys2_entries = 0; // SPLAT_DBG_KEYS2_ENTRIES: initial size of a frame slot's second key buffer (tests force its growth)
+    int dbg_hint_radius = -1;              // SPLAT_DBG_HINT_RADIUS: the near selection's neighbourhood, in tiles (default: by the camera's motion)
     unsigned int dbg_starts = 0;           // SPLAT_DBG_STARTS: statistics frames record (list length, nearest keys the walk needed) per wave
 };
 void use_launch_knobs(const LaunchKnobs* k);
@@ -101,7 +103,9 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
                        unsigned int* blockinfo /* per block: bit 31 = skipped by culling; one-pass binning: visible | singular << 9 */,
                        FrameStatus* status,
                        const unsigned int* layout = nullptr /* one-pass binning (fc.bucket_cap != 0): counts[t] is the cursor of tile t's
-                                                               region keys[layout[t] .. layout[t+1]); nullptr: two-pass counting */);
+                                                               region keys[layout[t] .. layout[t+1]); nullptr: two-pass counting */,
+                       bool count_only = false /* one-pass binning's COUNT flavour: counts[t] += the tile's pairs and nothing else (no SH,
+                                                  no record, no key) -- the pass in front of a layout that fits exactly this camera */);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
@@ -138,7 +142,8 @@ void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offs
                    unsigned int* near_thr = nullptr /* one word per tile, kept from frame to frame: the depth its last selection began at */,
                    unsigned int grid = 0 /* workgroups (each strides over the tile order); 0 = an eighth of the tiles */,
                    bool at_rest = false /* the camera of the last frames: selections sized tightly */,
-                   const unsigned int* off2 = nullptr /* see launch_sort */);
+                   const unsigned int* off2 = nullptr /* see launch_sort */,
+                   int hint_radius = 2 /* a tile's selection is sized from its own walks' need and its neighbours' within this many tiles */);
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,
                       uint32_t* argb, FrameStatus* status, const unsigned int* orig, unsigned int fused_sort_max = 0,

@@ -579,6 +579,31 @@ struct BucketBinner {
 
         }
     }
+    // COUNT flavour of K1 (no keys, no records: the pairs per tile and nothing else): the block's counts go out as plain
+    // (non-returning) atomics, the pairs the table does not hold one atomic each.  Ends the block's work.
+    __device__ __forceinline__ void count_only() {
+        const unsigned int tid = threadIdx.x;
+        __syncthreads();
+        bx0 = sh.box[0]; by0 = sh.box[1];
+        any = sh.box[2] >= 0;
+        hashed = any && (sh.box[2] - bx0) < HASH_DIM && (sh.box[3] - by0) < HASH_DIM;
+        if (hashed) {
+#pragma unroll
+            for (int q = 0; q < NRES; ++q) {
+                const int e = (int)tid + 256 * q;
+                const unsigned int cnt = sh.table[e];
+                const int ty = by0 + (((e >> HASH_BITS) - by0) & (HASH_DIM - 1));
+                const int tx = bx0 + (((e & (HASH_DIM - 1)) - 17 * ty - bx0) & (HASH_DIM - 1));
+                if (cnt) (void)__hip_atomic_fetch_add(gcount + (unsigned int)(ty * tiles_x + tx), cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (any) {
+            each_tile(small, 0ull, [&](int tx, int ty, unsigned long long) { (void)__hip_atomic_fetch_add(gcount + (unsigned int)(ty * tiles_x + tx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+        }
+        if (__syncthreads_or(big ? 1 : 0) == 0) return;
+        if (big) add_big(sh, tx0, tx1, ty0, ty1, 0ull);
+        __syncthreads();
+        expand_big(sh, tiles_x, [&](unsigned int tile, unsigned long long) { (void)__hip_atomic_fetch_add(gcount + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+    }
     // place() in two steps, so that the caller can put its record store between them: publish() waits for the
     // reservations (issued before the SH planes' loads, so they have arrived when those have) and hands them to the
     // block through the table; a store issued BEFORE that wait would have to complete first (gfx9 counts loads,
@@ -677,11 +702,12 @@ __device__ __forceinline__ bool block_may_reach_slab(const BlockBounds& bb, cons
 // CORRECTED = SPLAT_MODE_CORRECTED_PROJECTION, a compile-time flavour: in the reference's projection the clamped tx/ty
 // and the Jacobian's shear entries only reach the discarded third column of cov (src/gaussians.rs:133-151), so the
 // compiler drops them -- two divisions, the clamps and a third of the products -- when it can see that.
-#ifndef SPLAT_K1_WAVES
-#define SPLAT_K1_WAVES 1         // (A/B: 8 = at most 64 VGPRs, eight blocks per CU instead of seven)
-#endif
-template <bool BUCKET, bool CORRECTED = false>
-__global__ __launch_bounds__(256, SPLAT_K1_WAVES) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes,
+// (Eight blocks per CU instead of seven -- __launch_bounds__(256, 8): 64 VGPRs, five of them spilled -- measured in round 6:
+// K1 alone 0.146 -> 0.160 ms, the frame 3175 -> 3090 frames/s.  Not taken.)
+// COUNT (with BUCKET): the pairs per tile and nothing else -- geometry planes only, no SH, no record, no key: what a frame
+// needs to build regions that fit exactly ITS camera before it bins (enqueue_frame: count-first frames, the bootstrap).
+template <bool BUCKET, bool CORRECTED = false, bool COUNT = false>
+__global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float4* __restrict__ planes,
                                                          const unsigned int* __restrict__ orig, FrameConst fc,
                                                          Rec* __restrict__ recs, float* __restrict__ depth,
                                                          ushort4* __restrict__ rect, unsigned int* __restrict__ counts,
@@ -823,6 +849,12 @@ __global__ __launch_bounds__(256, SPLAT_K1_WAVES) void preprocess_kernel(uint64_
     // and the whole rest of the block used to wait that out.  In this order the reservations are in flight under
     // the SH arithmetic instead.
     Rec r;
+    if constexpr (COUNT) {
+        static_assert(BUCKET || !COUNT, "the count flavour belongs to one-pass binning");
+        binner.count(in_slab, singular, tx0, tx1, ty0, ty1);
+        binner.count_only();
+        return;
+    }
     if (in_slab) {
 #pragma unroll
         for (int p = 4; p < LIVE_PLANES; ++p) {
@@ -2788,11 +2820,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         // kernel needed scratch and half its uniform values spilled -- the hot path paid 4.4 % for a path a frame at rest never
         // takes (profiles/r06_repair_ab.txt).
         const bool again = walk_list();
-#if SPLAT_AB == 3
-        if (false) {
-#else
         if (has_far && __syncthreads_or(again ? 1 : 0) != 0) {                // (has_far is uniform in the workgroup: the tile's near_m)
-#endif
             if (tid == 0u) atomicAdd(&status->n_near_fallback, 1u);
             repair_tile<PAIR, LIBM>(ka, (unsigned int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem,
                                     (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned long long*)exptab, item, again);
@@ -2836,16 +2864,14 @@ static __device__ __attribute__((noinline)) void repair_tile(KernArgs ka, unsign
 //   selection would be most of the list anyway, is sorted in full, in its region, as a sort launch would leave it.
 // near_m[tile] = how many of the nearest keys are in order (== the list's length: all of them).  A wrong guess costs time
 // only -- a larger sort than necessary, or a tile that sorts its whole list inside the compositor after all -- never a pixel.
-#ifndef SPLAT_HINT_RADIUS
-#define SPLAT_HINT_RADIUS 2
-#endif
 __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __restrict__ offsets, const unsigned int* __restrict__ order,
                                                           const unsigned int* __restrict__ lens, unsigned long long* __restrict__ keys,
                                                           unsigned long long* __restrict__ keys2, FrameStatus* __restrict__ status,
                                                           const unsigned int* __restrict__ orig, unsigned int radix_min, unsigned int near_cap,
                                                           const unsigned int* __restrict__ need_hint, unsigned int* __restrict__ near_m,
                                                           unsigned int tiles_x, unsigned int tile_rows, unsigned int* __restrict__ near_thr,
-                                                          unsigned int n_slots, unsigned int at_rest, const unsigned int* __restrict__ off2) {
+                                                          unsigned int n_slots, unsigned int at_rest, const unsigned int* __restrict__ off2,
+                                                          int hint_radius) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
     if (status->overflow) return;
     // (an eighth as many workgroups as tiles, each taking the slots blockIdx.x, + gridDim.x, ... of the longest-first order until it
@@ -2869,25 +2895,26 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
         if (threadIdx.x < 64u) {
             const uint4 h4 = reinterpret_cast<const uint4*>(need_hint)[tile];
             unsigned int d0 = max(max(h4.x, h4.y), max(h4.z, h4.w));
-#if SPLAT_HINT_RADIUS > 0
             // ... and the tiles around it (a camera in motion carries a deep spot of the image from tile to tile: what the
-            // neighbours' walks needed last frame is what this tile's may need now).  A neighbour that ran out (~0) says nothing.
-            {
-                constexpr int D = 2 * SPLAT_HINT_RADIUS + 1;
-                const int lane = (int)threadIdx.x;
-                const int tx = (int)(tile % tiles_x) + lane % D - SPLAT_HINT_RADIUS, ty = (int)(tile / tiles_x) + lane / D - SPLAT_HINT_RADIUS;
+            // neighbours' walks needed last frame is what this tile's may need now), as far around as the camera moved since:
+            // hint_radius tiles, 2 for a camera at rest or creeping, up to 7 for a 10-degree step.  A neighbour that ran out (~0)
+            // says nothing.
+            if (hint_radius > 0) {
+                const int D = 2 * hint_radius + 1;
                 unsigned int nb = 0u;
-                if (lane < D * D && tx >= 0 && ty >= 0 && tx < (int)tiles_x && ty < (int)tile_rows) {
-                    const uint4 q = reinterpret_cast<const uint4*>(need_hint)[(unsigned int)ty * tiles_x + (unsigned int)tx];
-                    const unsigned int a = q.x == 0xffffffffu ? 0u : q.x, b = q.y == 0xffffffffu ? 0u : q.y;
-                    const unsigned int cc = q.z == 0xffffffffu ? 0u : q.z, d = q.w == 0xffffffffu ? 0u : q.w;
-                    nb = max(max(a, b), max(cc, d));
+                for (int idx = (int)threadIdx.x; idx < D * D; idx += 64) {
+                    const int tx = (int)(tile % tiles_x) + idx % D - hint_radius, ty = (int)(tile / tiles_x) + idx / D - hint_radius;
+                    if (tx >= 0 && ty >= 0 && tx < (int)tiles_x && ty < (int)tile_rows) {
+                        const uint4 q = reinterpret_cast<const uint4*>(need_hint)[(unsigned int)ty * tiles_x + (unsigned int)tx];
+                        const unsigned int a = q.x == 0xffffffffu ? 0u : q.x, b = q.y == 0xffffffffu ? 0u : q.y;
+                        const unsigned int cc = q.z == 0xffffffffu ? 0u : q.z, d = q.w == 0xffffffffu ? 0u : q.w;
+                        nb = max(nb, max(max(a, b), max(cc, d)));
+                    }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) nb = max(nb, (unsigned int)__shfl_xor((int)nb, o));
                 d0 = max(d0, nb);           // (~0 stays ~0)
             }
-#endif
             if (threadIdx.x == 0u) { word[0] = d0; word[1] = near_thr != nullptr ? near_thr[tile] : 0u; }
         }
         __syncthreads();
@@ -2953,9 +2980,6 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
 // (At most 96 SGPRs: with 97-112 a CU admits six 256-thread workgroups instead of seven -- MI355X_MICROARCH.md,
 // "Residency" -- and the compositor hides its LDS and dependency latency with residency.  The near-selection flavour
 // carries a few more uniform values than the others and would take 106.)
-#ifndef SPLAT_AB
-#define SPLAT_AB 0
-#endif
 template <bool PAIR, bool LIBM, int LONGM>
 __global__ __launch_bounds__(256, (LONGM != 0 && !PAIR) ? 7 : SPLAT_COMP_WAVES) __attribute__((amdgpu_num_sgpr(96))) void composite_exact_kernel(CompArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sort_lds_bytes<256, 2048>()];
@@ -3002,19 +3026,17 @@ void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* 
 }
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
                        float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
-                       const BlockBounds* bounds, unsigned int* blockinfo, FrameStatus* status, const unsigned int* layout) {
+                       const BlockBounds* bounds, unsigned int* blockinfo, FrameStatus* status, const unsigned int* layout, bool count_only) {
     if (!n) return;
     if (!bounds || !blockinfo) fc.cull_blocks = 0;
     if (!blockinfo || !layout) fc.bucket_cap = 0;
     const dim3 grid(blocks_for(n, 256)), block(256);
-    if (fc.bucket_cap && fc.corrected)
-        hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
-    else if (fc.bucket_cap)
-        hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
-    else if (fc.corrected)
-        hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
-    else
-        hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status); };
+    if (fc.bucket_cap && count_only) { if (fc.corrected) go(preprocess_kernel<true, true, true>); else go(preprocess_kernel<true, false, true>); }
+    else if (fc.bucket_cap && fc.corrected) go(preprocess_kernel<true, true>);
+    else if (fc.bucket_cap) go(preprocess_kernel<true, false>);
+    else if (fc.corrected) go(preprocess_kernel<false, true>);
+    else go(preprocess_kernel<false, false>);
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
@@ -3081,13 +3103,14 @@ void launch_sort(hipStream_t s, unsigned int n_tiles, unsigned int grid_big, uns
 void launch_select(hipStream_t s, unsigned int n_tiles, const unsigned int* offsets, const unsigned int* order, const unsigned int* lens,
                    unsigned long long* keys, unsigned long long* keys2, FrameStatus* status, const unsigned int* orig, unsigned int near_cap,
                    const unsigned int* need_hint, unsigned int* near_m, unsigned int tiles_x, unsigned int tile_rows, unsigned int* near_thr, unsigned int grid, bool at_rest,
-                   const unsigned int* off2) {
+                   const unsigned int* off2, int hint_radius) {
     if (!n_tiles) return;
     if (!off2) off2 = offsets;
+    if (g_knobs->dbg_hint_radius >= 0) hint_radius = g_knobs->dbg_hint_radius;
     if (g_knobs->dbg_select_stride) grid = (n_tiles + g_knobs->dbg_select_stride - 1u) / g_knobs->dbg_select_stride;
     if (!grid) grid = (n_tiles + 7u) / 8u;
     hipLaunchKernelGGL(select_near_kernel, dim3(std::min(grid, n_tiles)), dim3(256), 0, s, offsets, order, lens, keys, keys2, status, orig, sort_radix_min(),
-                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr, n_tiles, at_rest ? 1u : 0u, off2);
+                       std::min(std::max(near_cap, 64u), 2048u), need_hint, near_m, tiles_x, tile_rows, near_thr, n_tiles, at_rest ? 1u : 0u, off2, std::min(std::max(hint_radius, 0), 7));
 }
 void launch_composite(hipStream_t s, unsigned int n_tiles, FrameConst fc, const unsigned int* offsets,
                       const unsigned int* order, const unsigned int* lens, unsigned long long* keys, const Rec* recs,

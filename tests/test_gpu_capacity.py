@@ -252,6 +252,62 @@ def test_fuzzed_pose_sequences_through_the_frame_pipeline():
     assert "15 cases, 0 failures" in r.stdout
 
 
+def test_long_lists_that_outgrow_the_second_key_buffer_grow_it(monkeypatch):
+    """The second key buffer of a frame slot holds room for the lists of more than 2048 keys only (their sorted near selection,
+    the scatter space of their full sorts), handed out by the frame's scan.  A frame whose long lists ask for more than the
+    buffer has is flagged by that scan (overflow 4), skipped, and the buffer grown: a synchronous frame is redone inside its
+    call, an asynchronous one is reported once by splat_sync and is right when rendered again."""
+    monkeypatch.setenv("SPLAT_DBG_KEYS2_ENTRIES", "4096")
+    r = splat_amd.Renderer()
+    try:
+        g = splat_amd.synthetic_scene(120000, 72)
+        g.compute_cov3d(r)
+        r.upload(g)
+        far = make_camera(256, 256, (0.0, 0.0, 30.0))      # the whole cloud on a few tiles: tens of thousands of keys each
+        ref, ost = oracle_frame(g, far)
+        d0 = r.frames_dropped()
+        img = np.zeros((256, 256), np.uint32)
+        st = r.render(far.to_c(0.01), img)
+        assert st.max_tile_len > 2048 and st.n_pairs == ost.n_tile_pairs
+        assert r.frames_dropped() > d0, "the 4096-entry buffer was expected to be outgrown"
+        assert image_diff(img, ref)[0] <= 1
+        # the buffer has grown: frames of this pose fit from now on, asynchronous ones included
+        d1 = r.frames_dropped()
+        dimg = r.device_image(np.zeros((256, 256), np.uint32))
+        for _ in range(6):
+            r.render_frame_device(far.to_c(0.01), dimg)
+        r.sync()
+        assert r.frames_dropped() == d1
+        assert np.array_equal(r.device_download(dimg, 256, 256), img)
+        r.device_free(dimg)
+    finally:
+        r.close()
+    # ... and an ASYNCHRONOUS frame that outgrows it is skipped, reported once, and right when rendered again
+    r = splat_amd.Renderer()
+    try:
+        r.upload(g)
+        away = make_camera(256, 256, (0.0, 0.0, 5.0), yaw=np.pi)     # the cloud behind the camera: no list at all, nothing asked of the buffer
+        warm = np.zeros((256, 256), np.uint32)
+        for _ in range(6):
+            st = r.render(away.to_c(0.01), warm)
+        assert st.max_tile_len <= 2048
+        garbage = np.full((256, 256), 0x12345678, np.uint32)
+        dimg = r.device_image(garbage)
+        d0 = r.frames_dropped()
+        r.render_frame_device(far.to_c(0.01), dimg)
+        with pytest.raises(SplatError) as e:
+            r.sync()
+        assert e.value.code == _lib.ERR_CAPACITY
+        assert r.frames_dropped() == d0 + 1
+        assert np.array_equal(r.device_download(dimg, 256, 256), garbage)      # skipped: untouched
+        r.sync()                                                                # reported once
+        r.render_frame_device(far.to_c(0.01), dimg, sync=True)
+        assert np.array_equal(r.device_download(dimg, 256, 256), img)
+        r.device_free(dimg)
+    finally:
+        r.close()
+
+
 def test_frames_do_not_depend_on_the_schedule():
     """tools/fuzz_async.py --determinism: every fuzzed pose sequence is rendered by three processes -- the default frame
     pipeline (two binning chains + a compositor in flight), SPLAT_PIPELINE=1 (one stream) and AMD_SERIALIZE_KERNEL=3 (the

@@ -3,7 +3,7 @@
 frames of a yaw orbit at `step` degrees a frame.  usage: motion_trace.py [workload] [step_deg] [frames] [near_cap]"""
 import math, sys, time
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, splat_amd
 from splat_amd import _lib as L
 from bench import WORKLOADS, make_scene

@@ -2,7 +2,7 @@
 read the sort's HIP-event time.  (python tools/sort_latency.py)"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import splat_amd
 from splat_amd.camera import Camera
 
