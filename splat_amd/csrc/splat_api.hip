@@ -195,7 +195,9 @@ struct splat_ctx {
     int count_first = 1;                   // SPLAT_OPT_COUNT_FIRST: 0 only slots without a layout; 1 + the frames behind one that was binned twice, and behind
                                            // a camera jump; 2 + every frame whose camera moved by more than half a degree
     float cam_delta = 0.0f;                // how far the camera moved since the last frame (largest relative change of a view / projection entry)
-    int count_first_left = 0;              // moving frames left that count their pairs first (enqueue_frame): set when a frame was binned twice
+    int count_first_left = 0;              // moving frames left that count their pairs first (enqueue_frame): set when half the recent moving frames were binned twice
+    unsigned char ring_kind[EV_RING] = {}; // per event-ring entry, how its frame was binned: 1 = into regions sized for another camera (it may have been
+                                           // binned twice: its status says), 2 = it counted first, 0 = neither (same camera, two-pass)
     int hint_radius = 2;                   // tiles around a tile whose walks' needs size its near selection (by the camera's motion: enqueue_frame)
     int start_hints = 2;                   // SPLAT_OPT_START_HINTS / SPLAT_START_HINTS: 0 the compositor scans for its walks' starts on every frame; 1 not with
                                            // a camera at rest; 2 nor, three frames of four, with one in slow motion (see enqueue_frame)
@@ -377,7 +379,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow) c->frames_dropped++;
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) c->bucket_overflow = true;           // a tile's list outgrew its region: the layouts are stale
-    if (st.overflow == 2 || st.redone == 1u) { c->redo_armed = 256; c->count_first_left = 64; }  // ... or did and was binned again on the device: keep the redo launches on
+    if (st.overflow == 2 || st.redone == 1u) c->redo_armed = 256;  // ... or did and was binned again on the device: keep the redo launches on
     if (st.layout_total > c->cap) c->layout_want = std::max<uint64_t>(c->layout_want, st.layout_total);   // the regions were cut off
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 4) c->keys2_want = std::max<uint64_t>(c->keys2_want, st.n_long_keys);
@@ -639,6 +641,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     c->ring_next = (c->ring_next + 1) % EV_RING;
     harvest(c, r);
     std::memset(&c->h_status[r], 0, sizeof(FrameStatus));      // (this frame's scan fills it; until then it says nothing: see the peek below)
+    c->ring_kind[r] = 0;
     const int si = (int)(c->frame_idx++ % (uint64_t)slots_in_use(c));
     Slot& s = c->slots[si];
     FrameStatus* const d_st = c->d_status_ring + r;       // (initialised by this frame's scan)
@@ -720,19 +723,22 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     if (c->fc.bucket_cap) {
         // COUNT FIRST: the frame counts its pairs per tile (K1's count flavour: geometry planes only, no SH, no record, no key --
         // a third of a K1) and bins into regions that fit exactly ITS camera.  A slot without a layout does (first frames, a
-        // new scene / target / slab, after a frame outgrew the key buffer); so do the frames behind a camera JUMP (the jump's
-        // own and the eight behind it: the slots' regions are sized two frames ahead, from lists of before the jump); and,
-        // by SPLAT_OPT_COUNT_FIRST, either every frame whose camera moved by more than half a degree (2), or (1) the 64
-        // moving frames behind one that outgrew regions sized two frames back and was binned twice (the overflow redo: a K1,
-        // then another K1 -- 0.15 + 0.15 ms of binning where the frame that counts first pays 0.06 + 0.15), after which one
-        // tries its luck again.  (A host that runs 30 frames ahead of the device learns of a frame binned twice 30 frames
-        // late: hence 64, not 8.)
-        if (c->cam_jumped && c->count_first != 0) c->count_first_left = std::max(c->count_first_left, 9);
+        // new scene / target / slab, after a frame outgrew the key buffer); and, by SPLAT_OPT_COUNT_FIRST, (1, the default) the
+        // 64 moving frames behind one that outgrew regions sized two frames back and was binned twice (the overflow redo: a
+        // K1, then another K1 -- 0.15 + 0.15 ms of binning where the frame that counts first pays 0.06 + 0.15), after which
+        // one tries its luck again; or (2) every frame whose camera moved by more than half a degree.  (A host that runs 30
+        // frames ahead of the device learns of a frame binned twice 30 frames late: hence 64, not 8.)
+        // Measured (profiles/r06_count_first.txt): on the surface scene in motion the frames that count first are what lets a
+        // 32 N key buffer keep the rate of a 64 N one; on C3, whose lists never outgrow regions sized two frames back, counting
+        // first on every moving frame costs 13 % (orbit 2785 -> 2417) -- hence by evidence of a frame binned twice, not by
+        // motion alone; and the frames of a camera JUMP carry the redo launches (below) rather than counting first: on C3's
+        // uncorrelated poses the optimistic frame fits, and counting first would cost it 16 %.
         bool count_first = !s.layout_valid;
         if (!count_first && s.layout_cam[s.flip] != cam_hash && c->count_first != 0) {
             if (c->count_first >= 2 && c->cam_delta >= 0.009f) count_first = true;
             else if (c->count_first_left > 0) { count_first = true; --c->count_first_left; }
         }
+        if (count_first) c->ring_kind[r] = 2;
         if (count_first) {
             const int into = s.layout_valid ? s.flip : 1;
             HIP_TRY(c, hipMemsetAsync(s.redo_cursors, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));     // (the redo's buffer: a count-first frame has no redo)
@@ -784,9 +790,26 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         for (int q = 0; q < EV_RING; ++q) {
             if (!c->ring[q].used || q == r) continue;
             const volatile FrameStatus* hs = &c->h_status[q];
-            if (hs->overflow == 2u || hs->redone == 1u) { c->redo_armed = 256; c->count_first_left = 64; break; }
+            if (hs->overflow == 2u || hs->redone == 1u) { c->redo_armed = 256; break; }
+        }
+        // ... and whether counting first pays on this path: of the frames binned into another camera's regions whose status has
+        // arrived (in flight or harvested: a ring entry keeps both until it is used again), were three in four binned twice?
+        // A frame binned twice costs two K1s, one that counts first 1.4 alone on the chip and more beside another chain's K1:
+        // with half of them binned twice the optimistic frames still won (C3's uncorrelated poses, +10 %).  (One frame
+        // binned twice used to arm this: on C3's uncorrelated poses, where one frame in a few outgrows its regions, the 64
+        // count-first frames behind it cost 11 % -- profiles/r06_knob_matrix.json of that build, C3/random.)
+        if (c->count_first_left == 0) {
+            int known = 0, twice = 0;
+            for (int q = 0; q < EV_RING; ++q) {
+                if (q == r || c->ring_kind[q] != 1) continue;
+                const volatile FrameStatus* hs = &c->h_status[q];
+                if (!hs->arrived) continue;
+                ++known; twice += (hs->overflow == 2u || hs->redone == 1u) ? 1 : 0;
+            }
+            if (known >= 2 && 4 * twice >= 3 * known) c->count_first_left = 64;
         }
     }
+    if (c->fc.bucket_cap && moved) c->ring_kind[r] = 1;
     // (adaptive: while a list has outgrown its region lately -- or on the frame of a camera JUMP, whose lists have nothing to do with
     // the ones its regions were sized from: the first such frame used to be the one that was skipped and armed the rest)
     // (... and the frames right behind it: the slots' regions are sized two frames ahead, from lists of before the jump)

@@ -67,7 +67,8 @@ struct FrameStatus {
     unsigned int n_ge8192, n_ge2048;    // tiles whose list has >= 8192 / >= 2048 keys: in `order` they are a prefix
     unsigned int n_ge16384;             // likewise >= 16384 (the lists sorted as several runs and merged)
     unsigned int redone;                // 1: the frame outgrew its regions and was binned again on the device (overflow redo); written by every scan
-    unsigned int n_long_keys, pad2_;    // one-pass binning: entries of the second key buffer the frame's lists of more than 2048 keys ask for
+    unsigned int n_long_keys;           // one-pass binning: entries of the second key buffer the frame's lists of more than 2048 keys ask for
+    unsigned int arrived;               // 1: the frame's scan has written this status (the host zeroes its copy when it enqueues the frame)
     unsigned long long n_blocks_culled; // K1 blocks skipped by the bounds test (filled on the host from the block flags)
     unsigned long long layout_total;    // one-pass binning: key-buffer entries the regions built from this frame ask for (layout_kernel)
 };

@@ -1050,6 +1050,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid || ge16384 > grid_long)) status->overflow = 3u;
         status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
         status->redone = 0u;                          // (the ring entry may have carried a redone one-pass frame before)
+        status->arrived = 1u;
         if (host_status) *host_status = *status;      // (n_visible / n_singular: K1's atomics, complete before this kernel)
     }
     __syncthreads();   // lens[] written above by this workgroup are visible to it
@@ -1238,11 +1239,24 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                 c[u] = raw;
                 lens[k] = len;
                 offsets[k] = l0[u];
-                if (off2 != nullptr) off2[k] = len > 2048u ? atomicAdd(&pool2, (len + 63u) & ~63u) : 0u;
                 sum += c[u]; mx = max(mx, c[u]);
                 const unsigned int cls = cls_of(len);
                 if (cls_in_lds) cls_lds[k] = (unsigned char)cls;
                 atomicAdd(&row[wave][cls], 1u);
+            }
+            // the long lists' room in the second key buffer, a wave's tiles at a time: one atomic on the counter per wave and
+            // step (every lane on it, one after the other, was 9 us of this 28-us kernel)
+            if (off2 != nullptr) {
+                const unsigned int len = (k < m) ? min(c[u], l1[u] - l0[u]) : 0u;
+                const unsigned int want = len > 2048u ? (len + 63u) & ~63u : 0u;
+                const unsigned int inc = wave_inclusive_sum(want);
+                const unsigned int total = (unsigned int)wave_last((int)inc);
+                unsigned int room = 0u;
+                if (total != 0u) {
+                    if (lane == 63u) room = atomicAdd(&pool2, total);
+                    room = (unsigned int)wave_last((int)room);
+                }
+                if (k < m) off2[k] = want ? room + inc - want : 0u;
             }
         }
     }
@@ -1279,6 +1293,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         status->n_ge16384 = ge[0]; status->n_ge8192 = ge[1]; status->n_ge2048 = ge[2];
         status->overflow = (mx & 0x80000000u) ? 2u : ((ge[1] > grid_big || ge[2] > grid_mid || ge[0] > grid_long) ? 3u : 0u);
         status->n_long_keys = pool2;            // (complete: the barriers above)
+        status->arrived = 1u;
         if (off2 != nullptr && pool2 > cap2 && status->overflow == 0u) status->overflow = 4u;
         // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
         status->n_visible = 0; status->n_singular = 0;

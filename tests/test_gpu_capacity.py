@@ -38,6 +38,7 @@ def scene_and_poses():
     # (the device-side redo of such frames -- SPLAT_OPT_OVERFLOW_REDO, on by default -- is switched off here: these tests are
     # about what happens when a frame IS skipped; test_overflowing_async_frame_is_binned_again_on_the_device has it on)
     r.set_option(_lib.OPT_OVERFLOW_REDO, 0)
+    r.set_option(_lib.OPT_COUNT_FIRST, 0)          # (... and no frame counts its pairs first: one that does cannot outgrow its regions)
     g = splat_amd.synthetic_scene(120000, 71)
     g.compute_cov3d(r)
     near = make_camera(256, 256, (0.0, 0.0, 5.0))
@@ -285,12 +286,14 @@ def test_long_lists_that_outgrow_the_second_key_buffer_grow_it(monkeypatch):
     # ... and an ASYNCHRONOUS frame that outgrows it is skipped, reported once, and right when rendered again
     r = splat_amd.Renderer()
     try:
-        r.upload(g)
-        away = make_camera(256, 256, (0.0, 0.0, 5.0), yaw=np.pi)     # the cloud behind the camera: no list at all, nothing asked of the buffer
+        small = splat_amd.synthetic_scene(2000, 73)              # no list of more than 2048 keys: nothing asked of the buffer yet
+        small.compute_cov3d(r)
+        r.upload(small)
         warm = np.zeros((256, 256), np.uint32)
-        for _ in range(6):
-            st = r.render(away.to_c(0.01), warm)
+        for _ in range(4):
+            st = r.render(far.to_c(0.01), warm)
         assert st.max_tile_len <= 2048
+        r.upload(g)
         garbage = np.full((256, 256), 0x12345678, np.uint32)
         dimg = r.device_image(garbage)
         d0 = r.frames_dropped()

@@ -69,15 +69,7 @@ def measure(R, poses, img, warm, frames):
     return best, (dropped if best == 0.0 else 0)
 
 
-def main():
-    argv = sys.argv[1:]
-    scenes, motions, frames, out = ["C2", "C3", "C3s", "C5"], list(MOTIONS), 100, None
-    while argv:
-        if argv[0] == "--scenes": scenes = argv[1].split(",")
-        elif argv[0] == "--motions": motions = argv[1].split(",")
-        elif argv[0] == "--frames": frames = int(argv[1])
-        elif argv[0] == "--out": out = argv[1]
-        argv = argv[2:]
+def run(scenes=("C2", "C3", "C3s", "C5"), motions=MOTIONS, frames=100, out=None):
     table = {"what": __doc__.split("usage:")[0].strip(), "frames_per_measurement": frames, "cells": {}}
     worst = (1.0, None)
     for wl in scenes:
@@ -119,4 +111,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    argv = sys.argv[1:]
+    kw = {}
+    while argv:
+        if argv[0] == "--scenes": kw["scenes"] = argv[1].split(",")
+        elif argv[0] == "--motions": kw["motions"] = argv[1].split(",")
+        elif argv[0] == "--frames": kw["frames"] = int(argv[1])
+        elif argv[0] == "--out": kw["out"] = argv[1]
+        argv = argv[2:]
+    run(**kw)
