@@ -198,6 +198,7 @@ struct splat_ctx {
     int count_first_left = 0;              // moving frames left that count their pairs first (enqueue_frame): set when half the recent moving frames were binned twice
     unsigned char ring_kind[EV_RING] = {}; // per event-ring entry, how its frame was binned: 1 = into regions sized for another camera (it may have been
                                            // binned twice: its status says), 2 = it counted first, 0 = neither (same camera, two-pass)
+    bool idle = false;                     // nothing of this context is in flight (set by the waits that drain every stream, cleared by every enqueue)
     int hint_radius = 2;                   // tiles around a tile whose walks' needs size its near selection (by the camera's motion: enqueue_frame)
     int start_hints = 2;                   // SPLAT_OPT_START_HINTS / SPLAT_START_HINTS: 0 the compositor scans for its walks' starts on every frame; 1 not with
                                            // a camera at rest; 2 nor, three frames of four, with one in slow motion (see enqueue_frame)
@@ -657,6 +658,13 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // bound: C3 2241 -> 2334 fps, C1 17.4 k -> 19.2 k, C5 +1 %, C2 -1 %
     if (c->pipeline >= 6 && (c->frame_idx & 1ull)) bs = c->sort_stream;
     hipStream_t ss = c->pipeline == 3 ? c->sort_stream : bs;     // (4, 5: three / four slots on two streams)
+    // A frame the caller waits for, with nothing else in flight (the reference's loop: one synchronous frame per pose,
+    // src/main.rs:69-78), has nothing to overlap with: its whole chain goes on the caller's stream, in order -- no event
+    // recorded on one stream and waited for on another between its binning and its compositor (two barrier packets and a
+    // cross-queue hand-over: ~15 us of a 0.6-ms frame).
+    const bool solo = awaited && c->idle && c->pipeline != 0;
+    if (solo) { bs = c->stream; ss = c->stream; }
+    c->idle = false;
     const unsigned int m = c->n_tiles;
     if (c->pipeline) {
         // order this frame's binning after whatever the caller queued before the call (it may have
@@ -894,7 +902,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     }
     hipStream_t cs = li ? c->comp2 : c->stream;
     if (c->pre_wait) { HIP_TRY(c, hipStreamWaitEvent(cs, c->pre_wait, 0)); c->pre_wait = nullptr; }
-    if (c->pipeline) {
+    if (c->pipeline && ss != cs) {
         HIP_TRY(c, hipEventRecord(s.ev_ready, ss));
         HIP_TRY(c, hipStreamWaitEvent(cs, s.ev_ready, 0));
     }
@@ -947,6 +955,7 @@ int finish_frame(splat_ctx* c, bool* last_skipped = nullptr) {
     if (last_skipped) *last_skipped = false;
     int rc = sync_all(c);
     if (rc != SPLAT_OK) return rc;
+    c->idle = true;                          // every stream of the context has drained
     if (c->last_ring >= 0) c->last = c->h_status[c->last_ring];
     if (last_skipped) *last_skipped = c->last_ring >= 0 && c->last.overflow != 0;
     for (int k = 0; k < EV_RING; ++k) harvest(c, k);
