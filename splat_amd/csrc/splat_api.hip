@@ -232,6 +232,7 @@ struct splat_ctx {
     hipEvent_t pre_wait = nullptr;         // one-shot: the next frame's compositor waits for it (splat_render_stream: its image is still crossing PCIe)
     uint32_t env_pinned = 0;               // bit k: SPLAT_OPT_k was set from the environment at splat_create (splat_set_option leaves it alone)
     int host_zero_copy = 1;                // SPLAT_OPT_HOST_ZERO_COPY: splat_render_frame's compositor stores into a device-addressable host image
+    uint64_t region_mult = 0;              // the key buffer's entries per Gaussian chosen for this scene (0: not yet)
     unsigned int keys_per_gaussian = 0;    // SPLAT_OPT_KEYS_PER_GAUSSIAN: 0 = default_region_capacity decides
     splat::CommState* comm = nullptr;      // multi-GPU: RCCL communicator + partition (splat_multi.hip)
     std::string err;
@@ -540,8 +541,9 @@ uint64_t default_keys2_capacity(const splat_ctx* c) {
     if (c->knobs.dbg_keys2_entries) return c->knobs.dbg_keys2_entries;      // (tests force the growth path)
     return std::max<uint64_t>(1ull << 22, 12 * c->n);
 }
-uint64_t default_region_multiplier(const splat_ctx* c) {
+uint64_t default_region_multiplier(splat_ctx* c) {
     if (c->keys_per_gaussian) return c->keys_per_gaussian;
+    if (c->region_mult) return c->region_mult;             // (decided once per scene: the query below is a driver call)
     const uint64_t per_entry = 8ull * (uint64_t)slots_in_use(c);               // a key buffer in every frame slot
     const uint64_t GiB = 1ull << 30;
     // 32 entries per Gaussian (64 for scenes of up to half a million Gaussians, where it is a gigabyte: their frames are
@@ -557,6 +559,7 @@ uint64_t default_region_multiplier(const splat_ctx* c) {
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b != 0)
         while (mult > 16 && region_capacity_for(c, mult) * per_entry > (uint64_t)free_b / 4u) mult >>= 1;
     else (void)hipGetLastError();
+    c->region_mult = mult;
     return mult;
 }
 
@@ -1533,6 +1536,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
 #undef UP_TRY
     cleanup();
     c->n = n;
+    c->region_mult = 0;
     c->bucket_failed = false;              // key storage is sized at the first frame (prepare_binning)
     for (Slot& sl : c->slots) sl.layout_valid = false;
     c->sort_hint = false;
