@@ -1,16 +1,8 @@
 #!/bin/bash
-# scratch: the command list of the current gpurun call (rewritten per session; results land in gpurun_out/)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r06q; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
-tail -n 3 $O/pytest.log
-for rep in 1 2; do for sp in 0 1; do
-  SPLAT_DBG_SOLO_SPLIT=$sp timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-pmc > $O/b_sp$sp.$rep.json 2> $O/b_sp$sp.$rep.err
-done; done
-timeout 300 python tools/fuzz_parity.py 300 950000 > $O/fuzz.txt 2>&1; tail -n 1 $O/fuzz.txt
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob("gpurun_out/r06q/b_*.json")):
-    d=json.loads(open(f).read().strip().splitlines()[-1]); L=d["extra_legs"]
-    print(f.split('/')[-1], "value %.0f refloop %.0f pageable %.0f literal %.0f frame %.0f render %.0f rand %.0f first %.2f jump %.2f" % (d["value"], L["reference_loop_fps"], L["reference_loop_pageable_image_fps"], L["reference_loop_literal_clear_and_render_to_buffer_fps"], L["host_visible_splat_render_frame_fps"], L["host_visible_splat_render_fps"], L["random_pose_sync_fps"], L["first_frame_ms"], L["pose_jump_ms"]), L["reference_loop_frame_equals_device_frame"])
-PY
+O=gpurun_out/r06s; mkdir -p $O
+for rep in 1 2; do
+  timeout 300 python tools/motion_probe.py --steps 1,3,10 --caps 2048 C3 C3s > $O/base.$rep.txt 2>&1
+  SPLAT_DBG_SELECT_TIGHT=1 timeout 300 python tools/motion_probe.py --steps 1,3,10 --caps 2048 C3 C3s > $O/tight.$rep.txt 2>&1
+done
+for f in base.1 tight.1 base.2 tight.2; do echo $f; grep -h "frames/s" $O/$f.txt | cut -c1-180; done
