@@ -1,8 +1,7 @@
 #!/bin/bash
+# scratch: the command list of the current gpurun call (rewritten per session; results land in gpurun_out/)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r06s; mkdir -p $O
-for rep in 1 2; do
-  timeout 300 python tools/motion_probe.py --steps 1,3,10 --caps 2048 C3 C3s > $O/base.$rep.txt 2>&1
-  SPLAT_DBG_SELECT_TIGHT=1 timeout 300 python tools/motion_probe.py --steps 1,3,10 --caps 2048 C3 C3s > $O/tight.$rep.txt 2>&1
-done
-for f in base.1 tight.1 base.2 tight.2; do echo $f; grep -h "frames/s" $O/$f.txt | cut -c1-180; done
+O=gpurun_out/r06t; mkdir -p $O
+timeout 1500 python tools/parity_sweep.py C5 $O/parity_sweep_C5.json > $O/ps_C5.log 2>&1; tail -n 1 $O/ps_C5.log | cut -c1-300
+timeout 1500 python tools/parity_sweep.py C5 $O/parity_sweep_libm_C5.json libm > $O/psl_C5.log 2>&1; tail -n 1 $O/psl_C5.log | cut -c1-300
+timeout 900 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -n 2 $O/pytest.log
