@@ -280,9 +280,12 @@ int splat_set_frame_overlap(splat_ctx* ctx, int32_t n);
 #define SPLAT_OPT_COUNT_FIRST 21         /* one-pass binning: which frames count their pairs per tile first (K1's count flavour: geometry
                                             only, a third of a K1) and bin into regions that fit exactly their own camera, instead of
                                             into regions sized from the frame two back: 0 = only a frame slot without regions (first
-                                            frames, a new scene / target / slab); 1 = also the frames behind one that outgrew its
-                                            regions and was binned twice, and behind a camera jump; 2 = also every frame whose camera
-                                            moved by more than half a degree (default: see DESIGN.md section 3; SPLAT_COUNT_FIRST)    */
+                                            frames, a new scene / target / slab); 1 (default) = also the next 64 frames of a moving
+                                            camera once three in four of the recent frames binned into another camera's regions
+                                            outgrew them (were binned twice by the overflow redo, or skipped) -- under every
+                                            SPLAT_OPT_OVERFLOW_REDO setting; the frame of a camera jump does NOT count first (it
+                                            carries the redo launches instead); 2 = also every frame whose camera moved by more than
+                                            half a degree.  The rule is include/splat_policy.h (SPLAT_COUNT_FIRST)                    */
 int splat_set_option(splat_ctx* ctx, int32_t option, double value);
 int splat_get_option(const splat_ctx* ctx, int32_t option, double* value);
 void* splat_stream(splat_ctx* ctx);                   /* the hipStream_t the kernels run on */

@@ -65,8 +65,10 @@ int main(int argc, char** argv) {
                 pipeline.render_to_buffer(color.data());
             }
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            std::printf("Rendering took %.3f ms (gpu %.3f ms, %llu visible, %llu pairs)\n", ms, pipeline.last_stats.ms_total,
-                        (unsigned long long)pipeline.last_stats.n_visible, (unsigned long long)pipeline.last_stats.n_pairs);
+            // (the one-call frame asks for no statistics -- they cost a read-back per frame: last_stats is not this frame's)
+            if (one_call) std::printf("Rendering took %.3f ms\n", ms);
+            else std::printf("Rendering took %.3f ms (gpu %.3f ms, %llu visible, %llu pairs)\n", ms, pipeline.last_stats.ms_total,
+                             (unsigned long long)pipeline.last_stats.n_visible, (unsigned long long)pipeline.last_stats.n_pairs);
             pipeline.camera.update_yaw_angle(10.0f * 3.14159265f / 180.0f);   // Key::Right
         }
         if (one_call && !streaming) splat::GaussianSplatPipeline01::unpin_frame(color.data());

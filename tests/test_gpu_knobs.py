@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 # the automatic choice may lose this much to the best forced setting of a cell (the matrix's run-to-run spread is ~3 %: the
-# 5 % the review asked for holds on 17 of the 20 committed cells, 7 % on all -- DESIGN.md section 4 names the exceptions)
+# 5 % the review asked for holds on 18 of the 20 committed cells, 7 % on all -- DESIGN.md section 4 names the exceptions)
 WITHIN = 0.93
 
 
@@ -28,9 +28,10 @@ def test_committed_matrix_keeps_the_defaults_near_the_best_fixed_choice():
         assert worst <= 0.90, (knob, worst)
 
 
-@pytest.mark.gpu
+@pytest.mark.perf
 def test_defaults_are_near_the_best_fixed_choice_live():
-    """C2 and C3, at rest and at 10 degrees a frame, measured now"""
+    """C2 and C3, at rest and at 10 degrees a frame, measured now.  A wall-clock assertion: `-m perf`, not in the -m gpu set
+    (the committed matrix above is the gating check)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     cwd = os.getcwd()
     os.chdir(ROOT)

@@ -1047,6 +1047,51 @@ def test_render_frame_host_call_is_clear_plus_render_to_buffer(R):
         R.set_slab(0, -1)
 
 
+def test_render_frame_into_a_partly_locked_image_takes_the_copy_path(R):
+    """the zero-copy frame looked at the FIRST byte of the image only.  An image of which the caller page-locked
+    less than W*H*4 bytes (a slab's worth of a larger frame) must be rendered through the copy path -- a store past the
+    mapping is a GPU page fault that ends the context -- and an image locked by somebody else's allocator (a torch pinned
+    tensor) is asked of the runtime and still served, one way or the other."""
+    import ctypes as C
+    import torch
+    from splat_amd import _lib as L
+    g = gpu_scene(R, 20000, 46)
+    R.upload(g)
+    h, w = 208, 320
+    cam_c = make_camera(h, w).to_c(0.01)
+    want = np.zeros((h, w), np.uint32)
+    R.render(cam_c, want)
+    assert want.any()
+    R.set_option(L.OPT_HOST_ZERO_COPY, 1)
+    # page-aligned storage, the first 64 rows locked (a multiple of the page size: 64 * 320 * 4 = 20 pages)
+    raw = np.zeros(h * w + 1024, np.uint32)
+    off = (-raw.ctypes.data % 4096) // 4
+    img = raw[off:off + h * w].reshape(h, w)
+    part = img[:64]
+    assert L.lib().splat_host_register(C.c_void_p(part.ctypes.data), part.nbytes) == 0
+    try:
+        img[:] = 0xdeadbeef
+        R.render_frame(cam_c, img)
+        assert np.array_equal(img, want)
+        # the context is alive and the fully locked form still takes the zero-copy path's result
+        img[:] = 0xdeadbeef
+        R.render_frame(cam_c, img)
+        assert np.array_equal(img, want)
+    finally:
+        L.lib().splat_host_unregister(C.c_void_p(part.ctypes.data))
+    t = torch.empty((h, w), dtype=torch.int32).pin_memory()
+    arr = t.numpy().view(np.uint32)
+    arr[:] = 0xdeadbeef
+    R.render_frame(cam_c, arr)
+    assert np.array_equal(arr, want)
+    # a view INTO a larger pinned tensor whose tail is not part of it: rows 0..h of a taller image
+    big = torch.empty((h + 8, w), dtype=torch.int32).pin_memory()
+    sub = big.numpy().view(np.uint32)[8:]
+    sub[:] = 0xdeadbeef
+    R.render_frame(cam_c, sub)
+    assert np.array_equal(sub, want)
+
+
 def _channels(a):
     return np.stack([(a >> s) & 0xff for s in (24, 16, 8, 0)]).astype(np.int32)
 
