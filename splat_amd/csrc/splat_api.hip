@@ -67,6 +67,8 @@ struct Slot {                  // everything one frame writes before the image
                                            // lists of more than 2048 keys; two-pass binning mirrors the first buffer instead)
     unsigned int* blockinfo = nullptr;     // per K1 block: the info word this slot's last K1 wrote (see launch_preprocess);
                                            // per slot, because the K1s of consecutive frames run concurrently
+    uint4* large_list = nullptr;           // one-pass binning: the frame's large splats (key, tile rectangle), n entries -- K1 lists them,
+    unsigned int* large_count = nullptr;   // bin_large_kernel bins them tile by tile; the counter is zero between frames (scan / layout reset it)
     FrameStatus* d_status = nullptr;
     hipEvent_t ev_binned = nullptr;        // bin stream -> sort stream: buckets and lengths are final
     hipEvent_t ev_ready = nullptr;         // sort stream -> caller's stream: lists are sorted
@@ -197,6 +199,10 @@ struct splat_ctx {
     // to frame: the previous camera and how long it has been the same, the count-first / overflow-redo runs left, how the frames
     // in the status ring were binned.  reset_policy() where the lists it speaks of stop existing (scene, target, slab, options).
     splat_policy_state pol{};
+    // One-pass binning: splats of more tiles than this (and every splat wider or taller than K1's 32 x 32-tile window) go to the
+    // frame's large list and are binned tile by tile behind K1 (bin_large_kernel).  SPLAT_LARGE_TILES: 0 = the window alone
+    // decides, < 0 = no list at all (K1's blocks expand close-ups themselves, one atomic per pair: the round-5 path).
+    int large_tiles = 128;               // (C2 / C3 / C5, bench pose and from inside: 96-128 best of 0..1024, profiles/r07_large_splats.txt)
     int count_first = 1;                   // SPLAT_OPT_COUNT_FIRST: 0 only slots without a layout; 1 + the 64 moving frames behind a run of frames that outgrew
                                            // their regions (three in four of the recent ones); 2 + every frame whose camera moved by more than half a degree
     bool idle = false;                     // nothing of this context is in flight (set by the waits that drain every stream, cleared by every enqueue)
@@ -402,6 +408,64 @@ void ledger_del(void* p) {
     g_ledger.erase(it);
 }
 
+// Page-locked host ranges this library made (splat_host_alloc / splat_host_register): start -> bytes.  The zero-copy frame
+// stores W*H*4 bytes through the device mapping of `argb_out`; the mapping must cover all of them (ADVICE r5: a caller that
+// registered a slab's worth of a larger image got a GPU page fault instead of the copy path).  A range the table does not
+// know (locked by the caller's own hipHostMalloc / hipHostRegister, a framework's pinned tensor) is asked of the runtime.
+static std::mutex g_host_mu;
+static std::unordered_map<const char*, size_t> g_host_ranges;
+static void host_range_add(const void* p, size_t bytes) { std::lock_guard<std::mutex> g(g_host_mu); g_host_ranges[(const char*)p] = bytes; }
+static void host_range_del(const void* p) { std::lock_guard<std::mutex> g(g_host_mu); g_host_ranges.erase((const char*)p); }
+static bool host_range_is_locked(const void* host, void* dev, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        const char* lo = (const char*)host;
+        for (const auto& r : g_host_ranges)
+            if (r.first <= lo && lo < r.first + r.second) return lo + bytes <= r.first + r.second;      // (ours: the table decides)
+    }
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev) == hipSuccess && base != nullptr &&
+        (const char*)dev >= (const char*)base && (const char*)dev + bytes <= (const char*)base + size)
+        return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+// Device -> host copy of image rows behind a frame.  A destination of which only a PART is page-locked (ADVICE r5's case: the
+// caller registered a slab's worth of a larger image) is refused whole by hipMemcpyAsync (invalid argument): it is copied in
+// pieces cut at the borders of the locked ranges this library knows, and a piece the runtime still refuses goes through a
+// page-locked staging buffer.  The usual destination -- wholly locked or wholly pageable -- is one call as before.
+static hipError_t copy_to_host_image(uint32_t* dst, const uint32_t* src, size_t bytes, hipStream_t stream) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+    if (e != hipErrorInvalidValue) return e;
+    (void)hipGetLastError();
+    std::vector<size_t> cuts{0, bytes};
+    {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        const char* lo = (const char*)dst;
+        for (const auto& r : g_host_ranges)
+            for (const char* edge : {r.first, r.first + r.second})
+                if (edge > lo && edge < lo + bytes) cuts.push_back((size_t)(edge - lo));
+    }
+    std::sort(cuts.begin(), cuts.end());
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        const size_t off = cuts[k], len = cuts[k + 1] - cuts[k];
+        if (!len) continue;
+        e = hipMemcpyAsync((char*)dst + off, (const char*)src + off, len, hipMemcpyDeviceToHost, stream);
+        if (e == hipErrorInvalidValue) {
+            (void)hipGetLastError();
+            void* stage = nullptr;
+            if ((e = hipHostMalloc(&stage, len)) != hipSuccess) return e;
+            e = hipMemcpyAsync(stage, (const char*)src + off, len, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e == hipSuccess) std::memcpy((char*)dst + off, stage, len);
+            (void)hipHostFree(stage);
+        }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // The frame policy's memory speaks of lists that no longer exist (another scene, target, slab, key-buffer layout) or of
 // thresholds that changed (an option): forget it.  Statuses of frames still in the ring stay where they are; ring_kind = 0
 // makes the policy ignore them ('binned twice' words of an earlier scene could arm 64 count-first frames on the next).
@@ -594,6 +658,7 @@ int build_frame_const(splat_ctx* c, const splat_camera* cam, FrameConst* fc, uns
     fc->bucket_cap = 0;
     fc->corrected = (c->cfg.mode & SPLAT_MODE_CORRECTED_PROJECTION) ? 1 : 0;
     fc->redo_only = 0;
+    fc->large_tiles = std::max(0, c->large_tiles);
     fc->start_hints = 0;
     fc->start_light = 0;
     // (a singular cov2d needs lowpass == 0 or a non-PSD cov3d; with lowpass == 0 every Gaussian is
@@ -703,8 +768,11 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         if (count_first) {
             const int into = s.layout_valid ? s.flip : 1;
             HIP_TRY(c, hipMemsetAsync(s.redo_cursors, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));     // (the redo's buffer: a count-first frame has no redo)
-            launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout, true);
-            launch_layout(bs, m, s.redo_cursors, c->zero_layout, into ? s.lay_b : s.lay_a, into ? s.counts_b : s.counts, c->fc.bucket_cap, nullptr, nullptr, c->region_spare);
+            launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout, true,
+                              s.large_list, s.large_count);
+            launch_bin_large(bs, c->fc, s.large_list, s.large_count, s.redo_cursors, s.keys, d_st, true);
+            launch_layout(bs, m, s.redo_cursors, c->zero_layout, into ? s.lay_b : s.lay_a, into ? s.counts_b : s.counts, c->fc.bucket_cap, nullptr, nullptr, c->region_spare,
+                          nullptr, s.large_count);
             s.flip = into; s.layout_valid = true;
             s.layout_cam[into] = cam_hash;
         }
@@ -712,7 +780,9 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         layout = s.flip ? s.lay_b : s.lay_a;
     }
     HIP_TRY(c, mark(0, bs));
-    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, layout);
+    launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, layout, false,
+                      s.large_list, s.large_count);
+    if (c->fc.bucket_cap) launch_bin_large(bs, c->fc, s.large_list, s.large_count, cursors, s.keys, d_st, false);     // (the large splats K1 listed, tile by tile)
     HIP_TRY(c, mark(1, bs));
     c->grid_big = pd.grid_big; c->grid_mid = pd.grid_mid; c->grid_long = pd.grid_long;      // (what the sort launches cover; the scan validates)
     // (one-pass binning: a second workgroup of the scan's launch builds the regions of the NEXT frame on this binning
@@ -730,7 +800,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const unsigned int near_cap = pd.near_cap;
     unsigned int* const off2 = c->fc.bucket_cap ? s.off2 : nullptr;        // (two-pass binning: the second buffer mirrors the first)
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
-                next_layout, next_counts, c->region_spare, false, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull));
+                next_layout, next_counts, c->region_spare, false, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull), s.large_count);
     const bool redo = pd.redo != 0;
     if (redo) {
         // OVERFLOW REDO.  The regions this frame was binned into were sized for another camera (two frames back on a moving
@@ -744,9 +814,11 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         FrameConst fr = c->fc;
         fr.redo_only = 1;
         launch_layout(bs, m, cursors, layout, s.redo_layout, s.redo_cursors, c->fc.bucket_cap, nullptr, nullptr, c->region_spare, d_st);
-        launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, s.redo_layout);
+        launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, s.redo_layout, false,
+                          s.large_list, s.large_count);
+        launch_bin_large(bs, fr, s.large_list, s.large_count, s.redo_cursors, s.keys, d_st, false);
         launch_scan(bs, m, s.redo_cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], s.redo_layout,
-                    nullptr, nullptr, c->region_spare, true, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull));
+                    nullptr, nullptr, c->region_spare, true, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull), s.large_count);
     }
     HIP_TRY(c, mark(2, bs));
     if (ss != bs) {
@@ -1071,7 +1143,7 @@ void fill_stats(splat_ctx* c, splat_stats* st) {
 
 void free_scene(splat_ctx* c) {
     dfree(c->planes); dfree(c->orig); dfree(c->bounds);
-    for (Slot& s : c->slots) { dfree(s.recs); dfree(s.depth); dfree(s.rect); dfree(s.vislist); dfree(s.blockinfo); s.used = false; }
+    for (Slot& s : c->slots) { dfree(s.recs); dfree(s.depth); dfree(s.rect); dfree(s.vislist); dfree(s.blockinfo); dfree(s.large_list); dfree(s.large_count); s.used = false; }
     c->n = 0;
     c->h_orig.clear();
     c->last_slot = -1;
@@ -1243,6 +1315,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         c->keys_per_gaussian = v <= 0 ? 0u : (unsigned int)std::min(256, std::max(4, v));
         c->env_pinned |= 1u << SPLAT_OPT_KEYS_PER_GAUSSIAN;
     }
+    if (const char* lt = std::getenv("SPLAT_LARGE_TILES")) c->large_tiles = std::max(-1, std::min(1 << 20, std::atoi(lt)));
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
@@ -1418,6 +1491,11 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
         UP_TRY(dmalloc(c, &s.recs, sizeof(Rec) * n));
         UP_TRY(dmalloc(c, &s.blockinfo, sizeof(unsigned int) * ((n + 255) / 256)));
         UP_TRY(hipMemsetAsync(s.blockinfo, 0, sizeof(unsigned int) * ((n + 255) / 256), c->stream));
+        if (c->large_tiles >= 0) {          // (SPLAT_LARGE_TILES < 0: no list, K1's blocks expand their close-ups themselves)
+            UP_TRY(dmalloc(c, &s.large_list, sizeof(uint4) * n));
+            UP_TRY(dmalloc(c, &s.large_count, sizeof(unsigned int) * 4));
+            UP_TRY(hipMemsetAsync(s.large_count, 0, sizeof(unsigned int) * 4, c->stream));
+        }
     }
     UP_TRY(hipMemcpyAsync(c->orig, c->h_orig.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, c->stream));
     std::vector<BlockBounds> hb;
@@ -1588,7 +1666,7 @@ int render_device_impl(splat_ctx* c, const splat_camera* cam, void* d_argb, int3
         if (rc != SPLAT_OK) return rc;
         if (host_out && c->fc.row_px1 > c->fc.row_px0) {
             const size_t first = (size_t)c->fc.row_px0 * (size_t)c->fc.W, count = (size_t)(c->fc.row_px1 - c->fc.row_px0) * (size_t)c->fc.W;
-            HIP_TRY(c, hipMemcpyAsync(host_out + first, (const uint32_t*)d_argb + first, count * 4u, hipMemcpyDeviceToHost, frame_stream(c)));
+            HIP_TRY(c, copy_to_host_image(host_out + first, (const uint32_t*)d_argb + first, count * 4u, frame_stream(c)));
         }
         if (!sync && !stats) return SPLAT_OK;
         bool skipped = false;
@@ -1637,29 +1715,6 @@ int splat_render(splat_ctx* c, const splat_camera* cam, uint32_t* argb, splat_st
     HIP_TRY(c, hipMemcpyAsync(argb, c->d_img, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPLAT_OK;
-}
-
-// Page-locked host ranges this library made (splat_host_alloc / splat_host_register): start -> bytes.  The zero-copy frame
-// stores W*H*4 bytes through the device mapping of `argb_out`; the mapping must cover all of them (ADVICE r5: a caller that
-// registered a slab's worth of a larger image got a GPU page fault instead of the copy path).  A range the table does not
-// know (locked by the caller's own hipHostMalloc / hipHostRegister, a framework's pinned tensor) is asked of the runtime.
-static std::mutex g_host_mu;
-static std::unordered_map<const char*, size_t> g_host_ranges;
-static void host_range_add(const void* p, size_t bytes) { std::lock_guard<std::mutex> g(g_host_mu); g_host_ranges[(const char*)p] = bytes; }
-static void host_range_del(const void* p) { std::lock_guard<std::mutex> g(g_host_mu); g_host_ranges.erase((const char*)p); }
-static bool host_range_is_locked(const void* host, void* dev, size_t bytes) {
-    {
-        std::lock_guard<std::mutex> g(g_host_mu);
-        const char* lo = (const char*)host;
-        for (const auto& r : g_host_ranges)
-            if (r.first <= lo && lo < r.first + r.second) return lo + bytes <= r.first + r.second;      // (ours: the table decides)
-    }
-    hipDeviceptr_t base = nullptr; size_t size = 0;
-    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev) == hipSuccess && base != nullptr &&
-        (const char*)dev >= (const char*)base && (const char*)dev + bytes <= (const char*)base + size)
-        return true;
-    (void)hipGetLastError();
-    return false;
 }
 
 // The viewer loop's frame, host-visible and synchronous: `color.clear(0); render_to_buffer(&mut color)` (src/main.rs:73-74)

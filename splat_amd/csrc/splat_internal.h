@@ -9,6 +9,16 @@
 #ifndef SPLAT_K1X
 #define SPLAT_K1X 0      // K1 timing experiments (tools/k1_ab.py); 0 = the product
 #endif
+// Round-7 timing experiments (tools/lab/build_variant.sh name -DSPLAT_EXP_...=...; profiles/r07_*): 0 = the product
+#ifndef SPLAT_EXP_STAGE2
+#define SPLAT_EXP_STAGE2 0     // compositor: the staging verdicts computed twice (what they cost)
+#endif
+#ifndef SPLAT_EXP_K1DUMMY
+#define SPLAT_EXP_K1DUMMY 0    // K1: this many dummy VALU instructions per (Gaussian, tile) hand-out step (what per-pair verdicts would cost)
+#endif
+#ifndef SPLAT_EXP_K1DROP
+#define SPLAT_EXP_K1DROP 0     // K1: 1 = close-up rectangles dropped from binning, n >= 2 = every rectangle of more than n tiles (invalid frames)
+#endif
 
 namespace splat {
 
@@ -45,6 +55,8 @@ struct FrameConst {
     int start_hints;       // compositor: the camera is at rest -- a wave's exact walk may start where the previous frame's did (start_hint) instead of scanning for it
     int start_light;       // ... in very slow motion: half the margin on a hinted start, the scan every eighth frame instead of every fourth
     int redo_only;         // K1 as a REDO launch: leaves at once unless the frame's scan flagged a tile that outgrew its region
+    int large_tiles;       // one-pass binning: a splat of more tiles than this goes to the frame's large list (bin_large_kernel); 0 = only
+                           // the splats wider or taller than K1's 32 x 32-tile window
 };
 
 // Upload-time bounds of one K1 block (256 consecutive slots of the Morton-ordered scene): the AABB
@@ -106,7 +118,12 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
                        const unsigned int* layout = nullptr /* one-pass binning (fc.bucket_cap != 0): counts[t] is the cursor of tile t's
                                                                region keys[layout[t] .. layout[t+1]); nullptr: two-pass counting */,
                        bool count_only = false /* one-pass binning's COUNT flavour: counts[t] += the tile's pairs and nothing else (no SH,
-                                                  no record, no key) -- the pass in front of a layout that fits exactly this camera */);
+                                                  no record, no key) -- the pass in front of a layout that fits exactly this camera */,
+                       uint4* large_list = nullptr, unsigned int* large_count = nullptr /* one-pass binning: the frame's list of large
+                                                  splats (n entries) and its counter -- launch_bin_large behind this launch bins them */);
+// the large splats K1 listed, tile by tile (bin_large_kernel): same stream, right behind launch_preprocess; `cursors` as given to it
+void launch_bin_large(hipStream_t s, const FrameConst& fc, const uint4* large_list, const unsigned int* large_count, unsigned int* cursors,
+                      unsigned long long* keys, const FrameStatus* status, bool count_only);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
@@ -118,12 +135,14 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  bool redo_only = false /* the second scan of a frame binned again on the device: nothing unless status->overflow == 2 */,
                  unsigned int* off2 = nullptr /* one-pass binning: per tile, where its room in the SECOND key buffer starts -- handed out
                                                  by this scan to the lists of more than 2048 keys */,
-                 unsigned int cap2 = 0 /* entries of the second key buffer: beyond it the frame is flagged (overflow 4) */);
+                 unsigned int cap2 = 0 /* entries of the second key buffer: beyond it the frame is flagged (overflow 4) */,
+                 unsigned int* large_count = nullptr /* the frame's large-splat counter: reset here for the slot's next K1 */);
 // the regions (and cursors) of the slot's next one-pass frame from this frame's lists; an all-zero `layout` with cursors
 // counted from zero is the bootstrap
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
                    unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max = 4.0f,
-                   const FrameStatus* redo_gate = nullptr /* != nullptr: a redo launch -- does nothing unless redo_gate->overflow == 2 */);
+                   const FrameStatus* redo_gate = nullptr /* != nullptr: a redo launch -- does nothing unless redo_gate->overflow == 2 */,
+                   unsigned int* large_count = nullptr /* see launch_scan */);
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status);
 // grid_big / grid_mid: how many entries of `order` (longest lists first) the 1024- and 512-thread

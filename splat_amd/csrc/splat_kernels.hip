@@ -406,6 +406,13 @@ struct BucketBinner {
     unsigned int* __restrict__ const gcount;      // per tile: the CURSOR of its region (initialised to the region's start)
     unsigned long long* __restrict__ const keys;
     const unsigned int bcap;                      // entries of the key buffer: nothing is stored at or beyond it
+    // LARGE splats -- wider or taller than the table's window, or of more than large_tiles tiles -- are not expanded here: one
+    // entry (key, tile rectangle) goes to the frame's large list, and bin_large_kernel, behind this launch, bins the list TILE
+    // by tile (see there).  large_list == nullptr: the block expands them itself, one returning atomic per pair (expand_big).
+    uint4* __restrict__ const large_list;
+    unsigned int* __restrict__ const large_count;
+    const unsigned int large_cap;                 // entries of the list (the scene's Gaussians: it cannot overflow)
+    const int large_tiles;                        // 0: only the window decides
     // (A run that outgrows its tile's region spills into the next tile's.  Nobody looks: the scan sees the cursor beyond
     // the region's end and the frame is skipped as a whole -- sort and compositor never read its lists.)
     // this thread's rectangle
@@ -416,8 +423,23 @@ struct BucketBinner {
     int bx0, by0;
     unsigned int res[NRES];                // reservations in flight: position of the block's run in the tile's region, per table slot
 
-    __device__ __forceinline__ BucketBinner(BucketShared& s, FlatShared& f, int tiles_x_, unsigned int* g, unsigned long long* k, unsigned int cap)
-        : sh(s), fs(f), tiles_x(tiles_x_), gcount(g), keys(k), bcap(cap) {}
+    __device__ __forceinline__ BucketBinner(BucketShared& s, FlatShared& f, int tiles_x_, unsigned int* g, unsigned long long* k, unsigned int cap,
+                                            uint4* ll, unsigned int* lc, unsigned int lcap, int lt)
+        : sh(s), fs(f), tiles_x(tiles_x_), gcount(g), keys(k), bcap(cap), large_list(ll), large_count(lc), large_cap(lcap), large_tiles(lt) {}
+    // this wave's large splats, appended to the frame's list: one returning atomic per wave that has any (wave-uniform control flow)
+    __device__ __forceinline__ void append_large(unsigned long long key) const {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(big);
+        if (m == 0ull) return;
+        const unsigned int lane = threadIdx.x & 63u;
+        unsigned int base = 0u;
+        if (lane == (unsigned int)__builtin_ctzll(m)) base = __hip_atomic_fetch_add(large_count, (unsigned int)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+        if (big) {
+            const unsigned int at = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            if (at < large_cap)
+                large_list[at] = make_uint4((unsigned int)key, (unsigned int)(key >> 32), (unsigned int)tx0 | ((unsigned int)ty0 << 16), (unsigned int)tx1 | ((unsigned int)ty1 << 16));
+        }
+    }
     __device__ __forceinline__ static unsigned int hslot(int tx, int ty) { return (unsigned int)(((ty & (HASH_DIM - 1)) << HASH_BITS) | ((tx + 17 * ty) & (HASH_DIM - 1))); }
     __device__ __forceinline__ void put_at(unsigned int pos, unsigned long long k) const {
         if (pos < bcap) keys[pos] = k;
@@ -510,6 +532,18 @@ struct BucketBinner {
             const unsigned int e = f < flat_total ? (unsigned int)fs.exp[wave][f] : 0u;
             const unsigned int slot = e & (unsigned int)(HASH_CAP - 1), src = e >> 10;
             const unsigned int khi = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(unsigned int)(key >> 32));
+#if SPLAT_EXP_K1DUMMY
+            // timing experiment (VERDICT r5 item 1's gate): the arithmetic per-pair staging verdicts would cost here -- eight
+            // more cross-lane reads of the source Gaussian's record and SPLAT_EXP_K1DUMMY VALU instructions in four chains
+            {
+                float c0 = __uint_as_float(khi), c1 = c0 + 1.0f, c2 = c0 + 2.0f, c3 = c0 + 3.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) c0 += __uint_as_float((unsigned int)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)__float_as_uint(c1 + (float)q)));
+#pragma unroll
+                for (int q = 0; q < SPLAT_EXP_K1DUMMY / 4; ++q) { c0 = fmaf(c0, 1.0001f, c1); c1 = fmaf(c1, 0.9999f, c2); c2 = fmaf(c2, 1.0002f, c3); c3 = fmaf(c3, 0.9998f, c0); }
+                asm volatile("" :: "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+            }
+#endif
             if (f < flat_total) {
                 const unsigned int pos = atomicAdd(&sh.table[slot], 1u);      // (the table holds positions in the key buffer)
                 put_at(pos, ((unsigned long long)khi << 32) | (unsigned long long)(i0 + src));
@@ -520,11 +554,16 @@ struct BucketBinner {
         const unsigned int tid = threadIdx.x, lane = tid & 63u;
         tx0 = tx0_; tx1 = tx1_; ty0 = ty0_; ty1 = ty1_;
         w = tx1 - tx0 + 1; ntiles = vis ? w * (ty1 - ty0 + 1) : 0;
+#if SPLAT_EXP_K1DROP == 1       // timing experiments (invalid frames): what the close-up path costs -- its rectangles dropped
+        if (vis && !(w <= HASH_DIM && (ty1 - ty0) < HASH_DIM)) { vis = false; ntiles = 0; }
+#elif SPLAT_EXP_K1DROP >= 2     // ... and what every rectangle of more than SPLAT_EXP_K1DROP tiles costs
+        if (ntiles > SPLAT_EXP_K1DROP) { vis = false; ntiles = 0; }
+#endif
         // Through the hashed table: every rectangle that fits its HASH_DIM x HASH_DIM window (512 x 512 pixels).  Only a
         // splat wider or taller than that is a close-up for the slow path below.  (The limit used to be 64 tiles, one
         // lane-spread round; at the C3 bench pose the 0.45 % of the Gaussians above it put 8 % of the pairs -- and three
         // more barriers, a serial prefix and an exposed atomic round trip -- into most blocks: K1 0.169 -> 0.13 ms.)
-        small = vis && w <= HASH_DIM && (ty1 - ty0) < HASH_DIM; big = vis && !small;
+        small = vis && w <= HASH_DIM && (ty1 - ty0) < HASH_DIM && (large_list == nullptr || large_tiles <= 0 || ntiles <= large_tiles); big = vis && !small;
         {   // block statistics and bounding box of the aggregated rectangles: wave reduce, LDS atomics by lane 0
             const unsigned int nv = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vis));
             const unsigned int ns = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(singular));
@@ -599,6 +638,7 @@ struct BucketBinner {
         } else if (any) {
             each_tile(small, 0ull, [&](int tx, int ty, unsigned long long) { (void)__hip_atomic_fetch_add(gcount + (unsigned int)(ty * tiles_x + tx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
         }
+        if (large_list != nullptr) { append_large(0ull); return; }      // (counted tile by tile by bin_large_kernel<true>)
         if (__syncthreads_or(big ? 1 : 0) == 0) return;
         if (big) add_big(sh, tx0, tx1, ty0, ty1, 0ull);
         __syncthreads();
@@ -625,7 +665,9 @@ struct BucketBinner {
             after_barrier();
             if (any) each_tile(small, key, [&](int tx, int ty, unsigned long long k) { put_direct((unsigned int)(ty * tiles_x + tx), k); });
         }
-        // close-ups (wider or taller than the table's window): the whole block takes the tiles of each, one per thread
+        // large splats: to the frame's list (bin_large_kernel bins them tile by tile) ...
+        if (large_list != nullptr) { append_large(key); return; }
+        // ... or, without a list, close-ups (wider or taller than the table's window): the whole block takes the tiles of each, one per thread
         if (__syncthreads_or(big ? 1 : 0) == 0) return;
         if (big) add_big(sh, tx0, tx1, ty0, ty1, key);
         __syncthreads();
@@ -715,7 +757,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                                          unsigned long long* __restrict__ keys,
                                                          const BlockBounds* __restrict__ bounds,
                                                          unsigned int* __restrict__ blockinfo,
-                                                         FrameStatus* __restrict__ status) {
+                                                         FrameStatus* __restrict__ status,
+                                                         uint4* __restrict__ large_list, unsigned int* __restrict__ large_count) {
     __shared__ std::conditional_t<BUCKET, BucketShared, BinShared> sh;
     __shared__ std::conditional_t<BUCKET, FlatShared, unsigned int> fsh;
     __shared__ unsigned int swave[4];
@@ -842,7 +885,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
                                 : make_ushort4(1, 0, 1, 0);
         }
     }
-    std::conditional_t<BUCKET, BucketBinner, NoBinner> binner(sh, fsh, fc.tiles_x, counts, keys, fc.bucket_cap);
+    std::conditional_t<BUCKET, BucketBinner, NoBinner> binner(sh, fsh, fc.tiles_x, counts, keys, fc.bucket_cap, large_list, large_count, (unsigned int)min(n, (uint64_t)0xffffffffu), fc.large_tiles);
     // The SH planes' loads go out BEFORE the reservations: vector memory returns in order, so loads issued behind
     // the returning atomics could not be consumed before those have made their round trip to the L2 atomic unit
     // (queued behind every other block's atomics on the same hot tile counters) -- the SH stage, the record store
@@ -971,6 +1014,101 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
         const int a1[1] = {tx0}, b1[1] = {tx1}, c1[1] = {ty0}, d1[1] = {ty1};
         const unsigned long long k1[1] = {0ull};
         bin_block<false, 1>(sh, v1, a1, b1, c1, d1, fc.tiles_x, counts, nullptr, k1);
+    }
+}
+
+// LARGE SPLATS, binned tile by tile.  K1 expands a Gaussian's (Gaussian, tile) pairs block by block: the pairs of 256 Morton
+// neighbours meet in an LDS table and cost one returning global atomic per (block, tile).  A splat that covers hundreds or
+// thousands of tiles -- a camera inside the scene: 0.5 % of C3's visible Gaussians carry 18 % of the pairs there, on C5 40 % --
+// has no neighbours to share with: one atomic per pair on the same few thousand tile cursors from every block of the launch,
+// 3-8 G atomics/s, and K1 took 1.1 ms instead of 0.25 on C3 from inside the cloud, 13.5 instead of 1.75 on C5
+// (profiles/r07_k1_closeup.txt).  Such splats go to a list instead (BucketBinner::append_large: 16 B each), and this kernel,
+// launched behind K1 on the same stream, turns the list inside out: one workgroup per 4 x 4 TILES streams the whole list
+// (coalesced, L2-resident), keeps the entries whose rectangle meets its tiles, and appends their keys to those tiles' regions --
+// the cursors are this workgroup's alone by now (K1 has ended), so the only atomics are LDS ones on sixteen counters.
+// Replaces the per-splat row loops of euc's rasteriser (src/pipelines.rs:80-84) for the splats that fill the screen.
+// COUNT: the count flavour's twin (adds the pairs to the counts, stores nothing).  A frame without large splats: every workgroup
+// reads one word and leaves.
+constexpr int LARGE_G = 4;                 // tiles per side of a workgroup's group
+template <bool COUNT>
+__global__ __launch_bounds__(256) void bin_large_kernel(const uint4* __restrict__ list, const unsigned int* __restrict__ count_p,
+                                                        unsigned int* __restrict__ cursors, unsigned long long* __restrict__ keys,
+                                                        unsigned int bcap, int tiles_x, int tile_rows,
+                                                        const FrameStatus* __restrict__ status, unsigned int redo_only) {
+    if (redo_only && status->overflow != 2u) return;          // (a redo launch of a frame that needs none)
+    const unsigned int n = (unsigned int)__builtin_amdgcn_readfirstlane((int)*count_p);
+    if (n == 0u) return;
+    __shared__ unsigned int cnt[LARGE_G * LARGE_G];            // keys appended so far, per tile of the group
+    __shared__ unsigned int first[LARGE_G * LARGE_G];          // the tile's cursor when this launch began
+    __shared__ uint4 queue[4][128];                            // per wave: entries that meet the group, waiting for a full batch
+    const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int groups_x = (tiles_x + LARGE_G - 1) / LARGE_G;
+    const int gx = (int)(blockIdx.x % (unsigned int)groups_x), gy = (int)(blockIdx.x / (unsigned int)groups_x);
+    const int tx_lo = gx * LARGE_G, ty_lo = gy * LARGE_G;
+    const int tx_hi = min(tx_lo + LARGE_G - 1, tiles_x - 1), ty_hi = min(ty_lo + LARGE_G - 1, tile_rows - 1);
+    if (tid < (unsigned int)(LARGE_G * LARGE_G)) {
+        const int tx = tx_lo + (int)(tid % LARGE_G), ty = ty_lo + (int)(tid / LARGE_G);
+        first[tid] = (tx <= tx_hi && ty <= ty_hi) ? cursors[ty * tiles_x + tx] : 0u;
+        cnt[tid] = 0u;
+    }
+    __syncthreads();
+    uint4* const q = queue[wave];
+    // the keys of up to 64 queued entries, tile by tile: a ballot finds the entries that cover the tile, one LDS atomic reserves
+    // their run behind the tile's cursor
+    auto flush = [&](unsigned int k) {
+        const uint4 e = lane < k ? q[lane] : make_uint4(0u, 0u, 0xffffffffu, 0u);       // (x0 = y0 = 65535: covers nothing)
+        const int x0 = (int)(e.z & 0xffffu), y0 = (int)(e.z >> 16), x1 = (int)(e.w & 0xffffu), y1 = (int)(e.w >> 16);
+#pragma unroll
+        for (int t = 0; t < LARGE_G * LARGE_G; ++t) {
+            const int tx = tx_lo + t % LARGE_G, ty = ty_lo + t / LARGE_G;
+            const bool c = x0 <= tx && tx <= x1 && y0 <= ty && ty <= y1;           // (x1 < tiles_x, y1 < tile_rows: a tile beyond the grid is never covered)
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+            if (m == 0ull) continue;
+            unsigned int b = 0u;
+            if (lane == (unsigned int)__builtin_ctzll(m)) b = atomicAdd(&cnt[t], (unsigned int)__builtin_popcountll(m));
+            if constexpr (!COUNT) {
+                b = (unsigned int)__builtin_amdgcn_readlane((int)b, __builtin_ctzll(m));
+                if (c) {
+                    const unsigned int pos = first[t] + b + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                    if (pos < bcap) keys[pos] = ((unsigned long long)e.y << 32) | (unsigned long long)e.x;      // (see BucketBinner::put_at)
+                }
+            }
+        }
+    };
+    unsigned int qn = 0u;                                      // entries in this wave's queue (uniform)
+    for (unsigned int i0 = wave * 64u; i0 < n; i0 += 256u) {   // (wave w takes entries [64 w + 256 j, + 64): the four waves never meet)
+        const unsigned int i = i0 + lane;
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        bool pass = false;
+        if (i < n) {
+            e = list[i];
+            const int x0 = (int)(e.z & 0xffffu), y0 = (int)(e.z >> 16), x1 = (int)(e.w & 0xffffu), y1 = (int)(e.w >> 16);
+            pass = x0 <= tx_hi && x1 >= tx_lo && y0 <= ty_hi && y1 >= ty_lo;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+        if (m == 0ull) continue;
+        if (pass) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = e;
+        qn += (unsigned int)__builtin_popcountll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64u) {
+            flush(64u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 rest = q[64u + lane];                  // (at most 63 are left: they move to the front)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            qn -= 64u;
+            if (lane < qn) q[lane] = rest;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (qn != 0u) flush(qn);
+    __syncthreads();
+    if (tid < (unsigned int)(LARGE_G * LARGE_G)) {
+        const int tx = tx_lo + (int)(tid % LARGE_G), ty = ty_lo + (int)(tid / LARGE_G);
+        if (tx <= tx_hi && ty <= ty_hi && cnt[tid] != 0u) cursors[ty * tiles_x + tx] = first[tid] + cnt[tid];
     }
 }
 
@@ -1160,9 +1298,10 @@ __global__ __launch_bounds__(1024) void layout_kernel(unsigned int m, const unsi
                                                       const unsigned int* __restrict__ layout, unsigned int* __restrict__ next_layout,
                                                       unsigned int* __restrict__ next_counts, unsigned int key_entries,
                                                       FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status, float spare_max,
-                                                      const FrameStatus* __restrict__ redo_gate) {
+                                                      const FrameStatus* __restrict__ redo_gate, unsigned int* __restrict__ large_count) {
     __shared__ unsigned long long wsum[16];
     if (redo_gate != nullptr && redo_gate->overflow != 2u) return;        // (a redo launch of a frame that needs none)
+    if (large_count != nullptr && threadIdx.x == 0u) *large_count = 0u;   // (a count-first frame: its count pass's list has been counted; empty for its K1)
     build_layout<1024>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, wsum, spare_max);
 }
 
@@ -1182,9 +1321,11 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int cls_in_lds, FrameStatus* __restrict__ host_status,
                                                            unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
                                                            unsigned int key_entries, float spare_max, unsigned int redo_only,
-                                                           unsigned int* __restrict__ off2, unsigned int cap2) {
+                                                           unsigned int* __restrict__ off2, unsigned int cap2, unsigned int* __restrict__ large_count) {
     constexpr int NCLS = 64;
     if (redo_only && status->overflow != 2u) return;       // (the second scan of a frame that was binned again: see enqueue_frame)
+    // (the frame's large-splat list has been binned -- bin_large_kernel, in front of this launch: empty for the slot's next K1)
+    if (large_count != nullptr && blockIdx.x == 0u && threadIdx.x == 0u) *large_count = 0u;
     // Workgroup 1 of the launch (when there is one) builds the regions of the next frame on this binning stream from
     // the same cursors, beside the scan: no launch of its own, nothing added to the chain K1 -> scan -> sort.
     if (blockIdx.x == 1u) {
@@ -2546,6 +2687,15 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
         } else if (lane < cnt) {
             ov = any_sample_covered(r.a.x, r.a.z, xlo, xhi, off) && any_sample_covered(r.a.y, r.a.w, ylo, yhi, off);
             if (ov && only_contributing) ov = may_contribute(r);
+#if SPLAT_EXP_STAGE2
+            // timing experiment (tools/lab, VERDICT r5 item 1's gate): the staging verdict computed a second time behind a
+            // scheduling fence -- same frames, the launch's slowdown is what the verdicts cost
+            Rec r2 = r;
+            asm volatile("" : "+v"(r2.a.x), "+v"(r2.a.y), "+v"(r2.b.x), "+v"(r2.b.y), "+v"(r2.c.w));
+            bool ov2 = any_sample_covered(r2.a.x, r2.a.z, xlo, xhi, off) && any_sample_covered(r2.a.y, r2.a.w, ylo, yhi, off);
+            if (ov2 && only_contributing) ov2 = may_contribute(r2);
+            ov = ov & ov2;
+#endif
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(ov);
         if (save_k >= 0 && lane == 0u) wmask[save_k] = m;
@@ -3060,23 +3210,36 @@ void launch_cov3d(hipStream_t s, uint64_t n, const float* scales3, const float* 
 }
 void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const unsigned int* orig, FrameConst fc, Rec* recs,
                        float* depth, ushort4* rect, unsigned int* counts, unsigned int* vislist, unsigned long long* keys,
-                       const BlockBounds* bounds, unsigned int* blockinfo, FrameStatus* status, const unsigned int* layout, bool count_only) {
+                       const BlockBounds* bounds, unsigned int* blockinfo, FrameStatus* status, const unsigned int* layout, bool count_only,
+                       uint4* large_list, unsigned int* large_count) {
     if (!n) return;
     if (!bounds || !blockinfo) fc.cull_blocks = 0;
     if (!blockinfo || !layout) fc.bucket_cap = 0;
+    if (!large_list || !large_count || !fc.bucket_cap) { large_list = nullptr; large_count = nullptr; }
     const dim3 grid(blocks_for(n, 256)), block(256);
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status); };
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status, large_list, large_count); };
     if (fc.bucket_cap && count_only) { if (fc.corrected) go(preprocess_kernel<true, true, true>); else go(preprocess_kernel<true, false, true>); }
     else if (fc.bucket_cap && fc.corrected) go(preprocess_kernel<true, true>);
     else if (fc.bucket_cap) go(preprocess_kernel<true, false>);
     else if (fc.corrected) go(preprocess_kernel<false, true>);
     else go(preprocess_kernel<false, false>);
 }
+void launch_bin_large(hipStream_t s, const FrameConst& fc, const uint4* large_list, const unsigned int* large_count, unsigned int* cursors,
+                      unsigned long long* keys, const FrameStatus* status, bool count_only) {
+    if (!large_list || !large_count || !fc.bucket_cap || fc.tiles_x <= 0 || fc.n_tile_rows <= 0) return;
+    const unsigned int groups = (unsigned int)((fc.tiles_x + LARGE_G - 1) / LARGE_G) * (unsigned int)((fc.n_tile_rows + LARGE_G - 1) / LARGE_G);
+    if (count_only)
+        hipLaunchKernelGGL(bin_large_kernel<true>, dim3(groups), dim3(256), 0, s, large_list, large_count, cursors, keys, fc.bucket_cap, fc.tiles_x, fc.n_tile_rows,
+                           status, fc.redo_only ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(bin_large_kernel<false>, dim3(groups), dim3(256), 0, s, large_list, large_count, cursors, keys, fc.bucket_cap, fc.tiles_x, fc.n_tile_rows,
+                           status, fc.redo_only ? 1u : 0u);
+}
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
                  FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts, float spare_max,
-                 bool redo_only, unsigned int* off2, unsigned int cap2) {
+                 bool redo_only, unsigned int* off2, unsigned int cap2, unsigned int* large_count) {
     if (bucket_cap && layout)
     {
         const unsigned int nwg = (next_layout && next_counts) ? 2u : 1u;
@@ -3087,13 +3250,13 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         const unsigned int dyn = in_lds ? cls_bytes : 0u;
         if (nt == 256)
             hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(nwg), dim3(256), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count);
         else if (nt == 512)
             hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(nwg), dim3(512), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count);
         else
             hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(nwg), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,
@@ -3101,8 +3264,8 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
 }
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
                    unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max,
-                   const FrameStatus* redo_gate) {
-    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max, redo_gate);
+                   const FrameStatus* redo_gate, unsigned int* large_count) {
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max, redo_gate, large_count);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
