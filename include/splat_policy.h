@@ -7,6 +7,7 @@
  *   - hint radius     how far around a tile the near selection looks for what its walks may need
  *   - count first     does the frame count its (Gaussian, tile) pairs before it bins them (regions that fit ITS camera)
  *   - overflow redo   does the frame carry the launches that bin it again on the device if a list outgrew its region
+ *   - large list      do the frame's large splats go through the list and bin_large_kernel (one more launch on the chain)
  *   - who orders the lists of more than 2048 keys, the near selection's launch size, the sort launches' sizes, the walk flavour
  * The library's enqueue_frame() calls splat_policy_decide() and then only launches; tests/test_frame_policy.py drives the same
  * function through scripted camera paths with injected frame statuses on a box without a GPU.
@@ -43,6 +44,8 @@ typedef struct splat_policy_knobs {      /* the context's options that decisions
     int32_t pair_mode;                   /* SPLAT_OPT_PAIR_WALK: -1 auto, 0, 1 */
     int32_t pipeline;                    /* SPLAT_OPT_PIPELINE_DEPTH (0: everything on one stream) */
     int32_t tight_grids;                 /* debug: sort launches sized with no margin */
+    int32_t large_list_min;              /* large splats (SPLAT_LARGE_TILES) a recent frame must have had for frames to keep a large list:
+                                            0 = always, < 0 = never (K1's blocks expand close-ups themselves) */
 } splat_policy_knobs;
 
 typedef struct splat_policy_state {      /* carried from frame to frame; all zeros = a fresh context / scene / target */
@@ -50,7 +53,7 @@ typedef struct splat_policy_state {      /* carried from frame to frame; all zer
     uint32_t still_frames;               /* frames in a row with the same camera hash */
     int32_t count_first_left;            /* moving frames left that count first */
     int32_t redo_armed;                  /* moving frames left that carry the redo launches (adaptive mode) */
-    uint32_t reserved;
+    uint32_t large_on;                   /* the frames keep a large-splat list (hysteresis: off below half of large_list_min) */
     float last_view[32];                 /* the previous frame's view and projection */
     uint8_t ring_kind[SPLAT_POLICY_RING];/* per ring entry, how its frame was binned: 1 into another camera's regions, 2 counted first, 0 neither */
 } splat_policy_state;
@@ -81,6 +84,8 @@ typedef struct splat_policy_input {
     int32_t sort_hint;                   /* the list-length profile of an earlier frame is known: */
     uint32_t hint_maxlen, hint_ge2048, hint_ge8192, hint_ge16384;
     uint64_t hint_pairs;
+    uint32_t hint_large;                 /* large splats of the last harvested frame (listed or only counted) */
+    uint32_t reserved;
     splat_policy_frame_status status[SPLAT_POLICY_RING];
 } splat_policy_input;
 
@@ -102,7 +107,7 @@ typedef struct splat_policy_decision {
     uint32_t select_grid;                /* workgroups of the near selection's launch */
     uint32_t grid_big, grid_mid, grid_long;   /* prefixes of the longest-first order the sort launches cover */
     int32_t pair_walk;
-    int32_t reserved;
+    int32_t use_large_list;              /* K1 lists its large splats and bin_large_kernel bins them tile by tile (else K1 expands them itself) */
     splat_policy_state next;
 } splat_policy_decision;
 

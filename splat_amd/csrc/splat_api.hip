@@ -160,7 +160,7 @@ struct splat_ctx {
     // records per step with packed math (fewer issue slots: for frames whose compositor is bound by its longest
     // list's single wave, not by throughput), -1 = by the last harvested frame's pairs per key of the longest list
     int pair_mode = -1;                    // SPLAT_PAIR_BLEND
-    uint64_t hint_pairs = 0; unsigned int hint_maxlen = 0;
+    uint64_t hint_pairs = 0; unsigned int hint_maxlen = 0; unsigned int hint_large = 0;
     unsigned int grid_big = 0, grid_mid = 0, grid_long = 0;      // what the frame being enqueued uses
     FrameStatus last{};
     // frames skipped on the device (their storage outgrown: see finish_frame).  A synchronous call redoes its own
@@ -202,6 +202,7 @@ struct splat_ctx {
     // One-pass binning: splats of more tiles than this (and every splat wider or taller than K1's 32 x 32-tile window) go to the
     // frame's large list and are binned tile by tile behind K1 (bin_large_kernel).  SPLAT_LARGE_TILES: 0 = the window alone
     // decides, < 0 = no list at all (K1's blocks expand close-ups themselves, one atomic per pair: the round-5 path).
+    int large_list_min = 256;            // SPLAT_LARGE_LIST_MIN: large splats a recent frame must have had for frames to keep the list (splat_policy.h)
     int large_tiles = 128;               // (C2 / C3 / C5, bench pose and from inside: 96-128 best of 0..1024, profiles/r07_large_splats.txt)
     int count_first = 1;                   // SPLAT_OPT_COUNT_FIRST: 0 only slots without a layout; 1 + the 64 moving frames behind a run of frames that outgrew
                                            // their regions (three in four of the recent ones); 2 + every frame whose camera moved by more than half a degree
@@ -388,7 +389,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 4) c->keys2_want = std::max<uint64_t>(c->keys2_want, st.n_long_keys);
     if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
-    if (st.overflow == 0) { c->hint_pairs = st.n_pairs; c->hint_maxlen = st.max_tile_len; }
+    if (st.overflow == 0) { c->hint_pairs = st.n_pairs; c->hint_maxlen = st.max_tile_len; c->hint_large = st.n_large; }
     s.used = false;
 }
 
@@ -716,6 +717,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         pk.start_hints = c->start_hints; pk.count_first = c->count_first; pk.overflow_redo = c->overflow_redo; pk.early_min = c->early_min;
         pk.early_eps = c->early_eps; pk.near_cap = c->near_cap; pk.fused_sort_max = c->fused_sort_max; pk.sort_in_comp = c->sort_in_comp;
         pk.pair_mode = c->pair_mode; pk.pipeline = c->pipeline; pk.tight_grids = c->tight_grids ? 1 : 0;
+        pk.large_list_min = c->large_tiles < 0 ? -1 : c->large_list_min;
         splat_policy_input pi;
         std::memset(&pi, 0, sizeof pi);
         std::memcpy(pi.view, c->fc.view, sizeof pi.view); std::memcpy(pi.proj, c->fc.proj, sizeof pi.proj);
@@ -726,7 +728,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         pi.layout_valid = s.layout_valid ? 1 : 0; pi.layout_cam = s.layout_cam[s.flip];
         pi.awaited = awaited ? 1 : 0; pi.idle = c->idle ? 1 : 0; pi.has_keys2 = s.keys2 != nullptr ? 1 : 0; pi.n_tiles = m;
         pi.sort_hint = c->sort_hint ? 1 : 0; pi.hint_maxlen = c->hint_maxlen; pi.hint_ge2048 = c->hint_ge2048; pi.hint_ge8192 = c->hint_ge8192;
-        pi.hint_ge16384 = c->hint_ge16384; pi.hint_pairs = c->hint_pairs;
+        pi.hint_ge16384 = c->hint_ge16384; pi.hint_pairs = c->hint_pairs; pi.hint_large = c->hint_large;
         for (int q = 0; q < EV_RING; ++q) {      // (the scans of frames in flight write these words to the host: a peek, no wait)
             const volatile FrameStatus* hs = &c->h_status[q];
             pi.status[q].in_flight = c->ring[q].used ? 1u : 0u; pi.status[q].arrived = hs->arrived;
@@ -760,6 +762,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     // empty layout drops every key and counts every pair -- and builds regions that fit exactly this camera.
     unsigned int *cursors = s.counts, *layout = nullptr;
     const uint64_t cam_hash = pd.cam_hash;      // (what places the Gaussians on the target: the camera and the slab)
+    uint4* const large_list = pd.use_large_list ? s.large_list : nullptr;       // (no list: K1's blocks expand their close-ups themselves, and only count the large splats)
     c->fc.start_hints = pd.start_hints_mode; c->fc.start_light = pd.start_light; c->fc.early_min = pd.early_min;
     if (c->fc.bucket_cap) {
         // COUNT FIRST (pd.count_first): the frame counts its pairs per tile (K1's count flavour: geometry planes only, no SH, no
@@ -769,8 +772,8 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
             const int into = s.layout_valid ? s.flip : 1;
             HIP_TRY(c, hipMemsetAsync(s.redo_cursors, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));     // (the redo's buffer: a count-first frame has no redo)
             launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout, true,
-                              s.large_list, s.large_count);
-            launch_bin_large(bs, c->fc, s.large_list, s.large_count, s.redo_cursors, s.keys, d_st, true);
+                              large_list, s.large_count);
+            launch_bin_large(bs, c->fc, large_list, s.large_count, s.redo_cursors, s.keys, d_st, true);
             launch_layout(bs, m, s.redo_cursors, c->zero_layout, into ? s.lay_b : s.lay_a, into ? s.counts_b : s.counts, c->fc.bucket_cap, nullptr, nullptr, c->region_spare,
                           nullptr, s.large_count);
             s.flip = into; s.layout_valid = true;
@@ -781,8 +784,8 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     }
     HIP_TRY(c, mark(0, bs));
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, layout, false,
-                      s.large_list, s.large_count);
-    if (c->fc.bucket_cap) launch_bin_large(bs, c->fc, s.large_list, s.large_count, cursors, s.keys, d_st, false);     // (the large splats K1 listed, tile by tile)
+                      large_list, s.large_count);
+    if (c->fc.bucket_cap) launch_bin_large(bs, c->fc, large_list, s.large_count, cursors, s.keys, d_st, false);     // (the large splats K1 listed, tile by tile)
     HIP_TRY(c, mark(1, bs));
     c->grid_big = pd.grid_big; c->grid_mid = pd.grid_mid; c->grid_long = pd.grid_long;      // (what the sort launches cover; the scan validates)
     // (one-pass binning: a second workgroup of the scan's launch builds the regions of the NEXT frame on this binning
@@ -815,8 +818,8 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         fr.redo_only = 1;
         launch_layout(bs, m, cursors, layout, s.redo_layout, s.redo_cursors, c->fc.bucket_cap, nullptr, nullptr, c->region_spare, d_st);
         launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, s.redo_layout, false,
-                          s.large_list, s.large_count);
-        launch_bin_large(bs, fr, s.large_list, s.large_count, s.redo_cursors, s.keys, d_st, false);
+                          large_list, s.large_count);
+        launch_bin_large(bs, fr, large_list, s.large_count, s.redo_cursors, s.keys, d_st, false);
         launch_scan(bs, m, s.redo_cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], s.redo_layout,
                     nullptr, nullptr, c->region_spare, true, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull), s.large_count);
     }
@@ -1316,6 +1319,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         c->env_pinned |= 1u << SPLAT_OPT_KEYS_PER_GAUSSIAN;
     }
     if (const char* lt = std::getenv("SPLAT_LARGE_TILES")) c->large_tiles = std::max(-1, std::min(1 << 20, std::atoi(lt)));
+    if (const char* lm = std::getenv("SPLAT_LARGE_LIST_MIN")) c->large_list_min = std::max(-1, std::atoi(lm));
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
@@ -1523,6 +1527,13 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     // another scene under every tile: what the walks of the old one needed says nothing (near selection, start hints)
     if (c->need_hint && c->m_alloc) (void)fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc);
     reset_policy(c);
+    // The key buffers of one-pass binning depend on the scene's size only: made here, not inside the first frame's call (1.5 GB
+    // of hipMalloc on C3).  A failure is left to the first frame, which retries smaller sizes (prepare_binning).
+    if (c->use_buckets && !c->cfg.pair_capacity && !c->bucket_failed) {
+        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(c->cap, region_capacity_for(c, default_region_multiplier(c))), KEY_ENTRIES_MAX);
+        const uint64_t want2 = std::min<uint64_t>(std::max<uint64_t>(c->cap2, default_keys2_capacity(c)), KEY_ENTRIES_MAX);
+        if ((want + want2) * 8ull * (uint64_t)slots_in_use(c) <= c->bucket_bytes && ensure_keys(c, want, want2) != SPLAT_OK) (void)hipGetLastError();
+    }
     return SPLAT_OK;
 }
 

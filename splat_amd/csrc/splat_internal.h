@@ -75,7 +75,8 @@ struct FrameStatus {
     unsigned long long n_sort_fallback; // tiles whose radix-by-depth order failed the 64-bit check (depth ties): bitonic redo
     unsigned int n_near_tiles;       // tiles whose long list (> 2048 keys) was served by its selected nearest keys (select_near) ...
     unsigned int n_near_fallback;    // ... and those among them that needed the whole list sorted after all
-    unsigned long long n_iter_blend; //                                       phase B (exact blend)
+    unsigned int n_large;            // one-pass binning: splats K1 found large this frame (listed for bin_large_kernel, or only counted)
+    unsigned int reserved0;
     unsigned int n_ge8192, n_ge2048;    // tiles whose list has >= 8192 / >= 2048 keys: in `order` they are a prefix
     unsigned int n_ge16384;             // likewise >= 16384 (the lists sorted as several runs and merged)
     unsigned int redone;                // 1: the frame outgrew its regions and was binned again on the device (overflow redo); written by every scan

@@ -563,7 +563,14 @@ struct BucketBinner {
         // splat wider or taller than that is a close-up for the slow path below.  (The limit used to be 64 tiles, one
         // lane-spread round; at the C3 bench pose the 0.45 % of the Gaussians above it put 8 % of the pairs -- and three
         // more barriers, a serial prefix and an exposed atomic round trip -- into most blocks: K1 0.169 -> 0.13 ms.)
-        small = vis && w <= HASH_DIM && (ty1 - ty0) < HASH_DIM && (large_list == nullptr || large_tiles <= 0 || ntiles <= large_tiles); big = vis && !small;
+        const bool fits = w <= HASH_DIM && (ty1 - ty0) < HASH_DIM, few = large_tiles <= 0 || ntiles <= large_tiles;
+        small = vis && fits && (large_list == nullptr || few); big = vis && !small;
+        if (large_list == nullptr && large_count != nullptr) {
+            // no list this frame (the host found too few large splats lately to pay for bin_large_kernel's launch): they are
+            // still COUNTED, so that the host sees when that changes
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(vis && !(fits && few));
+            if (lm != 0ull && (threadIdx.x & 63u) == 0u) (void)__hip_atomic_fetch_add(large_count, (unsigned int)__builtin_popcountll(lm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         {   // block statistics and bounding box of the aggregated rectangles: wave reduce, LDS atomics by lane 0
             const unsigned int nv = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vis));
             const unsigned int ns = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(singular));
@@ -1186,7 +1193,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         const unsigned int ge16384 = start[cls_of(16384u)] + hist[cls_of(16384u)];
         status->n_ge8192 = ge8192; status->n_ge2048 = ge2048; status->n_ge16384 = ge16384;
         if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid || ge16384 > grid_long)) status->overflow = 3u;
-        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
+        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_large = 0; status->reserved0 = 0;
         status->redone = 0u;                          // (the ring entry may have carried a redone one-pass frame before)
         status->arrived = 1u;
         if (host_status) *host_status = *status;      // (n_visible / n_singular: K1's atomics, complete before this kernel)
@@ -1324,8 +1331,10 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int* __restrict__ off2, unsigned int cap2, unsigned int* __restrict__ large_count) {
     constexpr int NCLS = 64;
     if (redo_only && status->overflow != 2u) return;       // (the second scan of a frame that was binned again: see enqueue_frame)
-    // (the frame's large-splat list has been binned -- bin_large_kernel, in front of this launch: empty for the slot's next K1)
-    if (large_count != nullptr && blockIdx.x == 0u && threadIdx.x == 0u) *large_count = 0u;
+    // (the frame's large-splat list has been binned -- bin_large_kernel, in front of this launch: empty for the slot's next K1;
+    // how many there were goes into the status: the host decides from it whether the next frames keep a list at all)
+    unsigned int n_large_seen = 0u;
+    if (large_count != nullptr && blockIdx.x == 0u && threadIdx.x == 0u) { n_large_seen = *large_count; *large_count = 0u; }
     // Workgroup 1 of the launch (when there is one) builds the regions of the next frame on this binning stream from
     // the same cursors, beside the scan: no launch of its own, nothing added to the chain K1 -> scan -> sort.
     if (blockIdx.x == 1u) {
@@ -1438,7 +1447,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         if (off2 != nullptr && pool2 > cap2 && status->overflow == 0u) status->overflow = 4u;
         // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
         status->n_visible = 0; status->n_singular = 0;
-        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_iter_blend = 0;
+        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_large = n_large_seen; status->reserved0 = 0;
         status->redone = redo_only ? 1u : 0u;  // (1: this frame outgrew its regions and was binned again on the device)
         status->n_blocks_culled = 0;
         // ... and delivers it to the host: everything an asynchronous frame reports is decided here (layout_total, the
@@ -3215,7 +3224,7 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
     if (!n) return;
     if (!bounds || !blockinfo) fc.cull_blocks = 0;
     if (!blockinfo || !layout) fc.bucket_cap = 0;
-    if (!large_list || !large_count || !fc.bucket_cap) { large_list = nullptr; large_count = nullptr; }
+    if (!large_count || !fc.bucket_cap) { large_list = nullptr; large_count = nullptr; }      // (a counter without a list: large splats are only counted)
     const dim3 grid(blocks_for(n, 256)), block(256);
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status, large_list, large_count); };
     if (fc.bucket_cap && count_only) { if (fc.corrected) go(preprocess_kernel<true, true, true>); else go(preprocess_kernel<true, false, true>); }

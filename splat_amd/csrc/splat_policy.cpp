@@ -73,6 +73,7 @@ void splat_policy_default_knobs(splat_policy_knobs* k) {
     std::memset(k, 0, sizeof *k);
     k->start_hints = 2; k->count_first = 1; k->overflow_redo = 1; k->early_min = 768; k->early_eps = 1e-6f;
     k->near_cap = 2048u; k->fused_sort_max = 2048u; k->sort_in_comp = -1; k->pair_mode = -1; k->pipeline = 6; k->tight_grids = 0;
+    k->large_list_min = 256;
 }
 
 void splat_policy_struct_sizes(uint64_t sizes[4]) {
@@ -202,6 +203,16 @@ int splat_policy_decide(const splat_policy_knobs* kp, const splat_policy_state* 
     // (C2 316, an eighth-of-a-frame slab 92, C1 36) take the paired one; measured crossover between 316 and 737
     d.pair_walk = k.pair_mode >= 0 ? (k.pair_mode != 0 ? 1 : 0)
                                    : ((in.hint_maxlen != 0 && in.hint_pairs < (uint64_t)SPLAT_POLICY_PAIR_WALK_RATIO * (uint64_t)in.hint_maxlen) ? 1 : 0);
+    // ---- LARGE LIST: K1 lists the splats of hundreds of tiles and bin_large_kernel bins them tile by tile -- one more launch on
+    // the frame's chain (~1 us when the list is empty, ~5 us of dependent round trips for a few dozen entries).  Worth it from a
+    // few hundred large splats up (C3's bench pose has 900: K1 0.152 -> 0.134 ms; from inside the cloud thousands: 1.1 -> 0.18),
+    // not for the 33 of C2's bench pose (8390 -> 8170 frames/s with the list).  K1 counts its large splats either way; nothing
+    // known yet, or a camera jump: keep the list.  Half the threshold to let go again.
+    if (k.large_list_min < 0 || !in.one_pass) st.large_on = 0u;
+    else if (k.large_list_min == 0 || !in.sort_hint || d.cam_jumped) st.large_on = 1u;
+    else if (sp->large_on) st.large_on = in.hint_large >= (uint32_t)k.large_list_min / 2u ? 1u : 0u;
+    else st.large_on = in.hint_large >= (uint32_t)k.large_list_min ? 1u : 0u;
+    d.use_large_list = (int32_t)st.large_on;
     *out = d;
     return 0;
 }

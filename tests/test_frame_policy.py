@@ -23,12 +23,12 @@ DELTA_SLOW, DELTA_CREEP, DELTA_JUMP = 0.009, 0.003, 0.2
 class Knobs(C.Structure):
     _fields_ = [("start_hints", C.c_int32), ("count_first", C.c_int32), ("overflow_redo", C.c_int32), ("early_min", C.c_int32),
                 ("early_eps", C.c_float), ("near_cap", C.c_uint32), ("fused_sort_max", C.c_uint32), ("sort_in_comp", C.c_int32),
-                ("pair_mode", C.c_int32), ("pipeline", C.c_int32), ("tight_grids", C.c_int32)]
+                ("pair_mode", C.c_int32), ("pipeline", C.c_int32), ("tight_grids", C.c_int32), ("large_list_min", C.c_int32)]
 
 
 class State(C.Structure):
     _fields_ = [("last_cam_hash", C.c_uint64), ("still_frames", C.c_uint32), ("count_first_left", C.c_int32),
-                ("redo_armed", C.c_int32), ("reserved", C.c_uint32), ("last_view", C.c_float * 32), ("ring_kind", C.c_uint8 * RING)]
+                ("redo_armed", C.c_int32), ("large_on", C.c_uint32), ("last_view", C.c_float * 32), ("ring_kind", C.c_uint8 * RING)]
 
 
 class FrameStatus(C.Structure):
@@ -42,7 +42,7 @@ class Input(C.Structure):
                 ("one_pass", C.c_int32), ("layout_valid", C.c_int32), ("awaited", C.c_int32), ("layout_cam", C.c_uint64),
                 ("idle", C.c_int32), ("has_keys2", C.c_int32), ("n_tiles", C.c_uint32), ("sort_hint", C.c_int32),
                 ("hint_maxlen", C.c_uint32), ("hint_ge2048", C.c_uint32), ("hint_ge8192", C.c_uint32), ("hint_ge16384", C.c_uint32),
-                ("hint_pairs", C.c_uint64), ("status", FrameStatus * RING)]
+                ("hint_pairs", C.c_uint64), ("hint_large", C.c_uint32), ("reserved", C.c_uint32), ("status", FrameStatus * RING)]
 
 
 class Decision(C.Structure):
@@ -50,7 +50,7 @@ class Decision(C.Structure):
                 ("start_light", C.c_int32), ("early_min", C.c_int32), ("hint_radius", C.c_int32), ("count_first", C.c_int32),
                 ("moved", C.c_int32), ("redo", C.c_int32), ("ring_kind", C.c_int32), ("solo", C.c_int32), ("comp_sorts", C.c_int32),
                 ("near_cap", C.c_uint32), ("select_grid", C.c_uint32), ("grid_big", C.c_uint32), ("grid_mid", C.c_uint32),
-                ("grid_long", C.c_uint32), ("pair_walk", C.c_int32), ("reserved", C.c_int32), ("next", State)]
+                ("grid_long", C.c_uint32), ("pair_walk", C.c_int32), ("use_large_list", C.c_int32), ("next", State)]
 
 
 @pytest.fixture(scope="module")
@@ -113,7 +113,7 @@ class Driver:
         self.frame = 0
         self.slots = [dict(valid=False, cam=0) for _ in range(4)]
         self.status = [dict(in_flight=0, arrived=0, overflow=0, redone=0) for _ in range(RING)]
-        self.hints = dict(sort_hint=0, hint_maxlen=0, hint_ge2048=0, hint_ge8192=0, hint_ge16384=0, hint_pairs=0)
+        self.hints = dict(sort_hint=0, hint_maxlen=0, hint_ge2048=0, hint_ge8192=0, hint_ge16384=0, hint_pairs=0, hint_large=0)
         self.n_tiles = 8160
         self.log = []
 
@@ -508,3 +508,29 @@ def test_slab_and_target_are_part_of_the_camera(L):
     i.lowpass = 0.01
     i.view[3] = float("nan")
     assert L.splat_policy_decide(k, st, i, d) == 0 and d.cam_jumped == 1 and d.cam_delta == 1.0
+
+
+def test_large_list_is_kept_from_a_few_hundred_large_splats_with_hysteresis(L):
+    """K1 lists its large splats for bin_large_kernel only while recent frames had enough of them to pay for the launch (256;
+    128 to let go again); nothing known yet, or a camera jump, keeps the list; the knob's 0 / negative force it on / off"""
+    D = Driver(L)
+    assert D.step(0.0).use_large_list == 1                 # nothing known
+    D.hints.update(sort_hint=1, hint_large=33)             # C2's bench pose
+    D.settle()
+    assert D.log[-1].use_large_list == 0
+    seen = []
+    for n in (255, 256, 200, 128, 127, 255, 256):
+        D.hints["hint_large"] = n
+        seen.append(D.step(0.0).use_large_list)
+    assert seen == [0, 1, 1, 1, 0, 0, 1]
+    D.hints["hint_large"] = 0
+    assert D.step(0.0).use_large_list == 0
+    assert D.step(1.5).use_large_list == 1                 # a jump (into the cloud, for all the host knows)
+    assert D.step(1.5).use_large_list == 0                 # ... and the frame behind it goes by what was counted again
+    d = D.step(1.5, one_pass=0)
+    assert d.use_large_list == 0                           # two-pass binning has no list
+    for knob, want in ((0, 1), (-1, 0)):
+        D2 = Driver(L, large_list_min=knob)
+        D2.hints.update(sort_hint=1, hint_large=100000 if knob < 0 else 0)
+        D2.settle()
+        assert D2.step(0.3).use_large_list == want and D2.step(2.0).use_large_list == want

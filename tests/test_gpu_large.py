@@ -100,9 +100,11 @@ def test_frames_are_byte_identical_with_and_without_the_list_through_every_chain
     h, w = 360, 640
     seq = [POSES[0], POSES[0], POSES[1], POSES[1], POSES[2], POSES[0], POSES[3], POSES[3], POSES[1], POSES[0], POSES[2], POSES[2]]
     out = {}
-    for lt in (-1, None, 1):
+    # (-1: no list ever; default; 1: every splat of two tiles or more through the list; "lazy": the default threshold but a list only
+    # after a frame with a million large splats, i.e. on the first frames and behind jumps -- the policy's on / off switch)
+    for lt in (-1, None, 1, "lazy"):
         for redo in (1, 2):
-            r = renderer(lt, SPLAT_REGION_SPARE=1)
+            r = renderer(None, SPLAT_REGION_SPARE=1, SPLAT_LARGE_LIST_MIN=1000000) if lt == "lazy" else renderer(lt, SPLAT_REGION_SPARE=1)
             try:
                 r.set_option(_lib.OPT_OVERFLOW_REDO, redo)
                 g.compute_cov3d(r)
@@ -137,7 +139,7 @@ def test_frames_are_byte_identical_with_and_without_the_list_through_every_chain
         if frames is not None:
             for k, (a, b) in enumerate(zip(frames, ref_frames)):
                 assert np.array_equal(a, b), (key, k)
-    assert out[(None, 2)][0] is not None and out[(1, 2)][0] is not None
+    assert out[(None, 2)][0] is not None and out[(1, 2)][0] is not None and out[("lazy", 2)][0] is not None
 
 
 def test_count_only_pass_counts_the_large_splats():
