@@ -965,8 +965,10 @@ def main():
                              "pairs_equal": bool(int(tot[1]) == int(ost.n_tile_pairs) and int(tot[0]) == int(ost.n_visible)),
                              "tolerance_lsb": 1 if args.mode == "exact" else 2,
                              "against": "oracle/ (C++ restatement of src/gaussians.rs + src/pipelines.rs + src/camera.rs); "
-                                        "euc conventions ASSUMED, not pinned: y_up=1 from notes/screenshot.png (contradicts "
-                                        "SURVEY appendix B's recollection of CoordinateMode::VULKAN = y down), pixel-centre "
+                                        "euc conventions ASSUMED, not pinned: y_up=1 from notes/screenshot.png and from the Python "
+                                        "prototype the Rust was ported from, which maps NDC to pixels with (1 - y) * height / 2 "
+                                        "(notes/util.py:101-113) -- two inferences, no pin (SURVEY appendix B recollects "
+                                        "CoordinateMode::VULKAN = y down); pixel-centre "
                                         "samples, z-clip [0,1], inclusive rectangle -- euc@290e14c is not in the image"}
             # (--mode fast: within 1 of the exact frame by construction -- checked below -- and the exact frame within 1 of the
             # oracle through the exponential's last place: 2 in principle, 1 in every frame measured)

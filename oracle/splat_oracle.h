@@ -33,7 +33,7 @@ extern "C" {
 
 /* euc conventions that decide pixels. */
 typedef struct {
-    int32_t y_up;          /* 1: NDC +y is row 0 (default, pinned by screenshot) */
+    int32_t y_up;          /* 1: NDC +y is row 0 (default: INFERRED from notes/screenshot.png and notes/util.py:101-113, not pinned) */
     int32_t sample_half;   /* 1: sample at pixel centre (x+.5,y+.5) (default)   */
     int32_t zclip;         /* 1: cull quads whose ndc.z is outside [zmin,zmax]  */
     float zmin, zmax;      /* default 0..1 (euc CoordinateMode::VULKAN)         */
