@@ -35,6 +35,8 @@ pub const SPLAT_OPT_START_HINTS: i32 = 18;
 pub const SPLAT_OPT_HOST_ZERO_COPY: i32 = 19;
 pub const SPLAT_OPT_KEYS_PER_GAUSSIAN: i32 = 20;
 pub const SPLAT_OPT_COUNT_FIRST: i32 = 21;
+pub const SPLAT_OPT_LARGE_SPLAT_TILES: i32 = 22;
+pub const SPLAT_OPT_LARGE_LIST_MIN: i32 = 23;
 /// SPLAT_ABI_VERSION of the header this file mirrors; compared with splat_abi_version() before the first call
 pub const SPLAT_ABI_VERSION: u32 = 6;
 

@@ -126,6 +126,8 @@ OPT_START_HINTS = 18
 OPT_HOST_ZERO_COPY = 19
 OPT_KEYS_PER_GAUSSIAN = 20
 OPT_COUNT_FIRST = 21
+OPT_LARGE_SPLAT_TILES = 22
+OPT_LARGE_LIST_MIN = 23
 ABI_VERSION = 6          # SPLAT_ABI_VERSION of the header these structures were written against
 
 _LIB = None

@@ -1205,6 +1205,8 @@ bool store_option(splat_ctx* c, int opt, double v, bool dry = false) {
         case SPLAT_OPT_HOST_ZERO_COPY: if (v != 0.0 && v != 1.0) return false; SPLAT_DRY_; c->host_zero_copy = (int)v; return true;
         case SPLAT_OPT_COUNT_FIRST: if (v != 0.0 && v != 1.0 && v != 2.0) return false; SPLAT_DRY_; c->count_first = (int)v; return true;
         case SPLAT_OPT_KEYS_PER_GAUSSIAN: if (v != 0.0 && (v < 4.0 || v > 256.0)) return false; SPLAT_DRY_; c->keys_per_gaussian = (unsigned int)v; return true;
+        case SPLAT_OPT_LARGE_SPLAT_TILES: if (v < -1.0 || v > 1048576.0 || v != std::floor(v)) return false; SPLAT_DRY_; c->large_tiles = (int)v; return true;
+        case SPLAT_OPT_LARGE_LIST_MIN: if (v < -1.0 || v > 1e9 || v != std::floor(v)) return false; SPLAT_DRY_; c->large_list_min = (int)v; return true;
         default: return false;
     }
 #undef SPLAT_DRY_
@@ -1232,6 +1234,8 @@ bool load_option(const splat_ctx* c, int opt, double* v) {
         case SPLAT_OPT_HOST_ZERO_COPY: *v = c->host_zero_copy; return true;
         case SPLAT_OPT_KEYS_PER_GAUSSIAN: *v = c->keys_per_gaussian; return true;
         case SPLAT_OPT_COUNT_FIRST: *v = c->count_first; return true;
+        case SPLAT_OPT_LARGE_SPLAT_TILES: *v = c->large_tiles; return true;
+        case SPLAT_OPT_LARGE_LIST_MIN: *v = c->large_list_min; return true;
         default: return false;
     }
 }
@@ -1318,8 +1322,8 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
         c->keys_per_gaussian = v <= 0 ? 0u : (unsigned int)std::min(256, std::max(4, v));
         c->env_pinned |= 1u << SPLAT_OPT_KEYS_PER_GAUSSIAN;
     }
-    if (const char* lt = std::getenv("SPLAT_LARGE_TILES")) c->large_tiles = std::max(-1, std::min(1 << 20, std::atoi(lt)));
-    if (const char* lm = std::getenv("SPLAT_LARGE_LIST_MIN")) c->large_list_min = std::max(-1, std::atoi(lm));
+    option_from_env(c, SPLAT_OPT_LARGE_SPLAT_TILES, "SPLAT_LARGE_TILES", -1, 1048576);
+    option_from_env(c, SPLAT_OPT_LARGE_LIST_MIN, "SPLAT_LARGE_LIST_MIN", -1, 1e9);
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));
@@ -1451,6 +1455,14 @@ int splat_set_option(splat_ctx* c, int32_t option, double value) {
     // (another selection size: what the tiles' walks needed under the old one is forgotten)
     if (option == SPLAT_OPT_NEAR_SELECT_KEYS && c->need_hint && c->m_alloc)
         HIP_TRY(c, fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc));
+    // (the large list switched on with a scene in place: its buffers exist from now on -- splat_upload_scene makes them otherwise)
+    if (option == SPLAT_OPT_LARGE_SPLAT_TILES && c->large_tiles >= 0 && c->n != 0)
+        for (Slot& sl : c->slots)
+            if (!sl.large_list) {
+                HIP_TRY(c, dmalloc(c, &sl.large_list, sizeof(uint4) * c->n));
+                if (!sl.large_count) HIP_TRY(c, dmalloc(c, &sl.large_count, sizeof(unsigned int) * 4));
+                HIP_TRY(c, fill_now(sl.large_count, 0, sizeof(unsigned int) * 4));
+            }
     return SPLAT_OK;
 }
 
@@ -1527,6 +1539,9 @@ int splat_upload_scene(splat_ctx* c, uint64_t n, const float* pos4, const float*
     // another scene under every tile: what the walks of the old one needed says nothing (near selection, start hints)
     if (c->need_hint && c->m_alloc) (void)fill_now(c->need_hint, 0, sizeof(unsigned int) * 9u * (size_t)c->m_alloc);
     reset_policy(c);
+    // The per-tile arrays (a few hundred KB per frame slot at 4K) exist before the first frame as well: fifty small allocations
+    // and six synchronous fills were a third of its call.  A larger target than 3840 x 2160 makes them again, as always.
+    if (c->m_alloc == 0 && ensure_bins(c, 240u * 135u) != SPLAT_OK) (void)hipGetLastError();
     // The key buffers of one-pass binning depend on the scene's size only: made here, not inside the first frame's call (1.5 GB
     // of hipMalloc on C3).  A failure is left to the first frame, which retries smaller sizes (prepare_binning).
     if (c->use_buckets && !c->cfg.pair_capacity && !c->bucket_failed) {

@@ -4,9 +4,10 @@
 the frame rate (device-resident asynchronous frames, as bench.py's `value`) with every option on its default / automatic
 setting, and with ONE option at a time forced to each of its other settings:
     pair walk (auto | 0 | 1), sort in compositor (auto | 0 | 1), near selection (2048 | 0), early-out min list (768 | 384 | 1536),
-    overflow redo (adaptive | 0 | 2), start hints (2 | 0 | 1), count first (default | the other two of 0, 1, 2).
+    overflow redo (adaptive | 0 | 2), start hints (2 | 0 | 1), count first (default | the other two of 0, 1, 2),
+    large-splat list threshold (128 tiles | no list | window only | 512), large list kept from (256 large splats | always).
 A setting under which the device skipped frames inside the timed loop is no alternative (a skipped frame costs nothing).
-Writes the table as JSON (profiles/r06_knob_matrix.json is this tool's output); tests/test_gpu_knobs.py holds a subset live.
+Writes the table as JSON (profiles/r07_knob_matrix.json is this tool's output); tests/test_gpu_knobs.py holds a subset live.
 usage: knob_matrix.py [--scenes C2,C3] [--motions rest,10deg] [--frames 100] [--out file.json]"""
 import json, math, sys, time
 sys.path.insert(0, ".")
@@ -18,7 +19,8 @@ from bench import WORKLOADS, make_scene
 KNOBS = [("pair_walk", L.OPT_PAIR_WALK, -1, (0, 1)), ("sort_in_compositor", L.OPT_SORT_IN_COMPOSITOR, -1, (0, 1)),
          ("near_select_keys", L.OPT_NEAR_SELECT_KEYS, 2048, (0,)), ("early_out_min_list", L.OPT_EARLY_OUT_MIN_LIST, 768, (384, 1536)),
          ("overflow_redo", L.OPT_OVERFLOW_REDO, 1, (0, 2)), ("start_hints", L.OPT_START_HINTS, 2, (0, 1)),
-         ("count_first", L.OPT_COUNT_FIRST, None, (0, 1, 2))]
+         ("count_first", L.OPT_COUNT_FIRST, None, (0, 1, 2)),
+         ("large_splat_tiles", L.OPT_LARGE_SPLAT_TILES, 128, (-1, 0, 512)), ("large_list_min", L.OPT_LARGE_LIST_MIN, 256, (0,))]
 MOTIONS = ("rest", "1deg", "10deg", "inside", "random")
 
 
