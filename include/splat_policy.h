@@ -45,7 +45,8 @@ typedef struct splat_policy_knobs {      /* the context's options that decisions
     int32_t pipeline;                    /* SPLAT_OPT_PIPELINE_DEPTH (0: everything on one stream) */
     int32_t tight_grids;                 /* debug: sort launches sized with no margin */
     int32_t large_list_min;              /* large splats (SPLAT_LARGE_TILES) a recent frame must have had for frames to keep a large list:
-                                            0 = always, < 0 = never (K1's blocks expand close-ups themselves) */
+                                            0 = always, < 0 = never (K1's blocks expand close-ups themselves).  An asynchronous frame
+                                            of a camera AT REST keeps it only from four times as many splats outside K1's window */
 } splat_policy_knobs;
 
 typedef struct splat_policy_state {      /* carried from frame to frame; all zeros = a fresh context / scene / target */
@@ -85,7 +86,7 @@ typedef struct splat_policy_input {
     uint32_t hint_maxlen, hint_ge2048, hint_ge8192, hint_ge16384;
     uint64_t hint_pairs;
     uint32_t hint_large;                 /* large splats of the last harvested frame (listed or only counted) */
-    uint32_t reserved;
+    uint32_t hint_window;                /* ... those among them outside K1's 32 x 32-tile window: without a list, one global atomic per pair */
     splat_policy_frame_status status[SPLAT_POLICY_RING];
 } splat_policy_input;
 

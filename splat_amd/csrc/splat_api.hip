@@ -160,7 +160,7 @@ struct splat_ctx {
     // records per step with packed math (fewer issue slots: for frames whose compositor is bound by its longest
     // list's single wave, not by throughput), -1 = by the last harvested frame's pairs per key of the longest list
     int pair_mode = -1;                    // SPLAT_PAIR_BLEND
-    uint64_t hint_pairs = 0; unsigned int hint_maxlen = 0; unsigned int hint_large = 0;
+    uint64_t hint_pairs = 0; unsigned int hint_maxlen = 0; unsigned int hint_large = 0, hint_window = 0;
     unsigned int grid_big = 0, grid_mid = 0, grid_long = 0;      // what the frame being enqueued uses
     FrameStatus last{};
     // frames skipped on the device (their storage outgrown: see finish_frame).  A synchronous call redoes its own
@@ -389,7 +389,7 @@ void harvest(splat_ctx* c, int r) {
     if (st.overflow == 3) c->sort_grid_miss = true;
     if (st.overflow == 4) c->keys2_want = std::max<uint64_t>(c->keys2_want, st.n_long_keys);
     if (st.overflow == 0 || st.overflow == 3) { c->sort_hint = true; c->hint_ge8192 = st.n_ge8192; c->hint_ge2048 = st.n_ge2048; c->hint_ge16384 = st.n_ge16384; }
-    if (st.overflow == 0) { c->hint_pairs = st.n_pairs; c->hint_maxlen = st.max_tile_len; c->hint_large = st.n_large; }
+    if (st.overflow == 0) { c->hint_pairs = st.n_pairs; c->hint_maxlen = st.max_tile_len; c->hint_large = st.n_large; c->hint_window = st.n_window; }
     s.used = false;
 }
 
@@ -728,7 +728,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         pi.layout_valid = s.layout_valid ? 1 : 0; pi.layout_cam = s.layout_cam[s.flip];
         pi.awaited = awaited ? 1 : 0; pi.idle = c->idle ? 1 : 0; pi.has_keys2 = s.keys2 != nullptr ? 1 : 0; pi.n_tiles = m;
         pi.sort_hint = c->sort_hint ? 1 : 0; pi.hint_maxlen = c->hint_maxlen; pi.hint_ge2048 = c->hint_ge2048; pi.hint_ge8192 = c->hint_ge8192;
-        pi.hint_ge16384 = c->hint_ge16384; pi.hint_pairs = c->hint_pairs; pi.hint_large = c->hint_large;
+        pi.hint_ge16384 = c->hint_ge16384; pi.hint_pairs = c->hint_pairs; pi.hint_large = c->hint_large; pi.hint_window = c->hint_window;
         for (int q = 0; q < EV_RING; ++q) {      // (the scans of frames in flight write these words to the host: a peek, no wait)
             const volatile FrameStatus* hs = &c->h_status[q];
             pi.status[q].in_flight = c->ring[q].used ? 1u : 0u; pi.status[q].arrived = hs->arrived;

@@ -16,6 +16,9 @@
 #ifndef SPLAT_EXP_K1DUMMY
 #define SPLAT_EXP_K1DUMMY 0    // K1: this many dummy VALU instructions per (Gaussian, tile) hand-out step (what per-pair verdicts would cost)
 #endif
+#ifndef SPLAT_EXP_SORT2
+#define SPLAT_EXP_SORT2 0      // compositor: the short lists' in-LDS sort run twice (what it costs)
+#endif
 #ifndef SPLAT_EXP_K1DROP
 #define SPLAT_EXP_K1DROP 0     // K1: 1 = close-up rectangles dropped from binning, n >= 2 = every rectangle of more than n tiles (invalid frames)
 #endif
@@ -76,7 +79,7 @@ struct FrameStatus {
     unsigned int n_near_tiles;       // tiles whose long list (> 2048 keys) was served by its selected nearest keys (select_near) ...
     unsigned int n_near_fallback;    // ... and those among them that needed the whole list sorted after all
     unsigned int n_large;            // one-pass binning: splats K1 found large this frame (listed for bin_large_kernel, or only counted)
-    unsigned int reserved0;
+    unsigned int n_window;           // ... and those among them wider or taller than K1's 32 x 32-tile window (one atomic per pair without a list)
     unsigned int n_ge8192, n_ge2048;    // tiles whose list has >= 8192 / >= 2048 keys: in `order` they are a prefix
     unsigned int n_ge16384;             // likewise >= 16384 (the lists sorted as several runs and merged)
     unsigned int redone;                // 1: the frame outgrew its regions and was binned again on the device (overflow redo); written by every scan

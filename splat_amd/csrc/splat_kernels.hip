@@ -565,11 +565,16 @@ struct BucketBinner {
         // more barriers, a serial prefix and an exposed atomic round trip -- into most blocks: K1 0.169 -> 0.13 ms.)
         const bool fits = w <= HASH_DIM && (ty1 - ty0) < HASH_DIM, few = large_tiles <= 0 || ntiles <= large_tiles;
         small = vis && fits && (large_list == nullptr || few); big = vis && !small;
-        if (large_list == nullptr && large_count != nullptr) {
-            // no list this frame (the host found too few large splats lately to pay for bin_large_kernel's launch): they are
-            // still COUNTED, so that the host sees when that changes
-            const unsigned long long lm = __builtin_amdgcn_ballot_w64(vis && !(fits && few));
-            if (lm != 0ull && (threadIdx.x & 63u) == 0u) (void)__hip_atomic_fetch_add(large_count, (unsigned int)__builtin_popcountll(lm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (large_count != nullptr) {
+            // The host decides from counts whether frames keep a list at all (include/splat_policy.h): word 1 counts the splats
+            // outside the window -- the ones a block without a list pays one atomic per pair for -- and, when there is no list this
+            // frame, word 0 the splats that would have been listed (append_large counts those itself).
+            const unsigned long long wm = __builtin_amdgcn_ballot_w64(vis && !fits);
+            if (wm != 0ull && (threadIdx.x & 63u) == 0u) (void)__hip_atomic_fetch_add(large_count + 1, (unsigned int)__builtin_popcountll(wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (large_list == nullptr) {
+                const unsigned long long lm = __builtin_amdgcn_ballot_w64(vis && !(fits && few));
+                if (lm != 0ull && (threadIdx.x & 63u) == 0u) (void)__hip_atomic_fetch_add(large_count, (unsigned int)__builtin_popcountll(lm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         {   // block statistics and bounding box of the aggregated rectangles: wave reduce, LDS atomics by lane 0
             const unsigned int nv = (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(vis));
@@ -1193,7 +1198,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(unsigned int m, unsigned int
         const unsigned int ge16384 = start[cls_of(16384u)] + hist[cls_of(16384u)];
         status->n_ge8192 = ge8192; status->n_ge2048 = ge2048; status->n_ge16384 = ge16384;
         if (status->overflow == 0 && (ge8192 > grid_big || ge2048 > grid_mid || ge16384 > grid_long)) status->overflow = 3u;
-        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_large = 0; status->reserved0 = 0;
+        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_large = 0; status->n_window = 0;
         status->redone = 0u;                          // (the ring entry may have carried a redone one-pass frame before)
         status->arrived = 1u;
         if (host_status) *host_status = *status;      // (n_visible / n_singular: K1's atomics, complete before this kernel)
@@ -1308,7 +1313,7 @@ __global__ __launch_bounds__(1024) void layout_kernel(unsigned int m, const unsi
                                                       const FrameStatus* __restrict__ redo_gate, unsigned int* __restrict__ large_count) {
     __shared__ unsigned long long wsum[16];
     if (redo_gate != nullptr && redo_gate->overflow != 2u) return;        // (a redo launch of a frame that needs none)
-    if (large_count != nullptr && threadIdx.x == 0u) *large_count = 0u;   // (a count-first frame: its count pass's list has been counted; empty for its K1)
+    if (large_count != nullptr && threadIdx.x == 0u) { large_count[0] = 0u; large_count[1] = 0u; }   // (a count-first frame: its count pass's list has been counted; empty for its K1)
     build_layout<1024>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, wsum, spare_max);
 }
 
@@ -1333,8 +1338,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
     if (redo_only && status->overflow != 2u) return;       // (the second scan of a frame that was binned again: see enqueue_frame)
     // (the frame's large-splat list has been binned -- bin_large_kernel, in front of this launch: empty for the slot's next K1;
     // how many there were goes into the status: the host decides from it whether the next frames keep a list at all)
-    unsigned int n_large_seen = 0u;
-    if (large_count != nullptr && blockIdx.x == 0u && threadIdx.x == 0u) { n_large_seen = *large_count; *large_count = 0u; }
+    unsigned int n_large_seen = 0u, n_window_seen = 0u;
+    if (large_count != nullptr && blockIdx.x == 0u && threadIdx.x == 0u) { n_large_seen = large_count[0]; n_window_seen = large_count[1]; large_count[0] = 0u; large_count[1] = 0u; }
     // Workgroup 1 of the launch (when there is one) builds the regions of the next frame on this binning stream from
     // the same cursors, beside the scan: no launch of its own, nothing added to the chain K1 -> scan -> sort.
     if (blockIdx.x == 1u) {
@@ -1447,7 +1452,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
         if (off2 != nullptr && pool2 > cap2 && status->overflow == 0u) status->overflow = 4u;
         // this kernel initialises the frame's status (nothing before it in a one-pass frame touches it) ...
         status->n_visible = 0; status->n_singular = 0;
-        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_large = n_large_seen; status->reserved0 = 0;
+        status->n_fallback = 0; status->n_sort_fallback = 0; status->n_near_tiles = 0; status->n_near_fallback = 0; status->n_large = n_large_seen; status->n_window = n_window_seen;
         status->redone = redo_only ? 1u : 0u;  // (1: this frame outgrew its regions and was binned again on the device)
         status->n_blocks_culled = 0;
         // ... and delivers it to the host: everything an asynchronous frame reports is decided here (layout_total, the
@@ -2594,6 +2599,11 @@ __device__ __forceinline__ void composite_tile(unsigned char* smem, const unsign
             }
         }
         if (own_order) {
+#if SPLAT_EXP_SORT2
+            // timing experiment: the short lists' sort run twice (same frames): what it costs the compositor
+            sort_list_in_lds<256, 2048>(smem, gin, keys + beg, n_sort, radix_min, status, orig, lds_idx, false);
+            __syncthreads();
+#endif
             sort_list_in_lds<256, 2048>(smem, gin, keys + beg, n_sort, radix_min, status, orig, lds_idx, (keep_keys & 1u) != 0u);
             __syncthreads();          // the order is in LDS, the rest of the workspace is free for the batches
         }

@@ -208,10 +208,18 @@ int splat_policy_decide(const splat_policy_knobs* kp, const splat_policy_state* 
     // few hundred large splats up (C3's bench pose has 900: K1 0.152 -> 0.134 ms; from inside the cloud thousands: 1.1 -> 0.18),
     // not for the 33 of C2's bench pose (8390 -> 8170 frames/s with the list).  K1 counts its large splats either way; nothing
     // known yet, or a camera jump: keep the list.  Half the threshold to let go again.
+    // A camera AT REST whose frames nobody waits for is the one case where the list can cost: the walks start from hints, the
+    // compositor is at its fastest, and the frame rate is the binning chain's length -- which the list's launch adds to (the
+    // trained-like surface scene at rest: 3209 frames/s without, 2958 with, 7000 splats over the threshold but only 500 outside
+    // the window; profiles/r07_knob_matrix.json).  There the list stays only for what a block cannot do well itself: a
+    // thousand splats outside the window (a camera parked inside the scene has thousands).
+    const bool rest_async = st.still_frames >= (uint32_t)SPLAT_POLICY_STILL_FRAMES && !in.awaited;
+    const uint32_t have = rest_async ? in.hint_window : in.hint_large;
+    const uint32_t need = (uint32_t)k.large_list_min * (rest_async ? 4u : 1u);
     if (k.large_list_min < 0 || !in.one_pass) st.large_on = 0u;
     else if (k.large_list_min == 0 || !in.sort_hint || d.cam_jumped) st.large_on = 1u;
-    else if (sp->large_on) st.large_on = in.hint_large >= (uint32_t)k.large_list_min / 2u ? 1u : 0u;
-    else st.large_on = in.hint_large >= (uint32_t)k.large_list_min ? 1u : 0u;
+    else if (sp->large_on) st.large_on = have >= need / 2u ? 1u : 0u;
+    else st.large_on = have >= need ? 1u : 0u;
     d.use_large_list = (int32_t)st.large_on;
     *out = d;
     return 0;

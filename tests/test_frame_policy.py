@@ -42,7 +42,7 @@ class Input(C.Structure):
                 ("one_pass", C.c_int32), ("layout_valid", C.c_int32), ("awaited", C.c_int32), ("layout_cam", C.c_uint64),
                 ("idle", C.c_int32), ("has_keys2", C.c_int32), ("n_tiles", C.c_uint32), ("sort_hint", C.c_int32),
                 ("hint_maxlen", C.c_uint32), ("hint_ge2048", C.c_uint32), ("hint_ge8192", C.c_uint32), ("hint_ge16384", C.c_uint32),
-                ("hint_pairs", C.c_uint64), ("hint_large", C.c_uint32), ("reserved", C.c_uint32), ("status", FrameStatus * RING)]
+                ("hint_pairs", C.c_uint64), ("hint_large", C.c_uint32), ("hint_window", C.c_uint32), ("status", FrameStatus * RING)]
 
 
 class Decision(C.Structure):
@@ -113,7 +113,7 @@ class Driver:
         self.frame = 0
         self.slots = [dict(valid=False, cam=0) for _ in range(4)]
         self.status = [dict(in_flight=0, arrived=0, overflow=0, redone=0) for _ in range(RING)]
-        self.hints = dict(sort_hint=0, hint_maxlen=0, hint_ge2048=0, hint_ge8192=0, hint_ge16384=0, hint_pairs=0, hint_large=0)
+        self.hints = dict(sort_hint=0, hint_maxlen=0, hint_ge2048=0, hint_ge8192=0, hint_ge16384=0, hint_pairs=0, hint_large=0, hint_window=0)
         self.n_tiles = 8160
         self.log = []
 
@@ -511,26 +511,46 @@ def test_slab_and_target_are_part_of_the_camera(L):
 
 
 def test_large_list_is_kept_from_a_few_hundred_large_splats_with_hysteresis(L):
-    """K1 lists its large splats for bin_large_kernel only while recent frames had enough of them to pay for the launch (256;
-    128 to let go again); nothing known yet, or a camera jump, keeps the list; the knob's 0 / negative force it on / off"""
+    """K1 lists its large splats for bin_large_kernel only while recent frames had enough of them to pay for the launch: 256
+    large splats (128 to let go again) for a frame the caller waits for or a camera in motion; for the asynchronous frames of a
+    camera AT REST -- where the frame rate is the binning chain's length -- 1024 splats OUTSIDE K1's window (512 to let go).
+    Nothing known yet, or a camera jump, keeps the list; the knob's 0 / negative force it on / off."""
     D = Driver(L)
     assert D.step(0.0).use_large_list == 1                 # nothing known
-    D.hints.update(sort_hint=1, hint_large=33)             # C2's bench pose
+    D.hints.update(sort_hint=1, hint_large=33, hint_window=5)      # C2's bench pose
     D.settle()
     assert D.log[-1].use_large_list == 0
+    # synchronous frames at rest: the count of large splats decides
     seen = []
     for n in (255, 256, 200, 128, 127, 255, 256):
         D.hints["hint_large"] = n
+        seen.append(D.step(0.0, awaited=1).use_large_list)
+    assert seen == [0, 1, 1, 1, 0, 0, 1]
+    # asynchronous frames at rest: the surface scene's bench pose (7000 over the threshold, 500 outside the window) keeps none,
+    # a camera parked inside the scene (thousands outside the window) does
+    D.hints.update(hint_large=7065, hint_window=513)
+    assert D.step(0.0).use_large_list == 1                 # (still on from the frame before: 513 >= 512, the letting-go threshold)
+    D.hints["hint_window"] = 511
+    assert D.step(0.0).use_large_list == 0
+    seen = []
+    for n in (1023, 1024, 600, 512, 511, 1023, 3065):
+        D.hints["hint_window"] = n
         seen.append(D.step(0.0).use_large_list)
     assert seen == [0, 1, 1, 1, 0, 0, 1]
-    D.hints["hint_large"] = 0
-    assert D.step(0.0).use_large_list == 0
-    assert D.step(1.5).use_large_list == 1                 # a jump (into the cloud, for all the host knows)
-    assert D.step(1.5).use_large_list == 0                 # ... and the frame behind it goes by what was counted again
-    d = D.step(1.5, one_pass=0)
+    # the same scene in motion (asynchronous): the count of large splats decides again
+    D.hints.update(hint_large=7065, hint_window=513)
+    a = 0.0
+    for _ in range(4):
+        a += 0.05
+        assert D.step(a).use_large_list == 1
+    D.hints.update(hint_large=0, hint_window=0)
+    assert D.step(a + 0.05).use_large_list == 0
+    assert D.step(a + 1.5).use_large_list == 1             # a jump (into the cloud, for all the host knows)
+    assert D.step(a + 1.5).use_large_list == 0             # ... and the frame behind it goes by what was counted again
+    d = D.step(a + 1.5, one_pass=0)
     assert d.use_large_list == 0                           # two-pass binning has no list
     for knob, want in ((0, 1), (-1, 0)):
         D2 = Driver(L, large_list_min=knob)
-        D2.hints.update(sort_hint=1, hint_large=100000 if knob < 0 else 0)
+        D2.hints.update(sort_hint=1, hint_large=100000 if knob < 0 else 0, hint_window=100000 if knob < 0 else 0)
         D2.settle()
-        assert D2.step(0.3).use_large_list == want and D2.step(2.0).use_large_list == want
+        assert D2.step(0.0).use_large_list == want and D2.step(0.3).use_large_list == want and D2.step(2.0).use_large_list == want
