@@ -44,6 +44,7 @@ typedef struct splat_policy_knobs {      /* the context's options that decisions
     int32_t pair_mode;                   /* SPLAT_OPT_PAIR_WALK: -1 auto, 0, 1 */
     int32_t pipeline;                    /* SPLAT_OPT_PIPELINE_DEPTH (0: everything on one stream) */
     int32_t tight_grids;                 /* debug: sort launches sized with no margin */
+    int32_t layout_motion;               /* 1: a moving camera's regions are sized from the lists around each tile (layout_radius); 0: from its own */
     int32_t large_list_min;              /* large splats (SPLAT_LARGE_TILES) a recent frame must have had for frames to keep a large list:
                                             0 = always, < 0 = never (K1's blocks expand close-ups themselves).  An asynchronous frame
                                             of a camera AT REST keeps it only from four times as many splats outside K1's window */
@@ -109,6 +110,9 @@ typedef struct splat_policy_decision {
     uint32_t grid_big, grid_mid, grid_long;   /* prefixes of the longest-first order the sort launches cover */
     int32_t pair_walk;
     int32_t use_large_list;              /* K1 lists its large splats and bin_large_kernel bins them tile by tile (else K1 expands them itself) */
+    int32_t layout_radius;               /* tiles: the regions this frame's scan builds (for the frame two on) are sized from the longest
+                                            list within this distance of each tile; 0 = from the tile's own list (camera at rest, a jump) */
+    int32_t reserved;
     splat_policy_state next;
 } splat_policy_decision;
 

@@ -202,6 +202,7 @@ struct splat_ctx {
     // One-pass binning: splats of more tiles than this (and every splat wider or taller than K1's 32 x 32-tile window) go to the
     // frame's large list and are binned tile by tile behind K1 (bin_large_kernel).  SPLAT_LARGE_TILES: 0 = the window alone
     // decides, < 0 = no list at all (K1's blocks expand close-ups themselves, one atomic per pair: the round-5 path).
+    int layout_motion = 1;               // SPLAT_LAYOUT_MOTION=0: regions always sized from each tile's own list (round 6)
     int large_list_min = 256;            // SPLAT_LARGE_LIST_MIN: large splats a recent frame must have had for frames to keep the list (splat_policy.h)
     int large_tiles = 128;               // (C2 / C3 / C5, bench pose and from inside: 96-128 best of 0..1024, profiles/r07_large_splats.txt)
     int count_first = 1;                   // SPLAT_OPT_COUNT_FIRST: 0 only slots without a layout; 1 + the 64 moving frames behind a run of frames that outgrew
@@ -717,7 +718,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         pk.start_hints = c->start_hints; pk.count_first = c->count_first; pk.overflow_redo = c->overflow_redo; pk.early_min = c->early_min;
         pk.early_eps = c->early_eps; pk.near_cap = c->near_cap; pk.fused_sort_max = c->fused_sort_max; pk.sort_in_comp = c->sort_in_comp;
         pk.pair_mode = c->pair_mode; pk.pipeline = c->pipeline; pk.tight_grids = c->tight_grids ? 1 : 0;
-        pk.large_list_min = c->large_tiles < 0 ? -1 : c->large_list_min;
+        pk.large_list_min = c->large_tiles < 0 ? -1 : c->large_list_min; pk.layout_motion = c->layout_motion;
         splat_policy_input pi;
         std::memset(&pi, 0, sizeof pi);
         std::memcpy(pi.view, c->fc.view, sizeof pi.view); std::memcpy(pi.proj, c->fc.proj, sizeof pi.proj);
@@ -803,7 +804,8 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     const unsigned int near_cap = pd.near_cap;
     unsigned int* const off2 = c->fc.bucket_cap ? s.off2 : nullptr;        // (two-pass binning: the second buffer mirrors the first)
     launch_scan(bs, m, cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], layout,
-                next_layout, next_counts, c->region_spare, false, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull), s.large_count);
+                next_layout, next_counts, c->region_spare, false, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull), s.large_count,
+                (unsigned int)c->fc.tiles_x, (unsigned int)pd.layout_radius);
     const bool redo = pd.redo != 0;
     if (redo) {
         // OVERFLOW REDO.  The regions this frame was binned into were sized for another camera (two frames back on a moving
@@ -1324,6 +1326,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     }
     option_from_env(c, SPLAT_OPT_LARGE_SPLAT_TILES, "SPLAT_LARGE_TILES", -1, 1048576);
     option_from_env(c, SPLAT_OPT_LARGE_LIST_MIN, "SPLAT_LARGE_LIST_MIN", -1, 1e9);
+    if (const char* lm = std::getenv("SPLAT_LAYOUT_MOTION")) c->layout_motion = std::atoi(lm) != 0 ? 1 : 0;
     if (const char* k1 = std::getenv("SPLAT_SORT_RADIX_MIN")) c->knobs.sort_radix_min = (unsigned int)std::max(0, std::atoi(k1));
     if (const char* k2 = std::getenv("SPLAT_SCAN_THREADS")) c->knobs.scan_threads = std::atoi(k2);
     if (const char* k3 = std::getenv("SPLAT_DBG_NTILES")) c->knobs.dbg_ntiles = (unsigned int)std::max(0, std::atoi(k3));

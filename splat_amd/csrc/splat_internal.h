@@ -140,7 +140,9 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  unsigned int* off2 = nullptr /* one-pass binning: per tile, where its room in the SECOND key buffer starts -- handed out
                                                  by this scan to the lists of more than 2048 keys */,
                  unsigned int cap2 = 0 /* entries of the second key buffer: beyond it the frame is flagged (overflow 4) */,
-                 unsigned int* large_count = nullptr /* the frame's large-splat counter: reset here for the slot's next K1 */);
+                 unsigned int* large_count = nullptr /* the frame's large-splat counter: reset here for the slot's next K1 */,
+                 unsigned int tiles_x = 0, unsigned int motion_radius = 0 /* != 0 (a moving camera): the next frame's regions are sized from
+                                                 the longest list within this many tiles of each tile (build_layout) */);
 // the regions (and cursors) of the slot's next one-pass frame from this frame's lists; an all-zero `layout` with cursors
 // counted from zero is the bootstrap
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,

@@ -1222,9 +1222,49 @@ template <int NT>
 __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int* __restrict__ counts, const unsigned int* __restrict__ layout,
                                              unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
                                              unsigned int key_entries, FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status,
-                                             unsigned long long* wsum /* LDS, NT / 64 */, float spare_max) {
+                                             unsigned long long* wsum /* LDS, NT / 64 */, float spare_max,
+                                             unsigned int tiles_x = 0u, unsigned int motion_radius = 0u, unsigned short* mv = nullptr /* LDS, 2 m entries */) {
     const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned int C = (m + NT - 1u) / NT, k0 = min(tid * C, m), k1 = min(k0 + C, m);
+    // A MOVING camera (motion_radius > 0 tiles: how far the image shifts until the frame that will use these regions): a tile's
+    // margin is sized from the longest list within that distance, not from its own -- the list that will be over this tile two
+    // frames on is over a neighbour now.  (Sized from its own list, a tile beside a surface got 512 keys of room x the spare
+    // factor and the surface's 10 000-key list two frames later: on the trained-like scene at 3 degrees a frame nearly every
+    // frame outgrew its regions and paid a count pass or a second binning.)  Separable maximum through LDS: rows, then columns;
+    // lengths saturate at 65535 keys.  mv[0 .. m) ends up holding the filtered length of every tile.
+    const bool moving = motion_radius != 0u && mv != nullptr && tiles_x != 0u;
+    if (moving) {
+        unsigned short* const raw = mv;
+        unsigned short* const hmx = mv + m;
+        for (unsigned int k = tid; k < m; k += NT) raw[k] = (unsigned short)min(counts[k] - layout[k], 65535u);
+        __syncthreads();
+        const int R = (int)motion_radius, TX = (int)tiles_x, TY = (int)((m + tiles_x - 1u) / tiles_x);
+        // (fixed trip counts with clamped indices -- a duplicate does not change a maximum -- so that the 25 LDS reads of a tile
+        // are all in flight: as loops to the window's ends they were a chain of dependent reads, 0.1 ms of the scan's launch
+        // beside a busy compositor)
+        constexpr int RMAX = 12;
+        for (unsigned int k = tid; k < m; k += NT) {
+            const int ty = (int)(k / tiles_x), tx = (int)(k - (unsigned int)ty * tiles_x);
+            const int lo = max(tx - R, 0), hi = min(tx + R, TX - 1), row = ty * TX;
+            unsigned int v = 0u;
+#pragma unroll
+            for (int dx = -RMAX; dx <= RMAX; ++dx) v = max(v, (unsigned int)raw[row + min(max(tx + dx, lo), hi)]);
+            hmx[k] = (unsigned short)v;
+        }
+        __syncthreads();
+        const int last = (int)m - 1;
+        for (unsigned int k = tid; k < m; k += NT) {
+            const int ty = (int)(k / tiles_x), tx = (int)(k - (unsigned int)ty * tiles_x);
+            const int lo = max(ty - R, 0), hi = min(ty + R, TY - 1);
+            unsigned int v = 0u;
+#pragma unroll
+            for (int dy = -RMAX; dy <= RMAX; ++dy) v = max(v, (unsigned int)hmx[min(min(max(ty + dy, lo), hi) * TX + tx, last)]);
+            raw[k] = (unsigned short)v;            // (every thread reads hmx only: raw is free to take the result)
+        }
+        __syncthreads();
+    }
+    // what a tile's REGION is sized from: its own list, or the longest list around it
+    auto sized_from = [&](unsigned int k, unsigned int len) -> unsigned int { return moving ? max(len, (unsigned int)mv[k]) : len; };
     // A thread's tiles are visited three times (sum of the regions; sum of the grown regions; offsets).  Up to 32 tiles per
     // thread (1080p with 256 threads) their regions stay in registers after the first visit; more are re-read, eight
     // tiles' loads in flight at a time -- the kernel is a chain of round trips to L2 otherwise, and the scan's launch
@@ -1273,7 +1313,7 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
     // in units of 64 keys, 32 bits each: 2^38 keys)
     auto exact_for = [](unsigned int len) -> unsigned int { return (len + 63u) & ~63u; };
     unsigned long long local = 0, both = 0;
-    each_len([&](unsigned int, unsigned int len) { local += ((unsigned long long)(region_for(len) >> 6) << 32) | (unsigned long long)(exact_for(len) >> 6); });
+    each_len([&](unsigned int k, unsigned int len) { local += ((unsigned long long)(region_for(sized_from(k, len)) >> 6) << 32) | (unsigned long long)(exact_for(len) >> 6); });
     (void)block_scan(local, both);
     const unsigned long long total = (both >> 32) << 6, total_exact = (both & 0xffffffffull) << 6;
     // The buffer is there: what the regions do not ask for is handed out in proportion (up to four times a region's
@@ -1285,24 +1325,34 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
     const float spare = total ? fminf(spare_max, (float)key_entries / (float)total) : 1.0f;
     const bool squeeze = total > (unsigned long long)key_entries && total_exact <= (unsigned long long)key_entries;
     const float keep_frac = squeeze ? (float)((unsigned long long)key_entries - total_exact) / (float)(total - total_exact) * (1.0f - 1.0f / 1048576.0f) : 0.0f;
-    auto grown = [&](unsigned int len) -> unsigned int {
-        const unsigned int r = region_for(len);
+    auto grown = [&](unsigned int k, unsigned int len) -> unsigned int {
+        const unsigned int r = region_for(sized_from(k, len));
         if (squeeze) { const unsigned int e = exact_for(len); return e + ((unsigned int)((float)(r - e) * keep_frac) & ~63u); }   // (rounded down: the sum stays within key_entries)
         return spare > 1.0f ? max(r, (unsigned int)((float)r * spare) & ~63u) : r;    // (the sum stays within key_entries: every term is rounded down)
     };
     local = 0;
-    each_len([&](unsigned int, unsigned int len) { local += grown(len); });
+    each_len([&](unsigned int k, unsigned int len) { local += grown(k, len); });
     unsigned long long dummy;
     unsigned long long run = block_scan(local, dummy);
     each_len([&](unsigned int k, unsigned int len) {
         const unsigned int off = (unsigned int)min(run, (unsigned long long)key_entries);
         next_layout[k] = off; next_counts[k] = off;
-        run += grown(len);
+        run += grown(k, len);
     });
     if (tid == NT - 1u) next_layout[m] = (unsigned int)min(run, (unsigned long long)key_entries);      // (the last thread's run ends the last region)
+    // What the host grows the key buffer to is what the regions sized from each tile's OWN list ask for: the motion filter's
+    // larger margins live on the buffer's spare room and give way when there is none (squeeze), they are not a reason to make
+    // the buffer larger (the first build reported the filtered total: 48 M -> 110 M entries per slot on the surface scene).
+    unsigned long long reported = total;
+    if (moving) {
+        unsigned long long own = 0, all = 0;
+        each_len([&](unsigned int, unsigned int len) { own += (unsigned long long)(region_for(len) >> 6); });
+        (void)block_scan(own, all);
+        reported = all << 6;
+    }
     if (tid == 0u) {
-        if (status) status->layout_total = total;
-        if (host_status) host_status->layout_total = total;
+        if (status) status->layout_total = reported;
+        if (host_status) host_status->layout_total = reported;
     }
 }
 // (on its own: the bootstrap of a slot without a layout; otherwise the second workgroup of the scan's launch)
@@ -1333,7 +1383,8 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
                                                            unsigned int cls_in_lds, FrameStatus* __restrict__ host_status,
                                                            unsigned int* __restrict__ next_layout, unsigned int* __restrict__ next_counts,
                                                            unsigned int key_entries, float spare_max, unsigned int redo_only,
-                                                           unsigned int* __restrict__ off2, unsigned int cap2, unsigned int* __restrict__ large_count) {
+                                                           unsigned int* __restrict__ off2, unsigned int cap2, unsigned int* __restrict__ large_count,
+                                                           unsigned int tiles_x, unsigned int motion_radius) {
     constexpr int NCLS = 64;
     if (redo_only && status->overflow != 2u) return;       // (the second scan of a frame that was binned again: see enqueue_frame)
     // (the frame's large-splat list has been binned -- bin_large_kernel, in front of this launch: empty for the slot's next K1;
@@ -1344,7 +1395,9 @@ __global__ __launch_bounds__(SCAN_NT) void scan_bucket_kernel(unsigned int m, un
     // the same cursors, beside the scan: no launch of its own, nothing added to the chain K1 -> scan -> sort.
     if (blockIdx.x == 1u) {
         __shared__ unsigned long long lsum[SCAN_NT / 64];
-        build_layout<SCAN_NT>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, lsum, spare_max);
+        extern __shared__ unsigned char dyn_lds[];            // (the launch gives 4 m bytes when motion_radius != 0)
+        build_layout<SCAN_NT>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, lsum, spare_max,
+                              tiles_x, motion_radius, reinterpret_cast<unsigned short*>(dyn_lds));
         return;
     }
     __shared__ unsigned int row[SCAN_NT / 64][NCLS];
@@ -3258,7 +3311,7 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,
                  unsigned int bucket_cap, unsigned int grid_big, unsigned int grid_mid, unsigned int grid_long,
                  FrameStatus* host_status, const unsigned int* layout, unsigned int* next_layout, unsigned int* next_counts, float spare_max,
-                 bool redo_only, unsigned int* off2, unsigned int cap2, unsigned int* large_count) {
+                 bool redo_only, unsigned int* off2, unsigned int cap2, unsigned int* large_count, unsigned int tiles_x, unsigned int motion_radius) {
     if (bucket_cap && layout)
     {
         const unsigned int nwg = (next_layout && next_counts) ? 2u : 1u;
@@ -3266,16 +3319,21 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
         const int nt = g_knobs->scan_threads ? g_knobs->scan_threads : (m > 12000u ? 1024 : 256);
         // one byte of LDS per tile for the length classes (up to 48 KB: a 6-megapixel target), else they are re-read
         const unsigned int cls_bytes = (m + 15u) & ~15u, in_lds = cls_bytes <= 49152u ? 1u : 0u;
-        const unsigned int dyn = in_lds ? cls_bytes : 0u;
+        // (the layout workgroup's motion filter: two u16 per tile -- up to 12 288 tiles, a 1440p target; larger ones keep the
+        // regions sized from each tile's own list)
+        const unsigned int mv_bytes = (4u * m + 15u) & ~15u;
+        if (nwg < 2u || mv_bytes > 49152u || tiles_x == 0u) motion_radius = 0u;
+        motion_radius = std::min(motion_radius, 12u);          // (build_layout's window: RMAX)
+        const unsigned int dyn = std::max(in_lds ? cls_bytes : 0u, motion_radius ? mv_bytes : 0u);
         if (nt == 256)
             hipLaunchKernelGGL(scan_bucket_kernel<256>, dim3(nwg), dim3(256), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count, tiles_x, motion_radius);
         else if (nt == 512)
             hipLaunchKernelGGL(scan_bucket_kernel<512>, dim3(nwg), dim3(512), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count, tiles_x, motion_radius);
         else
             hipLaunchKernelGGL(scan_bucket_kernel<1024>, dim3(nwg), dim3(1024), dyn, s, m, counts, offsets, order, lens, status, layout,
-                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count);
+                               grid_big, grid_mid, grid_long, in_lds, host_status, next_layout, next_counts, bucket_cap, spare_max, redo_only ? 1u : 0u, off2, cap2, large_count, tiles_x, motion_radius);
     }
     else
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, m, counts, offsets, cursor, order, lens, status, capacity,

@@ -73,7 +73,7 @@ void splat_policy_default_knobs(splat_policy_knobs* k) {
     std::memset(k, 0, sizeof *k);
     k->start_hints = 2; k->count_first = 1; k->overflow_redo = 1; k->early_min = 768; k->early_eps = 1e-6f;
     k->near_cap = 2048u; k->fused_sort_max = 2048u; k->sort_in_comp = -1; k->pair_mode = -1; k->pipeline = 6; k->tight_grids = 0;
-    k->large_list_min = 256;
+    k->large_list_min = 256; k->layout_motion = 1;
 }
 
 void splat_policy_struct_sizes(uint64_t sizes[4]) {
@@ -221,6 +221,15 @@ int splat_policy_decide(const splat_policy_knobs* kp, const splat_policy_state* 
     else if (sp->large_on) st.large_on = have >= need / 2u ? 1u : 0u;
     else st.large_on = have >= need ? 1u : 0u;
     d.use_large_list = (int32_t)st.large_on;
+    // ---- the regions this frame's scan sizes are used two frames on (the chains of consecutive frames alternate between two
+    // streams; one frame on with a shallower pipeline): by then a moving camera has shifted the image by about that many steps of
+    // delta * focal pixels.  A tile's region is sized from the longest list within that distance (build_layout), so that the list
+    // that slides over it finds room -- not after a jump (the lists to come have nothing to do with these) and not at rest.
+    {
+        const float ahead = k.pipeline >= 6 ? 2.0f : 1.0f;
+        const float shift = ahead * delta * in.focal / (float)TILE_PX;            // tiles
+        d.layout_radius = (k.layout_motion != 0 && in.one_pass && !d.cam_jumped && shift >= 0.5f) ? std::min(12, (int)std::ceil(shift) + 1) : 0;
+    }
     *out = d;
     return 0;
 }

@@ -23,7 +23,7 @@ DELTA_SLOW, DELTA_CREEP, DELTA_JUMP = 0.009, 0.003, 0.2
 class Knobs(C.Structure):
     _fields_ = [("start_hints", C.c_int32), ("count_first", C.c_int32), ("overflow_redo", C.c_int32), ("early_min", C.c_int32),
                 ("early_eps", C.c_float), ("near_cap", C.c_uint32), ("fused_sort_max", C.c_uint32), ("sort_in_comp", C.c_int32),
-                ("pair_mode", C.c_int32), ("pipeline", C.c_int32), ("tight_grids", C.c_int32), ("large_list_min", C.c_int32)]
+                ("pair_mode", C.c_int32), ("pipeline", C.c_int32), ("tight_grids", C.c_int32), ("layout_motion", C.c_int32), ("large_list_min", C.c_int32)]
 
 
 class State(C.Structure):
@@ -50,7 +50,7 @@ class Decision(C.Structure):
                 ("start_light", C.c_int32), ("early_min", C.c_int32), ("hint_radius", C.c_int32), ("count_first", C.c_int32),
                 ("moved", C.c_int32), ("redo", C.c_int32), ("ring_kind", C.c_int32), ("solo", C.c_int32), ("comp_sorts", C.c_int32),
                 ("near_cap", C.c_uint32), ("select_grid", C.c_uint32), ("grid_big", C.c_uint32), ("grid_mid", C.c_uint32),
-                ("grid_long", C.c_uint32), ("pair_walk", C.c_int32), ("use_large_list", C.c_int32), ("next", State)]
+                ("grid_long", C.c_uint32), ("pair_walk", C.c_int32), ("use_large_list", C.c_int32), ("layout_radius", C.c_int32), ("reserved", C.c_int32), ("next", State)]
 
 
 @pytest.fixture(scope="module")
@@ -554,3 +554,35 @@ def test_large_list_is_kept_from_a_few_hundred_large_splats_with_hysteresis(L):
         D2.hints.update(sort_hint=1, hint_large=100000 if knob < 0 else 0, hint_window=100000 if knob < 0 else 0)
         D2.settle()
         assert D2.step(0.0).use_large_list == want and D2.step(0.3).use_large_list == want and D2.step(2.0).use_large_list == want
+
+
+def test_layout_radius_follows_the_cameras_motion(L):
+    """the regions a frame's scan builds are used two frames on: a moving camera's are sized from the longest list within the
+    distance the image shifts until then (2 x delta x focal / 16 tiles, + 1, at most 12); at rest, after a jump, with a shallow
+    shift (under half a tile) or switched off: from each tile's own list"""
+    D = Driver(L)
+    D.settle()
+    assert D.log[-1].layout_radius == 0
+    d = D.step(0.0005)                       # 0.0005 rad x 540 px x 2 / 16 = 0.03 tiles
+    assert d.layout_radius == 0
+    d = D.step(0.0005 + math.radians(1.0))   # a degree: 2 x 0.01745 x 540 / 16 = 1.18 tiles -> 2 + 1
+    assert d.layout_radius == 3, d.layout_radius
+    a = 0.02
+    seen = []
+    for _ in range(3):
+        a += math.radians(3.0)
+        seen.append(D.step(a).layout_radius)
+    assert all(4 <= r <= 5 for r in seen), seen       # 3 degrees: 3.5 tiles -> 4 + 1
+    a += math.radians(10.0)
+    assert D.step(a).layout_radius == 12              # capped
+    a += 2.0
+    d = D.step(a)
+    assert d.cam_jumped == 1 and d.layout_radius == 0
+    assert D.step(a).layout_radius == 0               # at rest again
+    D1 = Driver(L, pipeline=2)
+    D1.settle()
+    assert D1.step(math.radians(1.0)).layout_radius == 2      # one frame ahead: 0.59 tiles -> 1 + 1
+    D0 = Driver(L, layout_motion=0)
+    D0.settle()
+    assert D0.step(math.radians(3.0)).layout_radius == 0
+    assert D.step(a + 0.05, one_pass=0).layout_radius == 0

@@ -165,3 +165,48 @@ def test_count_only_pass_counts_the_large_splats():
         assert r.frames_dropped() == 0
     finally:
         r.close()
+
+
+def test_motion_sized_regions_change_no_pixel_and_lose_no_frame():
+    """A moving camera's tile regions are sized from the longest list AROUND each tile (build_layout's motion filter,
+    SPLAT_LAYOUT_MOTION; the radius is the frame policy's layout_radius).  Where the keys land in the buffer is all that changes:
+    an asynchronous yaw path at 2 and 8 degrees a frame gives the same bytes with the filter on and off, frame for frame, and
+    with the overflow redo on every moving frame nothing is dropped either way."""
+    g = closeup_scene(60000, 80)
+    h, w = 368, 640
+    out = {}
+    for lm in (0, 1):
+        r = renderer(None, SPLAT_LAYOUT_MOTION=lm, SPLAT_REGION_SPARE=1)
+        try:
+            r.set_option(_lib.OPT_OVERFLOW_REDO, 2)
+            g.compute_cov3d(r)
+            r.upload(g)
+            cam = splat_amd.Camera(h, w, (0.0, 0.0, 2.2))
+            poses = []
+            for k in range(40):
+                cam.update_camera_pose()
+                poses.append(cam.to_c(0.01))
+                cam.update_yaw_angle(np.radians(2.0 if k < 20 else 8.0))
+            imgs = [r.device_image(np.zeros((h, w), np.uint32)) for _ in poses]
+            d0 = r.frames_dropped()
+            for c, p in zip(poses, imgs):
+                r.render_frame_device(c, p)
+            r.sync()
+            assert r.frames_dropped() == d0
+            out[lm] = [r.device_download(p, h, w) for p in imgs]
+            for p in imgs:
+                r.device_free(p)
+        finally:
+            r.close()
+    assert any(f.any() for f in out[0])
+    for k, (a, b) in enumerate(zip(out[0], out[1])):
+        assert np.array_equal(a, b), k
+    # ... and the frames are the oracle's (every tenth pose)
+    cam = splat_amd.Camera(h, w, (0.0, 0.0, 2.2))
+    for k in range(40):
+        cam.update_camera_pose()
+        if k % 10 == 0:
+            ref, _ = O.render(scene_dict(g), oracle_camera(cam, 0.01), O.default_conventions(), np.zeros((h, w), np.uint32), nthreads=8)
+            mx, cnt = image_diff(out[1][k], ref)
+            assert mx <= 1 and cnt <= 1e-3 * h * w, (k, mx, cnt)
+        cam.update_yaw_angle(np.radians(2.0 if k < 20 else 8.0))
