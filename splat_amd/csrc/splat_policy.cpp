@@ -229,6 +229,10 @@ int splat_policy_decide(const splat_policy_knobs* kp, const splat_policy_state* 
         const float ahead = k.pipeline >= 6 ? 2.0f : 1.0f;
         const float shift = ahead * delta * in.focal / (float)TILE_PX;            // tiles
         d.layout_radius = (k.layout_motion != 0 && in.one_pass && !d.cam_jumped && shift >= 0.5f) ? std::min(12, (int)std::ceil(shift) + 1) : 0;
+        // (a frame the caller waits for with nothing else in flight pays the filter on its own chain -- 15-35 us of the scan's
+        // launch, the reference's loop on C3 1670 -> 1565 frames/s when it ran unasked: there only while lists have been
+        // outgrowing their regions lately; under frames in flight it is hidden)
+        if (d.solo && st.redo_armed <= 0 && st.count_first_left <= 0) d.layout_radius = 0;
     }
     *out = d;
     return 0;

@@ -586,3 +586,23 @@ def test_layout_radius_follows_the_cameras_motion(L):
     D0.settle()
     assert D0.step(math.radians(3.0)).layout_radius == 0
     assert D.step(a + 0.05, one_pass=0).layout_radius == 0
+
+
+def test_a_solo_frame_sizes_for_motion_only_while_lists_have_been_outgrowing_their_regions(L):
+    """the motion filter costs a synchronous frame with nothing in flight 15-35 us of its own chain: it runs there only while the
+    redo launches are armed or a count-first run is on (lists HAVE outgrown regions lately); under frames in flight always"""
+    D = Driver(L)
+    D.settle()
+    a = math.radians(3.0)
+    assert D.step(a, awaited=1, idle=1).layout_radius == 0
+    a += math.radians(3.0)
+    assert D.step(a, awaited=1, idle=0).layout_radius >= 4        # not solo: something is in flight
+    a += math.radians(3.0)
+    assert D.step(a).layout_radius >= 4                           # asynchronous
+    D.st.redo_armed = 5
+    a += math.radians(3.0)
+    assert D.step(a, awaited=1, idle=1).layout_radius >= 4
+    D.st.redo_armed = 0
+    D.st.count_first_left = 3
+    a += math.radians(3.0)
+    assert D.step(a, awaited=1, idle=1).layout_radius >= 4
