@@ -119,7 +119,8 @@ int splat_policy_decide(const splat_policy_knobs* kp, const splat_policy_state* 
     // how far the image moved since the last frame, in tiles: a rotation by delta radians shifts the centre by focal * delta
     // pixels.  The near selection looks that far around a tile for what its walks may need: 2 tiles for a camera at rest, 7 for a
     // 10-degree step.
-    d.hint_radius = std::min(7, std::max(2, (int)std::ceil(delta * in.focal / (float)TILE_PX) + 1));
+    // (std::min(64.0f, x) is 64 for a NaN or infinite x -- a camera whose focal length is not a number: no undefined cast)
+    d.hint_radius = std::min(7, std::max(2, (int)std::min(64.0f, std::ceil(delta * in.focal / (float)TILE_PX)) + 1));
     // (at rest the scan is paid once, in the first frames after the camera stopped: lists from half the usual length take the
     // early-out then -- 384 instead of 768 keys: C3 3060 -> 3120 frames/s, below that nothing more)
     d.early_min = k.early_min;
@@ -228,7 +229,7 @@ int splat_policy_decide(const splat_policy_knobs* kp, const splat_policy_state* 
     {
         const float ahead = k.pipeline >= 6 ? 2.0f : 1.0f;
         const float shift = ahead * delta * in.focal / (float)TILE_PX;            // tiles
-        d.layout_radius = (k.layout_motion != 0 && in.one_pass && !d.cam_jumped && shift >= 0.5f) ? std::min(12, (int)std::ceil(shift) + 1) : 0;
+        d.layout_radius = (k.layout_motion != 0 && in.one_pass && !d.cam_jumped && shift >= 0.5f) ? std::min(12, (int)std::min(64.0f, std::ceil(shift)) + 1) : 0;
         // (a frame the caller waits for with nothing else in flight pays the filter on its own chain -- 15-35 us of the scan's
         // launch, the reference's loop on C3 1670 -> 1565 frames/s when it ran unasked: there only while lists have been
         // outgrowing their regions lately; under frames in flight it is hidden)

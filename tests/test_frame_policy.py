@@ -508,6 +508,11 @@ def test_slab_and_target_are_part_of_the_camera(L):
     i.lowpass = 0.01
     i.view[3] = float("nan")
     assert L.splat_policy_decide(k, st, i, d) == 0 and d.cam_jumped == 1 and d.cam_delta == 1.0
+    # ... and a focal length that is not a number decides nothing undefined
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        i.view[3] = 0.0
+        i.focal = bad
+        assert L.splat_policy_decide(k, st, i, d) == 0 and 2 <= d.hint_radius <= 7 and 0 <= d.layout_radius <= 12
 
 
 def test_large_list_is_kept_from_a_few_hundred_large_splats_with_hysteresis(L):
