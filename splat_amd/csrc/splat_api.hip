@@ -774,7 +774,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
             HIP_TRY(c, hipMemsetAsync(s.redo_cursors, 0, sizeof(unsigned int) * ((size_t)m + 1), bs));     // (the redo's buffer: a count-first frame has no redo)
             launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, c->zero_layout, true,
                               large_list, s.large_count);
-            launch_bin_large(bs, c->fc, large_list, s.large_count, s.redo_cursors, s.keys, d_st, true);
+            launch_bin_large(bs, c->fc, large_list, s.large_count, (unsigned int)c->n, s.redo_cursors, s.keys, d_st, true);
             launch_layout(bs, m, s.redo_cursors, c->zero_layout, into ? s.lay_b : s.lay_a, into ? s.counts_b : s.counts, c->fc.bucket_cap, nullptr, nullptr, c->region_spare,
                           nullptr, s.large_count);
             s.flip = into; s.layout_valid = true;
@@ -786,7 +786,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
     HIP_TRY(c, mark(0, bs));
     launch_preprocess(bs, c->n, c->planes, c->orig, c->fc, s.recs, s.depth, s.rect, cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, layout, false,
                       large_list, s.large_count);
-    if (c->fc.bucket_cap) launch_bin_large(bs, c->fc, large_list, s.large_count, cursors, s.keys, d_st, false);     // (the large splats K1 listed, tile by tile)
+    if (c->fc.bucket_cap) launch_bin_large(bs, c->fc, large_list, s.large_count, (unsigned int)c->n, cursors, s.keys, d_st, false);     // (the large splats K1 listed, tile by tile)
     HIP_TRY(c, mark(1, bs));
     c->grid_big = pd.grid_big; c->grid_mid = pd.grid_mid; c->grid_long = pd.grid_long;      // (what the sort launches cover; the scan validates)
     // (one-pass binning: a second workgroup of the scan's launch builds the regions of the NEXT frame on this binning
@@ -821,7 +821,7 @@ int enqueue_frame(splat_ctx* c, uint32_t* d_argb, bool timed, bool want_iters = 
         launch_layout(bs, m, cursors, layout, s.redo_layout, s.redo_cursors, c->fc.bucket_cap, nullptr, nullptr, c->region_spare, d_st);
         launch_preprocess(bs, c->n, c->planes, c->orig, fr, s.recs, s.depth, s.rect, s.redo_cursors, s.vislist, s.keys, c->bounds, s.blockinfo, d_st, s.redo_layout, false,
                           large_list, s.large_count);
-        launch_bin_large(bs, fr, large_list, s.large_count, s.redo_cursors, s.keys, d_st, false);
+        launch_bin_large(bs, fr, large_list, s.large_count, (unsigned int)c->n, s.redo_cursors, s.keys, d_st, false);
         launch_scan(bs, m, s.redo_cursors, s.offsets, s.cursor, s.order, s.lens, d_st, c->cap, c->fc.bucket_cap, c->grid_big, c->grid_mid, c->grid_long, &c->h_status[r], s.redo_layout,
                     nullptr, nullptr, c->region_spare, true, off2, (unsigned int)std::min<uint64_t>(c->cap2, 0xffffffffull), s.large_count);
     }

@@ -126,7 +126,7 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
                        uint4* large_list = nullptr, unsigned int* large_count = nullptr /* one-pass binning: the frame's list of large
                                                   splats (n entries) and its counter -- launch_bin_large behind this launch bins them */);
 // the large splats K1 listed, tile by tile (bin_large_kernel): same stream, right behind launch_preprocess; `cursors` as given to it
-void launch_bin_large(hipStream_t s, const FrameConst& fc, const uint4* large_list, const unsigned int* large_count, unsigned int* cursors,
+void launch_bin_large(hipStream_t s, const FrameConst& fc, const uint4* large_list, const unsigned int* large_count, unsigned int large_cap, unsigned int* cursors,
                       unsigned long long* keys, const FrameStatus* status, bool count_only);
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
                  unsigned int* order, unsigned int* lens, FrameStatus* status, unsigned long long capacity,

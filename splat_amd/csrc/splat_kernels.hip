@@ -436,8 +436,11 @@ struct BucketBinner {
         base = (unsigned int)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
         if (big) {
             const unsigned int at = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            if (at < large_cap)
-                large_list[at] = make_uint4((unsigned int)key, (unsigned int)(key >> 32), (unsigned int)tx0 | ((unsigned int)ty0 << 16), (unsigned int)tx1 | ((unsigned int)ty1 << 16));
+            if (at < large_cap) {          // two planes: rectangles, then keys (bin_large_kernel's filter reads the first only)
+                uint2* const rects = reinterpret_cast<uint2*>(large_list);
+                rects[at] = make_uint2((unsigned int)tx0 | ((unsigned int)ty0 << 16), (unsigned int)tx1 | ((unsigned int)ty1 << 16));
+                rects[(size_t)large_cap + at] = make_uint2((unsigned int)key, (unsigned int)(key >> 32));
+            }
         }
     }
     __device__ __forceinline__ static unsigned int hslot(int tx, int ty) { return (unsigned int)(((ty & (HASH_DIM - 1)) << HASH_BITS) | ((tx + 17 * ty) & (HASH_DIM - 1))); }
@@ -1041,84 +1044,117 @@ __global__ __launch_bounds__(256) void preprocess_kernel(uint64_t n, const float
 // Replaces the per-splat row loops of euc's rasteriser (src/pipelines.rs:80-84) for the splats that fill the screen.
 // COUNT: the count flavour's twin (adds the pairs to the counts, stores nothing).  A frame without large splats: every workgroup
 // reads one word and leaves.
-constexpr int LARGE_G = 4;                 // tiles per side of a workgroup's group
+constexpr int LARGE_G = 4;                 // tiles per side of a workgroup's group (2 / 6 / 8 measured: profiles/r07_bin_large_v2_ab.txt)
+typedef unsigned short LargeU16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pk_min_u16(unsigned int a, unsigned int b) {
+    return __builtin_bit_cast(unsigned int, __builtin_elementwise_min(__builtin_bit_cast(LargeU16x2, a), __builtin_bit_cast(LargeU16x2, b)));
+}
+__device__ __forceinline__ unsigned int pk_max_u16(unsigned int a, unsigned int b) {
+    return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(LargeU16x2, a), __builtin_bit_cast(LargeU16x2, b)));
+}
+// The list is two planes of large_cap entries: the tile rectangles {x0 | y0 << 16, x1 | y1 << 16} -- all the filter reads, 8 B an
+// entry, so that a third of a million entries (C5 from inside) stay in an XCD's L2 -- and behind them the keys {slot, depth key}.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void bin_large_kernel(const uint4* __restrict__ list, const unsigned int* __restrict__ count_p,
+__global__ __launch_bounds__(256) void bin_large_kernel(const uint4* __restrict__ list, const unsigned int* __restrict__ count_p, unsigned int large_cap,
                                                         unsigned int* __restrict__ cursors, unsigned long long* __restrict__ keys,
                                                         unsigned int bcap, int tiles_x, int tile_rows,
                                                         const FrameStatus* __restrict__ status, unsigned int redo_only) {
     if (redo_only && status->overflow != 2u) return;          // (a redo launch of a frame that needs none)
-    const unsigned int n = (unsigned int)__builtin_amdgcn_readfirstlane((int)*count_p);
+    const unsigned int n = min((unsigned int)__builtin_amdgcn_readfirstlane((int)*count_p), large_cap);
     if (n == 0u) return;
-    __shared__ unsigned int cnt[LARGE_G * LARGE_G];            // keys appended so far, per tile of the group
-    __shared__ unsigned int first[LARGE_G * LARGE_G];          // the tile's cursor when this launch began
-    __shared__ uint4 queue[4][128];                            // per wave: entries that meet the group, waiting for a full batch
+    const uint2* __restrict__ const rects = reinterpret_cast<const uint2*>(list);
+    const uint2* __restrict__ const lkeys = rects + large_cap;
+    constexpr int NT = LARGE_G * LARGE_G;
+    constexpr int CH = 8;                                      // tiles handled at a time: their ballots live in scalar registers (16: 42 of them spilled)
+    static_assert(NT % CH == 0, "tiles of a group are handled CH at a time");
+    __shared__ unsigned int cnt[NT];                           // keys appended so far, per tile of the group
+    __shared__ unsigned int first[NT];                         // the tile's cursor when this launch began
+    __shared__ uint4 queue[4][128];                            // per wave: {rectangle, entry} that meet the group, waiting for a full batch
     const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int groups_x = (tiles_x + LARGE_G - 1) / LARGE_G;
     const int gx = (int)(blockIdx.x % (unsigned int)groups_x), gy = (int)(blockIdx.x / (unsigned int)groups_x);
     const int tx_lo = gx * LARGE_G, ty_lo = gy * LARGE_G;
     const int tx_hi = min(tx_lo + LARGE_G - 1, tiles_x - 1), ty_hi = min(ty_lo + LARGE_G - 1, tile_rows - 1);
-    if (tid < (unsigned int)(LARGE_G * LARGE_G)) {
+    if (tid < (unsigned int)NT) {
         const int tx = tx_lo + (int)(tid % LARGE_G), ty = ty_lo + (int)(tid / LARGE_G);
         first[tid] = (tx <= tx_hi && ty <= ty_hi) ? cursors[ty * tiles_x + tx] : 0u;
         cnt[tid] = 0u;
     }
     __syncthreads();
     uint4* const q = queue[wave];
-    // the keys of up to 64 queued entries, tile by tile: a ballot finds the entries that cover the tile, one LDS atomic reserves
-    // their run behind the tile's cursor
+    // The keys of up to 64 queued entries, eight tiles at a time: eight ballots find the entries that cover each tile, lane u
+    // reserves tile u's run behind its cursor -- ONE LDS atomic instruction for the eight (one per tile and batch, one after the
+    // other, was a chain of sixteen LDS round trips a batch) -- and the covering lanes store their keys.
     auto flush = [&](unsigned int k) {
-        const uint4 e = lane < k ? q[lane] : make_uint4(0u, 0u, 0xffffffffu, 0u);       // (x0 = y0 = 65535: covers nothing)
-        const int x0 = (int)(e.z & 0xffffu), y0 = (int)(e.z >> 16), x1 = (int)(e.w & 0xffffu), y1 = (int)(e.w >> 16);
+        const uint4 e = lane < k ? q[lane] : make_uint4(0xffffffffu, 0u, 0u, 0u);       // (x0 = y0 = 65535: covers nothing)
+        uint2 kk = make_uint2(0u, 0u);
+        if constexpr (!COUNT) { if (lane < k) kk = lkeys[e.z]; }
 #pragma unroll
-        for (int t = 0; t < LARGE_G * LARGE_G; ++t) {
-            const int tx = tx_lo + t % LARGE_G, ty = ty_lo + t / LARGE_G;
-            const bool c = x0 <= tx && tx <= x1 && y0 <= ty && ty <= y1;           // (x1 < tiles_x, y1 < tile_rows: a tile beyond the grid is never covered)
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
-            if (m == 0ull) continue;
-            unsigned int b = 0u;
-            if (lane == (unsigned int)__builtin_ctzll(m)) b = atomicAdd(&cnt[t], (unsigned int)__builtin_popcountll(m));
+        for (int c0 = 0; c0 < NT; c0 += CH) {
+            unsigned long long m[CH];
+            unsigned int mine = 0u, cbits = 0u;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const unsigned int tp = (unsigned int)(tx_lo + (c0 + u) % LARGE_G) | ((unsigned int)(ty_lo + (c0 + u) / LARGE_G) << 16);
+                // x0 <= tx && y0 <= ty && tx <= x1 && ty <= y1   (x1 < tiles_x, y1 < tile_rows: a tile beyond the grid is never covered)
+                const bool c = pk_max_u16(e.x, tp) == tp && pk_min_u16(e.y, tp) == tp;
+                m[u] = __builtin_amdgcn_ballot_w64(c);
+                if (lane == (unsigned int)u) mine = (unsigned int)__builtin_popcountll(m[u]);
+                cbits |= c ? (1u << u) : 0u;
+            }
+            unsigned int base = 0u;
+            if (lane < (unsigned int)CH) base = first[c0 + lane] + (mine ? atomicAdd(&cnt[c0 + lane], mine) : 0u);
             if constexpr (!COUNT) {
-                b = (unsigned int)__builtin_amdgcn_readlane((int)b, __builtin_ctzll(m));
-                if (c) {
-                    const unsigned int pos = first[t] + b + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                    if (pos < bcap) keys[pos] = ((unsigned long long)e.y << 32) | (unsigned long long)e.x;      // (see BucketBinner::put_at)
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    if (m[u] == 0ull) continue;
+                    const unsigned int bt = (unsigned int)__builtin_amdgcn_readlane((int)base, u);
+                    if (cbits & (1u << u)) {
+                        const unsigned int pos = bt + __builtin_amdgcn_mbcnt_hi((unsigned int)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m[u], 0u));
+                        if (pos < bcap) keys[pos] = ((unsigned long long)kk.y << 32) | (unsigned long long)kk.x;      // (see BucketBinner::put_at)
+                    }
                 }
             }
         }
     };
+    const unsigned int hi_p = (unsigned int)tx_hi | ((unsigned int)ty_hi << 16), lo_p = (unsigned int)tx_lo | ((unsigned int)ty_lo << 16);
     unsigned int qn = 0u;                                      // entries in this wave's queue (uniform)
-    for (unsigned int i0 = wave * 64u; i0 < n; i0 += 256u) {   // (wave w takes entries [64 w + 256 j, + 64): the four waves never meet)
-        const unsigned int i = i0 + lane;
-        uint4 e = make_uint4(0u, 0u, 0u, 0u);
-        bool pass = false;
-        if (i < n) {
-            e = list[i];
-            const int x0 = (int)(e.z & 0xffffu), y0 = (int)(e.z >> 16), x1 = (int)(e.w & 0xffffu), y1 = (int)(e.w >> 16);
-            pass = x0 <= tx_hi && x1 >= tx_lo && y0 <= ty_hi && y1 >= ty_lo;
+    constexpr int AHEAD = 4;                                   // rectangles a lane has in flight
+    for (unsigned int i0 = wave * 64u; i0 < n; i0 += 256u * AHEAD) {   // (wave w takes entries [64 w + 256 j, + 64): the four waves never meet)
+        uint2 r[AHEAD];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) {
+            const unsigned int i = i0 + 256u * a + lane;
+            r[a] = i < n ? rects[i] : make_uint2(0xffffffffu, 0u);
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-        if (m == 0ull) continue;
-        if (pass) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = e;
-        qn += (unsigned int)__builtin_popcountll(m);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (qn >= 64u) {
-            flush(64u);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint4 rest = q[64u + lane];                  // (at most 63 are left: they move to the front)
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) {
+            const unsigned int i = i0 + 256u * a + lane;
+            // x0 <= tx_hi && y0 <= ty_hi && x1 >= tx_lo && y1 >= ty_lo
+            const bool pass = pk_min_u16(r[a].x, hi_p) == r[a].x && pk_max_u16(r[a].y, lo_p) == r[a].y;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            if (m == 0ull) continue;
+            if (pass) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = make_uint4(r[a].x, r[a].y, i, 0u);
+            qn += (unsigned int)__builtin_popcountll(m);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            qn -= 64u;
-            if (lane < qn) q[lane] = rest;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (qn >= 64u) {
+                flush(64u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint4 rest = q[64u + lane];                  // (at most 63 are left: they move to the front)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                qn -= 64u;
+                if (lane < qn) q[lane] = rest;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     if (qn != 0u) flush(qn);
     __syncthreads();
-    if (tid < (unsigned int)(LARGE_G * LARGE_G)) {
+    if (tid < (unsigned int)NT) {
         const int tx = tx_lo + (int)(tid % LARGE_G), ty = ty_lo + (int)(tid / LARGE_G);
         if (tx <= tx_hi && ty <= ty_hi && cnt[tid] != 0u) cursors[ty * tiles_x + tx] = first[tid] + cnt[tid];
     }
@@ -3296,15 +3332,15 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
     else if (fc.corrected) go(preprocess_kernel<false, true>);
     else go(preprocess_kernel<false, false>);
 }
-void launch_bin_large(hipStream_t s, const FrameConst& fc, const uint4* large_list, const unsigned int* large_count, unsigned int* cursors,
+void launch_bin_large(hipStream_t s, const FrameConst& fc, const uint4* large_list, const unsigned int* large_count, unsigned int large_cap, unsigned int* cursors,
                       unsigned long long* keys, const FrameStatus* status, bool count_only) {
     if (!large_list || !large_count || !fc.bucket_cap || fc.tiles_x <= 0 || fc.n_tile_rows <= 0) return;
     const unsigned int groups = (unsigned int)((fc.tiles_x + LARGE_G - 1) / LARGE_G) * (unsigned int)((fc.n_tile_rows + LARGE_G - 1) / LARGE_G);
     if (count_only)
-        hipLaunchKernelGGL(bin_large_kernel<true>, dim3(groups), dim3(256), 0, s, large_list, large_count, cursors, keys, fc.bucket_cap, fc.tiles_x, fc.n_tile_rows,
+        hipLaunchKernelGGL(bin_large_kernel<true>, dim3(groups), dim3(256), 0, s, large_list, large_count, large_cap, cursors, keys, fc.bucket_cap, fc.tiles_x, fc.n_tile_rows,
                            status, fc.redo_only ? 1u : 0u);
     else
-        hipLaunchKernelGGL(bin_large_kernel<false>, dim3(groups), dim3(256), 0, s, large_list, large_count, cursors, keys, fc.bucket_cap, fc.tiles_x, fc.n_tile_rows,
+        hipLaunchKernelGGL(bin_large_kernel<false>, dim3(groups), dim3(256), 0, s, large_list, large_count, large_cap, cursors, keys, fc.bucket_cap, fc.tiles_x, fc.n_tile_rows,
                            status, fc.redo_only ? 1u : 0u);
 }
 void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned int* offsets, unsigned int* cursor,
