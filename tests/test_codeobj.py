@@ -84,6 +84,15 @@ def test_the_hot_compositor_touches_scratch_only_around_the_repair_call(kernels,
         assert not any(i.startswith("v_mfma") for i in ins)
 
 
+def test_the_large_list_kernel_keeps_its_ballots_in_scalar_registers(kernels):
+    # eight tiles' ballots at a time: sixteen spilled 42 scalar registers and was slower (profiles/r07_bin_large_v2_ab.txt)
+    for flav in ("<false>", "<true>"):
+        md = kernels["splat::bin_large_kernel" + flav][1]
+        assert md.get(".sgpr_spill_count", 0) == 0 and md.get(".vgpr_spill_count", 0) == 0, flav
+        assert md[".private_segment_fixed_size"] == 0 and md[".vgpr_count"] <= 64, flav
+        assert md[".group_segment_fixed_size"] <= 9 * 1024, flav
+
+
 def test_codeobj_tool_prints_a_table():
     if shutil.which("c++filt") is None:
         pytest.skip("c++filt missing")
