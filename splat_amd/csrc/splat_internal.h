@@ -16,6 +16,9 @@
 #ifndef SPLAT_EXP_K1DUMMY
 #define SPLAT_EXP_K1DUMMY 0    // K1: this many dummy VALU instructions per (Gaussian, tile) hand-out step (what per-pair verdicts would cost)
 #endif
+#ifndef SPLAT_EXP_SKIPFULL
+#define SPLAT_EXP_SKIPFULL 0   // near selection: lists of this many keys or more that need a full sort are left unsorted (what their sort costs a frame)
+#endif
 #ifndef SPLAT_EXP_SORT2
 #define SPLAT_EXP_SORT2 0      // compositor: the short lists' in-LDS sort run twice (what it costs)
 #endif

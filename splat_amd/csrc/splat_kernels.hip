@@ -3251,6 +3251,10 @@ __global__ __launch_bounds__(256) void select_near_kernel(const unsigned int* __
             __syncthreads();
         }
     }
+#if SPLAT_EXP_SKIPFULL
+    // timing experiment (frames invalid): lists that would be sorted in full, of SPLAT_EXP_SKIPFULL keys or more, are left alone
+    if (m == 0u && want >= n && n >= (unsigned int)SPLAT_EXP_SKIPFULL) { m = n; if (threadIdx.x == 0u) atomicAdd(&status->n_fallback, 1u); }
+#endif
     if (m == 0u)
         m = sort_long_list(smem, keys + beg, k2, n, want, radix_min, status, orig,
                            (deepest != 0u && deepest != 0xffffffffu) ? min(n, deepest + (deepest >> 3)) : 0u);
