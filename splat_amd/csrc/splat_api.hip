@@ -1337,6 +1337,7 @@ int splat_create(const splat_config* cfg, splat_ctx** out) {
     if (const char* k9 = std::getenv("SPLAT_DBG_HINT_RADIUS")) c->knobs.dbg_hint_radius = std::atoi(k9);
     if (const char* k5 = std::getenv("SPLAT_DBG_STARTS")) c->knobs.dbg_starts = std::atoi(k5) != 0 ? 1u : 0u;
     if (const char* k4 = std::getenv("SPLAT_COMP_LDS_PAD")) c->knobs.comp_lds_pad = (unsigned int)std::max(0, std::atoi(k4));
+    if (const char* k1p = std::getenv("SPLAT_K1_LDS_PAD")) c->knobs.k1_lds_pad = (unsigned int)std::min(48 * 1024, std::max(0, std::atoi(k1p)));
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         splat_destroy(c);

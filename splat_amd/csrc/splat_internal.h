@@ -107,6 +107,7 @@ struct LaunchKnobs {
     int scan_threads = 0;                  // 0: by the tile count
     unsigned int dbg_ntiles = 0;           // != 0: composite only the N longest tiles
     unsigned int comp_lds_pad = 0;         // extra dynamic LDS per compositor workgroup (an occupancy cap)
+    unsigned int k1_lds_pad = 0;           // SPLAT_K1_LDS_PAD: the same for K1 (lab: how K1's time depends on the blocks resident per CU)
     unsigned int dbg_select_stride = 0;    // SPLAT_DBG_SELECT_STRIDE: slots of the tile order per workgroup of the near selection's launch (default 8)
     unsigned long long dbg_keys2_entries = 0; // SPLAT_DBG_KEYS2_ENTRIES: initial size of a frame slot's second key buffer (tests force its growth)
     int dbg_hint_radius = -1;              // SPLAT_DBG_HINT_RADIUS: the near selection's neighbourhood, in tiles (default: by the camera's motion)

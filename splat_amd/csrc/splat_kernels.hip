@@ -3329,7 +3329,7 @@ void launch_preprocess(hipStream_t s, uint64_t n, const float4* planes, const un
     if (!blockinfo || !layout) fc.bucket_cap = 0;
     if (!large_count || !fc.bucket_cap) { large_list = nullptr; large_count = nullptr; }      // (a counter without a list: large splats are only counted)
     const dim3 grid(blocks_for(n, 256)), block(256);
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status, large_list, large_count); };
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, g_knobs->k1_lds_pad, s, n, planes, orig, fc, recs, depth, rect, counts, vislist, keys, bounds, blockinfo, status, large_list, large_count); };
     if (fc.bucket_cap && count_only) { if (fc.corrected) go(preprocess_kernel<true, true, true>); else go(preprocess_kernel<true, false, true>); }
     else if (fc.bucket_cap && fc.corrected) go(preprocess_kernel<true, true>);
     else if (fc.bucket_cap) go(preprocess_kernel<true, false>);
