@@ -1392,15 +1392,19 @@ __device__ __forceinline__ void build_layout(unsigned int m, const unsigned int*
     }
 }
 // (on its own: the bootstrap of a slot without a layout; otherwise the second workgroup of the scan's launch)
-__global__ __launch_bounds__(1024) void layout_kernel(unsigned int m, const unsigned int* __restrict__ counts,
+// (NT = 256 for the launch in a frame's overflow-redo chain: nine times in ten it reads one word and leaves, and a 16-wave
+// workgroup first waits for a CU with sixteen free wave slots on a chip the compositor fills -- 150 us median on the binning
+// chain of a moving camera's frame, rocprofv3 trace of tools/motion_probe.py; four waves find room at once)
+template <int NT>
+__global__ __launch_bounds__(NT) void layout_kernel(unsigned int m, const unsigned int* __restrict__ counts,
                                                       const unsigned int* __restrict__ layout, unsigned int* __restrict__ next_layout,
                                                       unsigned int* __restrict__ next_counts, unsigned int key_entries,
                                                       FrameStatus* __restrict__ status, FrameStatus* __restrict__ host_status, float spare_max,
                                                       const FrameStatus* __restrict__ redo_gate, unsigned int* __restrict__ large_count) {
-    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long wsum[NT / 64];
     if (redo_gate != nullptr && redo_gate->overflow != 2u) return;        // (a redo launch of a frame that needs none)
     if (large_count != nullptr && threadIdx.x == 0u) { large_count[0] = 0u; large_count[1] = 0u; }   // (a count-first frame: its count pass's list has been counted; empty for its K1)
-    build_layout<1024>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, wsum, spare_max);
+    build_layout<NT>(m, counts, layout, next_layout, next_counts, key_entries, status, host_status, wsum, spare_max);
 }
 
 // The scan of one-pass binning has no prefix sum to do (a list starts at its bucket): lengths, the
@@ -3382,7 +3386,10 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
                    unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max,
                    const FrameStatus* redo_gate, unsigned int* large_count) {
-    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max, redo_gate, large_count);
+    if (redo_gate != nullptr)
+        hipLaunchKernelGGL(layout_kernel<256>, dim3(1), dim3(256), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max, redo_gate, large_count);
+    else
+        hipLaunchKernelGGL(layout_kernel<1024>, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max, redo_gate, large_count);
 }
 void launch_emit(hipStream_t s, uint64_t n, FrameConst fc, const float* depth, const ushort4* rect, const unsigned int* orig,
                  const unsigned int* vislist, unsigned int* cursor, unsigned long long* keys, const FrameStatus* status) {
