@@ -860,6 +860,28 @@ def main():
                 prof_src = tj.get(args.workload + ":source")
             except Exception:
                 traffic = None
+        # the frame on the axis that bounds it: VALU wave-instructions of the frame's four kernels (committed
+        # counter pass) against this run's frame time on the chip's 1024 SIMDs
+        frame_valu = None
+        try:
+            wlj = json.load(open(tp)).get(args.workload, {}) if os.path.exists(tp) else {}
+            parts = {}
+            for kn, short in (("composite_exact_kernel<false, false, 2>", "composite"), ("preprocess_kernel<true, false, false>", "preprocess"),
+                              ("select_near_kernel", "select"), ("scan_bucket_kernel<256>", "scan")):
+                v = wlj.get(kn + ":detail", {}).get("valu_insts")
+                if v:
+                    parts[short] = float(v)
+            if "composite" in parts and "preprocess" in parts and world == 1 and args.mode == "exact" and not args.orbit:
+                tot_valu = sum(parts.values())
+                frame_valu = {"wave_instructions_per_frame": tot_valu, "by_kernel": parts, "simds": 1024, "clock_ghz": 2.4,
+                              "cycles_per_wave_instruction_per_simd": (dt / args.steps) * 2.4e9 * 1024 / tot_valu,
+                              "issue_cost_cycles": {"full_rate": "2.4-2.8", "half_rate": "4.1-4.4", "quarter_rate": "8.1", "compositor_mix": "~3.0"},
+                              "what": "SQ_INSTS_VALU per launch of the frame's kernels (profiles/%s_pmc_SQ.csv, the fixed-pose frame of this "
+                                      "workload) / this run's frame time on 1024 SIMDs at 2.4 GHz, beside the measured issue cost per instruction "
+                                      "class (tools/lab/valu_probe.hip, LAB_NOTEBOOK.md section 3): the pipelined frame runs at the chip's VALU "
+                                      "issue rate for its instruction mix" % (prof_src or "rNN")}
+        except Exception:
+            frame_valu = None
         traffic_live, traffic_note, live_all = False, None, None
         if world == 1 and not args.no_live_pmc:
             # bytes measured in THIS run: the context is idle now (the timed region and the legs are over); the two counter
@@ -928,6 +950,7 @@ def main():
                                "achieved": int(tot[2]) / (t_frame * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                                "frac": int(tot[2]) / (t_frame * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                               "valu": frame_valu,
                                "note": "B_alg / wall time per frame; kernels of consecutive frames overlap, so the sum of "
                                        "their durations exceeds the frame time"
                                        + ("; N > 1: the ranks' algorithmic bytes summed (every rank reads the whole scene in its "
