@@ -3386,7 +3386,7 @@ void launch_scan(hipStream_t s, unsigned int m, unsigned int* counts, unsigned i
 void launch_layout(hipStream_t s, unsigned int m, const unsigned int* counts, const unsigned int* layout, unsigned int* next_layout,
                    unsigned int* next_counts, unsigned int key_entries, FrameStatus* status, FrameStatus* host_status, float spare_max,
                    const FrameStatus* redo_gate, unsigned int* large_count) {
-    if (redo_gate != nullptr)
+    if (redo_gate != nullptr && m <= 12000u)        // (above that -- a 4K target -- the launch keeps its sixteen waves, as the scan does: when it does run, it runs long)
         hipLaunchKernelGGL(layout_kernel<256>, dim3(1), dim3(256), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max, redo_gate, large_count);
     else
         hipLaunchKernelGGL(layout_kernel<1024>, dim3(1), dim3(1024), 0, s, m, counts, layout, next_layout, next_counts, key_entries, status, host_status, spare_max, redo_gate, large_count);
